@@ -1,0 +1,325 @@
+"""Benchmark / fixture problem definitions (equations, constants and bounds only).
+
+Each function returns a fresh :class:`pycollo_amd.problem.ProblemSpec`.  Dynamics and bounds are
+restated from the reference's example scripts and unit-test fixtures (cited per function); none of
+the reference's front-end machinery is involved.  ``K``/``order`` set a uniform initial mesh.
+"""
+from __future__ import annotations
+
+import numpy as np
+import sympy as sym
+
+from ..problem import ProblemSpec
+
+
+def _mesh(ph, K, order):
+    ph.mesh.number_mesh_sections = K
+    ph.mesh.number_mesh_section_nodes = order
+
+
+def brachistochrone(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Betts ex. 4.10; examples/brachistochrone/brachistochrone.py:14-50,
+    tests/unit/conftest.py:14-76.  3 states, 1 control, tF free, objective tF."""
+    x, y, v, u = sym.symbols("x y v u")
+    prob = ProblemSpec("Brachistochrone")
+    ph = prob.new_phase("A")
+    ph.state_variables = [x, y, v]
+    ph.control_variables = [u]
+    grav = 9.81
+    ph.state_equations = [v * sym.sin(u), v * sym.cos(u), grav * sym.cos(u)]
+    prob.objective_function = ph.final_time_variable
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = [0, 10]
+    ph.bounds.state_variables = [[0, 10], [0, 10], [-50, 50]]
+    ph.bounds.control_variables = [[-np.pi / 2, np.pi / 2]]
+    ph.bounds.initial_state_constraints = {x: 0, y: 0, v: 0}
+    ph.bounds.final_state_constraints = {x: 2, y: 2}
+    _mesh(ph, K, order)
+    return prob
+
+
+def hypersensitive(K: int = 10, order: int = 4, *, test_fixture_bounds: bool = False) -> ProblemSpec:
+    """Betts ex. 4.4; examples/hypersensitive_problem/hypersensitive_problem.py:14-35.
+    ``test_fixture_bounds`` switches to the bounds of tests/unit/conftest.py:193-230."""
+    y, u = sym.symbols("y u")
+    prob = ProblemSpec("Hypersensitive problem")
+    ph = prob.new_phase("A")
+    ph.state_variables = [y]
+    ph.control_variables = [u]
+    ph.state_equations = [-y**3 + u]
+    ph.integrand_functions = [0.5 * (y**2 + u**2)]
+    prob.objective_function = ph.integral_variables[0]
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = 10000.0
+    if test_fixture_bounds:
+        ph.bounds.state_variables = [[0, 2]]
+        ph.bounds.control_variables = [[-1, 8]]
+        ph.bounds.integral_variables = [[0, 2000]]
+    else:
+        ph.bounds.state_variables = [[-50, 50]]
+        ph.bounds.control_variables = [[-50, 50]]
+        ph.bounds.integral_variables = [[0, 100000]]
+    ph.bounds.initial_state_constraints = [[1.0, 1.0]]
+    ph.bounds.final_state_constraints = [[1.5, 1.5]]
+    _mesh(ph, K, order)
+    return prob
+
+
+def cart_pole(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Kelly (2017) cart-pole swing-up; examples/cart_pole_swing_up/cart_pole_swing_up_explicit.py:22-77."""
+    q1, q2, q1d, q2d, q1dd, q2dd, F = sym.symbols("q1 q2 q1d q2d q1dd q2dd F")
+    m1, m2, l, g = sym.symbols("m1 m2 l g")
+    prob = ProblemSpec("Cart-Pole Swing-Up")
+    ph = prob.new_phase("A")
+    ph.state_variables = [q1, q2, q1d, q2d]
+    ph.control_variables = [F]
+    ph.state_equations = [q1d, q2d, q1dd, q2dd]
+    ph.integrand_functions = [F**2]
+    ph.bounds.initial_time = 0
+    ph.bounds.final_time = 2.0
+    ph.bounds.state_variables = {q1: [-2.0, 2.0], q2: [-10, 10], q1d: [-10, 10], q2d: [-10, 10]}
+    ph.bounds.control_variables = {F: [-20.0, 20.0]}
+    ph.bounds.integral_variables = [[0, 100]]
+    ph.bounds.initial_state_constraints = {q1: 0, q2: 0, q1d: 0, q2d: 0}
+    ph.bounds.final_state_constraints = {q1: 1.0, q2: np.pi, q1d: 0, q2d: 0}
+    s2, c2 = sym.sin(q2), sym.cos(q2)
+    prob.objective_function = ph.integral_variables[0]
+    prob.auxiliary_data = {
+        g: 9.81, l: 0.5, m1: 1.0, m2: 0.3,
+        q1dd: (l * m2 * s2 * q2d**2 + F + m2 * g * c2 * s2) / (m1 + m2 * (1 - c2**2)),
+        q2dd: -(l * m2 * c2 * s2 * q2d**2 + F * c2 + (m1 + m2) * g * s2) / (l * m1 + l * m2 * (1 - c2**2)),
+    }
+    _mesh(ph, K, order)
+    return prob
+
+
+def shuttle(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Betts ex. 6.1 maximum crossrange;
+    examples/space_shuttle_reentry_trajectory/space_shuttle_reentry_trajectory_maximum_crossrange.py:117-200.
+    6 states, 2 controls, tF free, objective -theta(tF)."""
+    h, phi, theta, nu, gamma, psi, alpha, beta = sym.symbols("h phi theta nu gamma psi alpha beta")
+    D, L, g, r, rho, rho_0, h_r, c_L, c_D = sym.symbols("D L g r rho rho_0 h_r c_L c_D")
+    Re, S, cl0, cl1, mu, cd0, cd1, cd2, m = sym.symbols("Re S c_lift_0 c_lift_1 mu c_drag_0 c_drag_1 c_drag_2 m")
+    prob = ProblemSpec("Space shuttle reentry trajectory maximum crossrange")
+    ph = prob.new_phase("A")
+    ph.state_variables = [h, phi, theta, nu, gamma, psi]
+    ph.control_variables = [alpha, beta]
+    cg, sg = sym.cos(gamma), sym.sin(gamma)
+    ph.state_equations = {
+        h: nu * sg,
+        phi: nu * cg * sym.sin(psi) / (r * sym.cos(theta)),
+        theta: nu * cg * sym.cos(psi) / r,
+        nu: -(D / m) - g * sg,
+        gamma: L * sym.cos(beta) / (m * nu) + cg * ((nu / r) - (g / nu)),
+        psi: L * sym.sin(beta) / (m * nu * cg) + nu * cg * sym.sin(psi) * sym.sin(theta) / (r * sym.cos(theta)),
+    }
+    prob.objective_function = -ph.final_state_variables[2]
+    prob.auxiliary_data = {
+        rho_0: 1.225570827014494, h_r: 7254.24, Re: 6371203.92, S: 249.9091776,
+        cl0: -0.2070, cl1: 1.6756, mu: 3.986031954093051e14,
+        cd0: 0.07854, cd1: -0.3529, cd2: 2.0400, m: 92079.2525560557,
+        D: 0.5 * c_D * S * rho * nu**2,
+        L: 0.5 * c_L * S * rho * nu**2,
+        g: mu / (r**2),
+        r: Re + h,
+        rho: rho_0 * sym.exp(-h / h_r),
+        c_L: cl0 + cl1 * alpha,
+        c_D: cd0 + cd1 * alpha + cd2 * alpha**2,
+    }
+    deg = np.pi / 180
+    ph.bounds.initial_time = [0.0, 0.0]
+    ph.bounds.final_time = [0.0, 3000.0]
+    ph.bounds.state_variables = {h: [0, 300000], phi: [-np.pi, np.pi], theta: [-70 * deg, 70 * deg],
+                                 nu: [10, 45000], gamma: [-80 * deg, 80 * deg], psi: [-np.pi, np.pi]}
+    ph.bounds.control_variables = {alpha: [-np.pi / 2, np.pi / 2], beta: [-np.pi / 2, deg]}
+    ph.bounds.initial_state_constraints = {h: 79248, phi: 0, theta: 0, nu: 7802.88, gamma: -1 * deg, psi: 90 * deg}
+    ph.bounds.final_state_constraints = {h: [24384, 24384], nu: [762, 762], gamma: [-5 * deg, -5 * deg]}
+    _mesh(ph, K, order)
+    return prob
+
+
+def delta_iii(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Betts ex. 6.15 Delta III ascent, 4 phases, 18 linkage constraints;
+    examples/delta_iii_launch_vehicle/delta_iii_launch_vehicle.py:198-459.
+    7 states, 3 controls, 2 path constraints per phase; all phase times fixed."""
+    r_x, r_y, r_z, v_x, v_y, v_z, m = sym.symbols("r_x r_y r_z v_x v_y v_z m")
+    u_x, u_y, u_z = sym.symbols("u_x u_y u_z")
+    D_x, D_y, D_z, T, xi, C_D, S, omega_E = sym.symbols("D_x D_y D_z T xi C_D S omega_E")
+    v_r_x, v_r_y, v_r_z, oxr_x, oxr_y, oxr_z = sym.symbols("v_r_x v_r_y v_r_z omega_x_r_x omega_x_r_y omega_x_r_z")
+    mu, R_E, psi_L, g_0, h_0, h, rho, rho_0 = sym.symbols("mu R_E psi_L g_0 h_0 h rho rho_0")
+    r_n, u_n, v_n, v_r_n, T_over_m = sym.symbols("r_vec_norm u_vec_norm v_vec_norm v_r_vec_norm T_over_m")
+
+    t_launch, t_sep_S, t_sep_1, t_sep_2, t_orbit = 0.0, 75.2, 150.4, 261.0, 961.0
+    m_tot_S, m_tot_1, m_tot_2 = 19290, 104380, 19300
+    m_prop_S, m_prop_1 = 17010, 95550
+    m_struct_S, m_struct_1 = 2280, 8830
+    T_eng_S, T_eng_1, T_eng_2 = 628500, 1083100, 110094
+    I_S, I_1, I_2 = 283.33364, 301.68776, 467.21311
+    tau_S, tau_1 = 75.2, 261
+    m_payload = 4164
+    m0_A = 9 * m_tot_S + m_tot_1 + m_tot_2 + m_payload
+    mF_A = m0_A - 6 * m_prop_S - (tau_S / tau_1) * m_prop_1
+    m0_B = mF_A - 6 * m_struct_S
+    mF_B = m0_B - 3 * m_prop_S - (tau_S / tau_1) * m_prop_1
+    m0_C = mF_B - 3 * m_struct_S
+    mF_C = m0_C - (1 - 2 * (tau_S / tau_1)) * m_prop_1
+    m0_D = mF_C - m_struct_1
+    mF_D = m_payload
+    R_E_val, psi_L_val, omega_val = 6378145.0, (28.5 / 180) * np.pi, 7.29211585e-5
+    g0_val = 9.80665
+
+    prob = ProblemSpec("Delta III Launch Vehicle Ascent Problem")
+    grav = -mu / (r_n**3)
+    phase_data = [
+        ("A", t_launch, t_sep_S, m0_A, mF_A, 6 * T_eng_S + T_eng_1, (1 / g0_val) * (6 * (T_eng_S / I_S) + T_eng_1 / I_1)),
+        ("B", t_sep_S, t_sep_1, m0_B, mF_B, 3 * T_eng_S + T_eng_1, (1 / g0_val) * (3 * (T_eng_S / I_S) + T_eng_1 / I_1)),
+        ("C", t_sep_1, t_sep_2, m0_C, mF_C, T_eng_1, T_eng_1 / (g0_val * I_1)),
+        ("D", t_sep_2, t_orbit, m0_D, mF_D, T_eng_2, T_eng_2 / (g0_val * I_2)),
+    ]
+    phases = []
+    for name, ta, tb, m_a, m_b, thrust, mdot in phase_data:
+        ph = prob.new_phase(name)
+        ph.state_variables = [r_x, r_y, r_z, v_x, v_y, v_z, m]
+        ph.control_variables = [u_x, u_y, u_z]
+        ph.state_equations = {r_x: v_x, r_y: v_y, r_z: v_z,
+                              v_x: grav * r_x + T_over_m * u_x + D_x / m,
+                              v_y: grav * r_y + T_over_m * u_y + D_y / m,
+                              v_z: grav * r_z + T_over_m * u_z + D_z / m,
+                              m: -xi}
+        ph.path_constraints = [u_n - 1, r_n - R_E]
+        ph.auxiliary_data = {T: thrust, xi: mdot}
+        ph.bounds.initial_time = ta
+        ph.bounds.final_time = tb
+        ph.bounds.state_variables = {r_x: [-2 * R_E_val, 2 * R_E_val], r_y: [-2 * R_E_val, 2 * R_E_val],
+                                     r_z: [-2 * R_E_val, 2 * R_E_val], v_x: [-10000, 10000],
+                                     v_y: [-10000, 10000], v_z: [-10000, 10000], m: [m_b, m_a]}
+        ph.bounds.control_variables = {u_x: [-1.1, 1.1], u_y: [-1.1, 1.1], u_z: [-1.1, 1.1]}
+        ph.bounds.path_constraints = [[0, 0], [0, "inf"]]
+        ph.bounds.initial_state_constraints = {m: m_a}
+        ph.bounds.final_state_constraints = {m: m_b}
+        _mesh(ph, K, order)
+        phases.append(ph)
+    A = phases[0]
+    A.bounds.initial_state_constraints = {r_x: R_E_val * np.cos(psi_L_val), r_y: 0, r_z: R_E_val * np.sin(psi_L_val),
+                                          v_x: 0, v_y: omega_val * R_E_val * np.cos(psi_L_val), v_z: 0, m: m0_A}
+    Dp = phases[3]
+    rf = Dp.final_state_variables
+    prob.objective_function = -(sym.sqrt(rf[0]**2 + rf[1]**2 + rf[2]**2) - R_E)
+    link = []
+    for a, b in zip(phases[:-1], phases[1:]):
+        for i in range(6):
+            link.append(a.final_state_variables[i] - b.initial_state_variables[i])
+    prob.endpoint_constraints = link
+    prob.bounds.endpoint_constraints = [0] * len(link)
+    prob.auxiliary_data = {
+        mu: 3.986012e14, R_E: R_E_val,
+        r_n: sym.sqrt(r_x**2 + r_y**2 + r_z**2),
+        v_n: sym.sqrt(v_x**2 + v_y**2 + v_z**2),
+        u_n: sym.sqrt(u_x**2 + u_y**2 + u_z**2),
+        D_x: -0.5 * C_D * S * rho * v_r_n * v_r_x,
+        D_y: -0.5 * C_D * S * rho * v_r_n * v_r_y,
+        D_z: -0.5 * C_D * S * rho * v_r_n * v_r_z,
+        C_D: 0.5, S: 4 * np.pi,
+        v_r_n: sym.sqrt(v_r_x**2 + v_r_y**2 + v_r_z**2),
+        v_r_x: v_x - oxr_x, v_r_y: v_y - oxr_y, v_r_z: v_z - oxr_z,
+        oxr_x: -omega_E * r_y, oxr_y: omega_E * r_x, oxr_z: 0,
+        g_0: g0_val, h_0: 7200, h: r_n - R_E, rho: rho_0 * sym.exp(-h / h_0), rho_0: 1.225,
+        omega_E: omega_val, T_over_m: T / m, psi_L: psi_L_val,
+    }
+    return prob
+
+
+def double_pendulum(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Double-pendulum swing-up test fixture (tests/unit/conftest.py:79-190): 4 states, 2 controls,
+    1 integral, 2 static parameters (m0, p0), tF free."""
+    a0, a1, v0, v1, T0, T1 = sym.symbols("a0 a1 v0 v1 T0 T1")
+    g = sym.symbols("g")
+    m0, p0, d0, l0, k0, I0 = sym.symbols("m0 p0 d0 l0 k0 I0")
+    m1, p1, d1, l1, k1, I1 = sym.symbols("m1 p1 d1 l1 k1 I1")
+    c0, s0, c1, s1 = sym.symbols("c0 s0 c1 s1")
+    M00, M01, M10, M11, K0, K1, detM = sym.symbols("M00 M01 M10 M11 K0 K1 detM")
+    prob = ProblemSpec("Double Pendulum Swing-Up")
+    ph = prob.new_phase("A")
+    ph.state_variables = [a0, a1, v0, v1]
+    ph.control_variables = [T0, T1]
+    ph.state_equations = [v0, v1, (M11 * K0 - M01 * K1) / detM, (M00 * K1 - M10 * K0) / detM]
+    ph.integrand_functions = [T0**2 + T1**2]
+    ph.auxiliary_data = {g: -9.81, k1: 1 / 12, I0: m0 * (k0**2 + p0**2), I1: m1 * (k1**2 + p1**2),
+                         s0: sym.sin(a0), c1: sym.cos(a1)}
+    prob.parameter_variables = [m0, p0]
+    prob.objective_function = ph.integral_variables[0]
+    prob.auxiliary_data = {
+        g: 0, d0: 0.5, k0: 1 / 12, m1: 1.0, p1: 0.5, d1: 0.5, l0: p0 + d0, l1: p1 + d1,
+        I0: m0 * (k0**2 + p0**2), I1: m1 * (k1**2 + p1**2),
+        c0: sym.cos(a0), s0: sym.sin(a0), c1: sym.cos(a1), s1: sym.sin(a1),
+        M00: I0 + m1 * l0**2, M01: m1 * p1 * l0 * (s0 * s1 + c0 * c1), M10: M01, M11: I1,
+        K0: T0 + g * (m0 * p0 + m1 * l0) * c0 + m1 * p1 * l0 * (s1 * c0 - s0 * c1) * v1**2,
+        K1: T1 + g * m1 * p1 * c1 + m1 * p1 * l0 * (s0 * c1 - s1 * c0) * v0**2,
+        detM: M00 * M11 - M01 * M10,
+    }
+    ph.bounds.initial_time = 0
+    ph.bounds.final_time = [1, 3]
+    ph.bounds.state_variables = [[-np.pi, np.pi], [-np.pi, np.pi], [-10, 10], [-10, 10]]
+    ph.bounds.control_variables = [[-15, 15], [-15, 15]]
+    ph.bounds.integral_variables = [0, 1000]
+    ph.bounds.initial_state_constraints = [[-0.5 * np.pi] * 2, [-0.5 * np.pi] * 2, [0, 0], [0, 0]]
+    ph.bounds.final_state_constraints = [[0.5 * np.pi] * 2, [0.5 * np.pi] * 2, [0, 0], [0, 0]]
+    prob.bounds.parameter_variables = [[0.5, 1.5], [0.5, 1.5]]
+    _mesh(ph, K, order)
+    return prob
+
+
+def two_phase_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
+    """Small synthetic multi-phase problem exercising every block type at once: two phases with
+    different dynamics, free interior time, a path constraint, integrals, a static parameter that
+    enters dynamics / path / integrand, linkage endpoint constraints and a nonlinear objective.
+    (Not from the reference; it exists so that parity tests cover q/t/s coupling and phase offsets.)"""
+    x, v, u, k = sym.symbols("x v u k")
+    prob = ProblemSpec("two-phase transfer")
+    prob.parameter_variables = [k]
+    prob.bounds.parameter_variables = [[0.5, 2.0]]
+    A = prob.new_phase("A")
+    A.state_variables = [x, v]
+    A.control_variables = [u]
+    A.state_equations = [v, u - k * sym.sin(x) * v]
+    A.path_constraints = [u**2 + k * x]
+    A.integrand_functions = [u**2 + k * x**2]
+    A.bounds.initial_time = 0.0
+    A.bounds.final_time = [0.5, 2.0]
+    A.bounds.state_variables = [[-2, 2], [-3, 3]]
+    A.bounds.control_variables = [[-4, 4]]
+    A.bounds.integral_variables = [[0, 50]]
+    A.bounds.path_constraints = [[-1, 20]]
+    A.bounds.initial_state_constraints = {x: 0, v: 0}
+    B = prob.new_phase("B")
+    B.state_variables = [x, v]
+    B.control_variables = [u]
+    B.state_equations = [v * sym.cos(x), -k * x + u * sym.exp(-v**2)]
+    B.integrand_functions = [sym.sqrt(1 + u**2), x * v * k]
+    B.bounds.initial_time = [0.5, 2.0]
+    B.bounds.final_time = [2.5, 4.0]
+    B.bounds.state_variables = [[-2, 2], [-3, 3]]
+    B.bounds.control_variables = [[-4, 4]]
+    B.bounds.integral_variables = [[0, 50], [-10, 10]]
+    B.bounds.final_state_constraints = {x: 1.0, v: 0.0}
+    prob.objective_function = (A.integral_variables[0] + B.integral_variables[0] * B.final_time_variable
+                               + k * B.final_state_variables[1]**2 * A.initial_state_variables[0])
+    prob.endpoint_constraints = [A.final_state_variables[0] - B.initial_state_variables[0],
+                                 A.final_state_variables[1] - B.initial_state_variables[1],
+                                 A.final_time_variable - B.initial_time_variable,
+                                 B.integral_variables[1] * k - sym.sin(A.final_state_variables[0]) * B.final_time_variable]
+    prob.bounds.endpoint_constraints = [0, 0, 0, [-1, 1]]
+    _mesh(A, K, order)
+    _mesh(B, K + 1, order + 1)
+    return prob
+
+
+REGISTRY = {
+    "brachistochrone": brachistochrone,
+    "hypersensitive": hypersensitive,
+    "cart_pole": cart_pole,
+    "shuttle": shuttle,
+    "delta_iii": delta_iii,
+    "double_pendulum": double_pendulum,
+    "two_phase_transfer": two_phase_transfer,
+}
