@@ -1,0 +1,141 @@
+/*
+ * pycollo_amd -- C ABI of the MI355X collocation NLP-callback engine.
+ *
+ * Drop-in boundary for pycollo's hot path.  The callback set mirrors IPOPT's
+ * IpStdCInterface.h (Eval_F_CB, Eval_Grad_F_CB, Eval_G_CB, Eval_Jac_G_CB, Eval_H_CB) so a handle can
+ * be driven by IPOPT with or without Python; each entry point cites the reference interface it
+ * replaces.  All functions return 1 on success and 0 on failure (IPOPT convention);
+ * pc_last_error() describes the last failure on the calling thread.  NaN/Inf are written through.
+ *
+ * Ownership: the caller owns every pointer it passes.  The library owns all device memory, one HIP
+ * stream per handle and copies of the descriptor arrays.  Calls on one handle are not re-entrant
+ * (IPOPT is serial); different handles may be used from different threads.
+ *
+ * Index arrays are 0-based int32 (IPOPT "C_STYLE"), CSR order: row-major, ascending columns.
+ * The Hessian is the lower triangle.
+ */
+#ifndef PYCOLLO_AMD_H
+#define PYCOLLO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pc_handle pc_handle;
+
+/* kinds of point (endpoint) variables, pycollo/backend.py:1264-1269 */
+enum { PC_PT_Y0 = 0, PC_PT_YF = 1, PC_PT_Q = 2, PC_PT_T0 = 3, PC_PT_TF = 4, PC_PT_S = 5 };
+
+/* One phase of the optimal control problem on one mesh (pycollo/mesh.py:236-356 tables,
+ * pycollo/backend.py:854-1305 phase data reduced to counts and structural masks). */
+typedef struct {
+  int32_t n_y, n_u, n_q, n_p;      /* needed states, controls, integrals; path constraints */
+  int32_t t0_free, tF_free;        /* 1 if t0 / tF is an NLP variable (bounds.py:456-480) */
+  double t0_fixed, tF_fixed;       /* value used when the time is not free (backend.py:1579-1586) */
+  int32_t K;                       /* mesh sections */
+  const int32_t* n_k;              /* [K] nodes per section, both ends included (mesh N_K) */
+  const double* h_k;               /* [K] section widths in tau (mesh h_K), sum = 2 */
+  /* structural non-zeros of d[f|p|g]/d[z|s], sorted by (row, col); rows: n_y+n_p+n_q, cols: n_z+n_s */
+  int32_t n_jac;
+  const int32_t* jac_row;
+  const int32_t* jac_col;
+  /* structural non-zeros of the node-Lagrangian Hessian in [z|s], lower triangle, sorted by (row, col) */
+  int32_t n_hess;
+  const int32_t* hess_row;
+  const int32_t* hess_col;
+  const char* bulk_kernel;         /* kernel symbol inside the code object */
+} pc_phase_desc;
+
+typedef struct {
+  int32_t n_phases;
+  const pc_phase_desc* phases;
+  int32_t n_s;                     /* needed static parameters */
+  /* point variables in x_point_var order (pycollo/backend.py:658-661) */
+  int32_t n_point;
+  const int32_t* point_phase;      /* -1 for static parameters */
+  const int32_t* point_kind;       /* PC_PT_* */
+  const int32_t* point_idx;        /* index within its kind */
+  int32_t n_b;                     /* endpoint constraints */
+  int32_t n_jgrad;                 /* structural non-zeros of dJ/dxb */
+  const int32_t* jgrad_col;
+  int32_t n_bjac;                  /* of db/dxb, sorted by (row, col) */
+  const int32_t* bjac_row;
+  const int32_t* bjac_col;
+  int32_t n_pthess;                /* of d2(sigma J + lam.b)/dxb2, lower triangle, sorted */
+  const int32_t* pthess_row;
+  const int32_t* pthess_col;
+  /* quadrature tables as data (pycollo/quadrature.py:189-261): for every order n in `orders`,
+   * packed back to back: A (n-1) x n row-major in quad_A, weights n in quad_w */
+  int32_t n_orders;
+  const int32_t* orders;
+  const double* quad_A;
+  const double* quad_w;
+  const char* code_object;         /* path of the gfx950 code object; may be NULL when device < 0 */
+  const char* tail_kernel;
+  int32_t device;                  /* HIP device ordinal; -1 = structure only, no evaluation possible */
+  int32_t threads_per_block;       /* 0 = choose from the mesh size; else 64, 128 or 256 */
+} pc_problem_desc;
+
+typedef struct {
+  int32_t n, m;
+  int64_t nnz_jac, nnz_hess;
+  int64_t algorithmic_bytes;       /* 8*(n+m) read + 8*(m+nnz_jac+nnz_hess) written per eval_all */
+  int32_t n_tiles_total, threads_per_block;
+  int32_t lds_bytes_max, n_launches; /* kernels per eval_all */
+} pc_info;
+
+const char* pc_last_error(void);
+
+/* replaces: Casadi.generate_nlp_function_callables + create_nlp_solver (pycollo/backend.py:1403-1411,
+ * 1681-1693) and the legacy CompiledFunctions constructor (pycollo/compiled.py:19-30) */
+int pc_create(const pc_problem_desc* desc, pc_handle** out);
+void pc_destroy(pc_handle* h);
+int pc_get_info(const pc_handle* h, pc_info* info);
+
+/* replaces: Iteration.num_x / num_c (pycollo/iteration.py:231-235,287-290),
+ * Casadi.evaluate_G_num_nonzero (backend.py:1763-1771), evaluate_H_num_nonzero (:1799-1805) */
+int pc_sizes(const pc_handle* h, int32_t* n, int32_t* m, int64_t* nnz_jac, int64_t* nnz_hess);
+/* replaces: Casadi.evaluate_G_structure (backend.py:1747-1761), IPOPTProblem.jacobianstructure
+ * (pycollo/nlp.py:56-57); CSR (row-major) order */
+int pc_jac_structure(const pc_handle* h, int32_t* iRow, int32_t* jCol);
+/* replaces: IPOPTProblem.hessianstructure (nlp.py:62-63), evaluate_H_structure (backend.py:1790-1797) */
+int pc_hess_structure(const pc_handle* h, int32_t* iRow, int32_t* jCol);
+
+/* replaces: the V/r/W/w substitutions of create_nlp_solver (backend.py:1459-1463,1684-1689);
+ * vectors are per OCP variable / constraint (scaling.py:166-167,274) */
+int pc_set_scaling(pc_handle* h, const double* V_ocp, const double* r_ocp, const double* W_ocp, double w_J);
+
+/* replaces: nlp_f / IPOPTProblem.objective (backend.py:1713-1715, nlp.py:47-48) */
+int pc_eval_f(pc_handle* h, const double* x, int new_x, double* f);
+/* replaces: nlp_grad_f / IPOPTProblem.gradient (backend.py:1717-1720, nlp.py:50-51); dense n */
+int pc_eval_grad_f(pc_handle* h, const double* x, int new_x, double* grad);
+/* replaces: nlp_g / IPOPTProblem.constraints (backend.py:1722-1725, nlp.py:53-54); dense m */
+int pc_eval_g(pc_handle* h, const double* x, int new_x, double* g);
+/* replaces: nlp_jac_g / IPOPTProblem.jacobian (backend.py:1738-1745, nlp.py:56-57) */
+int pc_eval_jac_g(pc_handle* h, const double* x, int new_x, double* values);
+/* replaces: nlp_hess_l / IPOPTProblem.hessian (nlp.py:59-60, pycollo/iteration.py:1057) */
+int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const double* lambda,
+              int new_lambda, double* values);
+/* fused g + jac_g + hess at one (x, sigma, lambda): the benchmarked call (host pointers) */
+int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* g,
+                double* jac, double* hess);
+/* same with every vector resident in device memory; asynchronous on `stream` (hipStream_t, NULL =
+ * the handle's stream).  No host synchronisation is performed. */
+int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda,
+                       double* d_g, double* d_jac, double* d_hess, void* stream);
+int pc_synchronize(pc_handle* h);
+
+/* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling
+ * (pycollo/scaling.py:392-395) without densifying G; evaluates G at x with the current scaling */
+int pc_row_norms_jac(pc_handle* h, const double* x, double* norms);
+
+/* timing of the last n pc_eval_all_device launches is measured by the caller with HIP events on the
+ * stream it passed; this returns the stream the handle owns (hipStream_t) */
+void* pc_stream(pc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYCOLLO_AMD_H */

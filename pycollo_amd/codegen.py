@@ -1,0 +1,237 @@
+"""HIP source generation + hipcc driver for the per-problem collocation code object.
+
+The hand-written kernels live in ``csrc/pc_kernels.hpp``; this module only emits what is specific to
+one problem: compile-time sizes, the structural non-zero lists and one straight-line, CSE'd
+``eval`` per phase (the role ``numbafy`` / ``numbafy_hessian`` play in the reference --
+pycollo/numbafy.py:90-103,231-245: precomputed constants -> tiered intermediates -> stacked outputs),
+and the endpoint function block.  The translation unit is compiled for gfx950 into a code object
+(``.hsaco``) that the C-ABI library loads with ``hipModuleLoad``; objects are cached by model digest.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+
+import sympy as sym
+from sympy.printing.c import C99CodePrinter
+
+from .model import Model, PhaseModel, PointModel
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+CACHE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache")
+ARCH = "gfx950"
+
+
+class _Printer(C99CodePrinter):
+    """C printer that keeps fp64 integer powers off the transcendental path."""
+
+    def _print_Pow(self, expr):
+        base, exp = expr.base, expr.exp
+        b = self.parenthesize(base, 200)  # always parenthesise non-atomic bases
+        if exp.is_Integer:
+            n = int(exp)
+            if n == 0:
+                return "1.0"
+            a = abs(n)
+            if a <= 4:
+                body = "*".join([b] * a)
+                body = f"({body})" if a > 1 else b
+            else:
+                body = f"pc_powi<{a}>({self._print(base)})"
+            return body if n > 0 else f"(1.0/{body})"
+        if exp == sym.Rational(1, 2):
+            return f"sqrt({self._print(base)})"
+        if exp == sym.Rational(-1, 2):
+            return f"(1.0/sqrt({self._print(base)}))"
+        if exp == sym.Rational(3, 2):
+            return f"({b}*sqrt({self._print(base)}))"
+        if exp == sym.Rational(-3, 2):
+            return f"(1.0/({b}*sqrt({self._print(base)})))"
+        return f"pow({self._print(base)}, {self._print(exp)})"
+
+    def parenthesize(self, item, level, strict=False):
+        s = self._print(item)
+        if item.is_Atom and not (item.is_Number and item < 0):
+            return s
+        return f"({s})"
+
+    def _print_sec(self, expr):
+        return f"(1.0/cos({self._print(expr.args[0])}))"
+
+    def _print_csc(self, expr):
+        return f"(1.0/sin({self._print(expr.args[0])}))"
+
+    def _print_cot(self, expr):
+        return f"(1.0/tan({self._print(expr.args[0])}))"
+
+    def _print_Float(self, expr):
+        return repr(float(expr))
+
+    def _print_Integer(self, expr):
+        return f"{int(expr)}.0"
+
+    def _print_Rational(self, expr):
+        return f"({int(expr.p)}.0/{int(expr.q)}.0)"
+
+
+_PRINTER = _Printer({"allow_unknown_functions": False})
+
+
+def _c(expr) -> str:
+    return _PRINTER.doprint(sym.sympify(expr))
+
+
+def _emit_block(inputs: dict, outputs: list[tuple[str, sym.Expr]], tmp: str) -> list[str]:
+    """CSE a list of (lvalue, expr) assignments; ``inputs`` maps symbols to C rvalues."""
+    if not outputs:
+        return []
+    exprs = [sym.sympify(e) for _, e in outputs]
+    repl, reduced = sym.cse(exprs, symbols=sym.numbered_symbols(tmp), order="none")
+    lines = []
+    sub = dict(inputs)
+    for s, e in repl:
+        lines.append(f"    const double {s} = {_c(e.xreplace(sub))};")
+    for (lhs, _), e in zip(outputs, reduced):
+        lines.append(f"    {lhs} = {_c(e.xreplace(sub))};")
+    return lines
+
+
+def _constexpr_table(name: str, values: list[int]) -> str:
+    if not values:
+        return f"  static constexpr int {name}(int) {{ return 0; }}"
+    body = ", ".join(str(int(v)) for v in values)
+    return (f"  static constexpr int {name}(int e) {{ constexpr int t[{len(values)}] = {{{body}}}; return t[e]; }}")
+
+
+def _phase_struct(pm: PhaseModel) -> str:
+    name = f"Phase{pm.index}"
+    nfn, nv = pm.n_fn, pm.n_v
+    v_in = {s: sym.Symbol(f"v[{i}]") for i, s in enumerate(pm.z + pm.s)}
+    mult = pm.mf + pm.mp + pm.mg
+    m_in = {s: sym.Symbol(f"mult[{i}]") for i, s in enumerate(mult)}
+    inputs = {**v_in, **m_in}
+    outs = [(f"F[{i}]", e) for i, e in enumerate(pm.f + pm.p + pm.g)]
+    outs += [(f"Jv[{i}]", e) for i, (_, _, e) in enumerate(pm.jac)]
+    outs += [(f"Hv[{i}]", e) for i, (_, _, e) in enumerate(pm.hess)]
+    body = [f"    constexpr double {k} = {float(val)!r};" for k, val in pm.consts]
+    body += _emit_block(inputs, outs, "w")
+    lines = [f"struct {name} {{",
+             f"  static constexpr int NY = {pm.n_y}, NU = {pm.n_u}, NQ = {pm.n_q}, NP = {pm.n_p}, NS = {pm.n_s};",
+             f"  static constexpr bool T0_FREE = {'true' if pm.t_free[0] else 'false'}, "
+             f"TF_FREE = {'true' if pm.t_free[1] else 'false'};",
+             f"  static constexpr int NJ = {len(pm.jac)}, NH = {len(pm.hess)};",
+             _constexpr_table("jr", [r for r, _, _ in pm.jac]),
+             _constexpr_table("jc", [c for _, c, _ in pm.jac]),
+             _constexpr_table("hr", [r for r, _, _ in pm.hess]),
+             _constexpr_table("hc", [c for _, c, _ in pm.hess]),
+             "  __device__ static __forceinline__ void eval(const double* __restrict__ v, const double* __restrict__ mult,",
+             "      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ Hv) {",
+             "    (void)v; (void)mult; (void)F; (void)Jv; (void)Hv;"]
+    lines += body
+    lines += ["  }", "};", ""]
+    assert nfn >= 0 and nv >= 0
+    return "\n".join(lines)
+
+
+def _point_struct(pt: PointModel) -> str:
+    xb_in = {pv.symbol: sym.Symbol(f"xb[{i}]") for i, pv in enumerate(pt.vars)}
+    inputs = dict(xb_in)
+    inputs[pt.sigma] = sym.Symbol("sw")
+    inputs.update({s: sym.Symbol(f"lb[{i}]") for i, s in enumerate(pt.lam)})
+    outs = [("Jval", pt.J)]
+    outs += [(f"gJ[{i}]", e) for i, (_, e) in enumerate(pt.J_grad)]
+    outs += [(f"b[{i}]", e) for i, e in enumerate(pt.b)]
+    outs += [(f"jb[{i}]", e) for i, (_, _, e) in enumerate(pt.b_jac)]
+    outs += [(f"hb[{i}]", e) for i, (_, _, e) in enumerate(pt.hess)]
+    body = [f"    constexpr double {k} = {float(val)!r};" for k, val in pt.consts]
+    body += _emit_block(inputs, outs, "w")
+    lines = ["struct Point {",
+             f"  static constexpr int NPV = {len(pt.vars)}, NB = {len(pt.b)}, NGJ = {len(pt.J_grad)}, "
+             f"NBJ = {len(pt.b_jac)}, NPH = {len(pt.hess)};",
+             _constexpr_table("gc", [c for c, _ in pt.J_grad]),
+             _constexpr_table("br", [r for r, _, _ in pt.b_jac]),
+             _constexpr_table("bc", [c for _, c, _ in pt.b_jac]),
+             _constexpr_table("phr", [r for r, _, _ in pt.hess]),
+             _constexpr_table("phc", [c for _, c, _ in pt.hess]),
+             "  __device__ static __forceinline__ void eval(const double* __restrict__ xb, double sw, const double* __restrict__ lb,",
+             "      double& Jval, double* __restrict__ gJ, double* __restrict__ b, double* __restrict__ jb, double* __restrict__ hb) {",
+             "    (void)xb; (void)sw; (void)lb; (void)gJ; (void)b; (void)jb; (void)hb;"]
+    lines += body
+    lines += ["  }", "};", ""]
+    return "\n".join(lines)
+
+
+def generate_source(model: Model) -> str:
+    parts = [f"// generated by pycollo_amd.codegen for model '{model.name}' digest {model.digest} -- do not edit",
+             '#include "pc_kernels.hpp"',
+             "",
+             "template <int N> __device__ __forceinline__ double pc_powi(double x) {",
+             "  double r = 1.0;",
+             "#pragma unroll",
+             "  for (int i = 0; i < N; ++i) r *= x;",
+             "  return r;",
+             "}",
+             "",
+             "namespace gen {"]
+    for pm in model.phases:
+        parts.append(_phase_struct(pm))
+    parts.append(_point_struct(model.point))
+    parts.append("}  // namespace gen\n")
+    for pm in model.phases:
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{pm.index}(PcPhaseArgs a) '
+                     f'{{ pc::bulk<gen::Phase{pm.index}>(a); }}')
+    parts.append("")
+    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) {')
+    parts.append("  pc::tail_begin(a);")
+    for pm in model.phases:
+        parts.append(f"  pc::tail_phase<gen::Phase{pm.index}>(a, {pm.index});")
+    parts.append("  pc::tail_point<gen::Point>(a);")
+    parts.append("}")
+    parts.append("")
+    return "\n".join(parts)
+
+
+def _kernels_stamp() -> str:
+    h = hashlib.sha256()
+    for fn in ("pc_kernels.hpp", "pc_args.h"):
+        with open(os.path.join(CSRC, fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def hipcc_path() -> str | None:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def code_object_path(model: Model) -> str:
+    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}.hsaco")
+
+
+def build_code_object(model: Model, force: bool = False, verbose: bool = False) -> str:
+    """Return the path of the gfx950 code object for ``model``, compiling it if it is not cached."""
+    os.makedirs(CACHE, exist_ok=True)
+    out = code_object_path(model)
+    if os.path.exists(out) and not force:
+        return out
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError(f"code object {out} is not built and hipcc is not available to build it")
+    src = out[:-6] + ".hip"
+    with open(src, "w") as f:
+        f.write(generate_source(model))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17",
+           f"-I{CSRC}", "-o", out + ".tmp", src]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
+    if verbose:
+        print(res.stderr)
+    os.replace(out + ".tmp", out)
+    return out

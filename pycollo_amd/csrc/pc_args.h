@@ -1,0 +1,78 @@
+// Shared host/device argument blocks for the collocation kernels.
+// Plain C structs: the host library fills them, generated kernels receive them by value.
+#ifndef PC_ARGS_H
+#define PC_ARGS_H
+
+#include <stdint.h>
+
+#define PC_MAX_ORDER 20
+#define PC_FLAG_C 1
+#define PC_FLAG_G 2
+#define PC_FLAG_H 4
+
+// Per-phase arguments of the bulk kernel.
+struct PcPhaseArgs {
+  // NLP vectors (device)
+  const double* x;      // [num_x] scaled variables
+  const double* lam;    // [num_c] multipliers (may be null unless PC_FLAG_H)
+  double* c;            // [num_c]
+  double* G;            // [nnz_G]
+  double* H;            // [nnz_H]
+  // mesh (device)
+  const int32_t* tile_k0;  // [n_tiles+1] first section of every tile
+  const int32_t* sec_s;    // [K+1] first node of every section; sec_s[K] = N-1
+  const double* sec_h;     // [K] section widths in tau
+  const int64_t* sec_E;    // [K+1] prefix sum of (n_k-1)*n_k
+  const double* qa;        // packed A tables of the orders in use
+  const double* qw;        // packed weight tables
+  // packed scaling doubles: Vz[NZ] rz[NZ] Vq[NQ] rq[NQ] Vt[2] rt[2] Vs[NS] rs[NS] Wd[NY] Wp[NP] Wi[NQ]
+  const double* scal;
+  // CSR value offsets (device)
+  const int64_t* goff;    // [NY] defect block bases | [NP] path bases | [NQ] integral bases
+  const int64_t* hoff;    // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
+  const int64_t* hslot0;  // [NHZZ] slots of the node block at node 0
+  const int64_t* hslotN;  // [NHZZ] slots of the node block at node N-1
+  double* partials;       // [n_tiles][NRED] per-tile partial sums
+  int64_t x_off, s_off;   // first x index of the phase / of the static parameters
+  int64_t c_off, c_path_off, c_int_off;
+  double t_fixed[2];
+  int32_t N, K, n_tiles, flags;
+  int32_t qa_total, qw_total;
+  int32_t qa_off[PC_MAX_ORDER + 1];
+  int32_t qw_off[PC_MAX_ORDER + 1];
+};
+
+#define PC_MAX_PHASES 16
+
+struct PcTailPhase {
+  const double* partials;  // [n_tiles][NRED]
+  const double* scal;
+  int64_t x_off, s_off, c_int_off;
+  int64_t gq_base[8];      // CSR offset of the q column of every integral row (then t, s follow)
+  const int64_t* hsum_slot;  // [2*NS] (t_j, s_l) slots then [NS*(NS+1)/2] (s_l, s_l') slots; -1 absent
+  double t_fixed[2];
+  int32_t n_tiles, N;
+};
+
+struct PcTailArgs {
+  const double* x;
+  const double* lam;
+  double* c;
+  double* G;
+  double* H;
+  double* fobj;                 // [1] objective value (scaled by w_J)
+  double* grad;                 // [num_x] or null (caller zero-fills)
+  const double* params;         // [0] = sigma (objective factor), [1] = w_J
+  const int64_t* point_x;       // [n_point] x index of every point variable
+  const double* point_V;        // [n_point]
+  const double* point_r;        // [n_point]
+  const double* W_end;          // [n_b]
+  const int64_t* tail_owned;    // [n_tail_owned] H slots written by the tail only (zeroed first)
+  const int64_t* pt_hslot;      // [n_pt_hess] H slot of every endpoint Hessian entry
+  int64_t c_end_off;            // first endpoint row of c
+  int64_t g_end_base;           // CSR offset of the first endpoint row of G
+  int32_t n_tail_owned, flags;
+  PcTailPhase ph[PC_MAX_PHASES];
+};
+
+#endif  // PC_ARGS_H

@@ -1,0 +1,661 @@
+// C-ABI engine: owns device memory, the per-problem code object and the launch sequence.
+// See include/pycollo_amd.h for the contract and the reference interfaces each entry point replaces.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pycollo_amd.h"
+#include "pc_args.h"
+#include "pc_pattern.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const std::string& s) { g_err = s; }
+
+#define HIP_OK(expr)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+// LDS plan must match pc_kernels.hpp::lds_plan (kept in one place there; mirrored here because this
+// TU does not include device templates).
+int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED) {
+  int o = 0;
+  o += qa_total;
+  o += qw_total;
+  o += TB + 2;
+  o += TB + 2;
+  o += (TB + 4) / 2 + 1;
+  o += (TB + 1) / 2 + 1;
+  o += NY * TB;
+  o += NY * TB;
+  o += NFS * TB;
+  o += NY * (TB + PC_MAX_ORDER);
+  o += (NRED > 0 ? NRED : 1) * 16;
+  return o;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    free();
+    n = count;
+    if (count) HIP_OK(hipMalloc(&p, count * sizeof(T)));
+  }
+  void upload(const std::vector<T>& v) {
+    alloc(v.size());
+    if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~DevBuf() { free(); }
+};
+
+template <class T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    free();
+    n = count;
+    if (count) HIP_OK(hipHostMalloc(&p, count * sizeof(T), hipHostMallocDefault));
+  }
+  void free() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  ~PinBuf() { free(); }
+};
+
+struct PhaseDev {
+  DevBuf<int32_t> tile_k0, sec_s;
+  DevBuf<double> sec_h, scal, partials;
+  DevBuf<int64_t> sec_E, goff, hoff, hslot0, hslotN, hsum_slot;
+  hipFunction_t fn = nullptr;
+  int lds_bytes = 0, n_tiles = 0, nfs = 0;
+  std::vector<double> scal_host;
+};
+
+// generic kernel: 2-norm of every CSR row (scaling.py:392-395 without densifying)
+__global__ void row_norms_kernel(const int64_t* __restrict__ indptr, const double* __restrict__ val,
+                                 double* __restrict__ out, int64_t m) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= m) return;
+  double acc = 0.0;
+  for (int64_t i = indptr[wave] + lane; i < indptr[wave + 1]; i += 64) acc += val[i] * val[i];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) out[wave] = sqrt(acc);
+}
+
+}  // namespace
+
+struct pc_handle {
+  pcp::Problem Q;
+  int device = -1;
+  int TB = 64;
+  bool scaling_set = false;
+  double w_J = 1.0;
+  // quadrature
+  std::vector<double> qa, qw;
+  int32_t qa_off[PC_MAX_ORDER + 1], qw_off[PC_MAX_ORDER + 1];
+  // device
+  hipStream_t stream = nullptr;
+  hipModule_t module = nullptr;
+  hipFunction_t tail_fn = nullptr;
+  std::vector<std::unique_ptr<PhaseDev>> pd;
+  DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_params, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
+  DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
+  PinBuf<double> h_x, h_lam, h_c, h_G, h_H, h_params, h_fobj, h_grad, h_norms;
+  std::vector<double> V_ocp, r_ocp, W_ocp;
+  // cache for new_x == 0
+  bool have_cG = false;
+  int n_launches = 0;
+  int lds_max = 0;
+};
+
+namespace {
+
+void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
+                double* d_fobj, double* d_grad, int flags, hipStream_t st) {
+  auto& Q = h->Q;
+  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+    auto& P = Q.ph[ip];
+    auto& D = *h->pd[ip];
+    PcPhaseArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = d_x;
+    a.lam = d_lam;
+    a.c = d_c;
+    a.G = d_G;
+    a.H = d_H;
+    a.tile_k0 = D.tile_k0.p;
+    a.sec_s = D.sec_s.p;
+    a.sec_h = D.sec_h.p;
+    a.sec_E = D.sec_E.p;
+    a.qa = h->d_qa.p;
+    a.qw = h->d_qw.p;
+    a.scal = D.scal.p;
+    a.goff = D.goff.p;
+    a.hoff = D.hoff.p;
+    a.hslot0 = D.hslot0.p;
+    a.hslotN = D.hslotN.p;
+    a.partials = D.partials.p;
+    a.x_off = P.x_off;
+    a.s_off = Q.s_off;
+    a.c_off = P.c_off;
+    a.c_path_off = P.c_path_off;
+    a.c_int_off = P.c_int_off;
+    a.t_fixed[0] = P.t_fixed[0];
+    a.t_fixed[1] = P.t_fixed[1];
+    a.N = P.N;
+    a.K = P.K;
+    a.n_tiles = D.n_tiles;
+    a.flags = flags;
+    a.qa_total = (int32_t)h->qa.size();
+    a.qw_total = (int32_t)h->qw.size();
+    std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
+    std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
+    size_t sz = sizeof(a);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIP_OK(hipModuleLaunchKernel(D.fn, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
+  }
+  PcTailArgs t;
+  std::memset(&t, 0, sizeof(t));
+  t.x = d_x;
+  t.lam = d_lam;
+  t.c = d_c;
+  t.G = d_G;
+  t.H = d_H;
+  t.fobj = d_fobj;
+  t.grad = d_grad;
+  t.params = h->d_params.p;
+  t.point_x = h->d_point_x.p;
+  t.point_V = h->d_pointV.p;
+  t.point_r = h->d_pointr.p;
+  t.W_end = h->d_Wend.p;
+  t.tail_owned = h->d_tail_owned.p;
+  t.pt_hslot = h->d_pt_hslot.p;
+  t.c_end_off = Q.c_end_off;
+  t.g_end_base = Q.g_end_base;
+  t.n_tail_owned = (int32_t)Q.tail_owned.size();
+  t.flags = flags;
+  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+    auto& P = Q.ph[ip];
+    auto& D = *h->pd[ip];
+    PcTailPhase& tp = t.ph[ip];
+    tp.partials = D.partials.p;
+    tp.scal = D.scal.p;
+    tp.x_off = P.x_off;
+    tp.s_off = Q.s_off;
+    tp.c_int_off = P.c_int_off;
+    for (int m = 0; m < 8; ++m) tp.gq_base[m] = P.gq_base[m];
+    tp.hsum_slot = D.hsum_slot.p;
+    tp.t_fixed[0] = P.t_fixed[0];
+    tp.t_fixed[1] = P.t_fixed[1];
+    tp.n_tiles = D.n_tiles;
+    tp.N = P.N;
+  }
+  size_t sz = sizeof(t);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
+}
+
+void upload_scaling(pc_handle* h) {
+  auto& Q = h->Q;
+  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+    auto& P = Q.ph[ip];
+    auto& D = *h->pd[ip];
+    const int NZ = P.n_z, NQ = P.n_q, NS = Q.n_s, NY = P.n_y, NP = P.n_p;
+    std::vector<double> s(2 * NZ + 2 * NQ + 4 + 2 * NS + NY + NP + NQ, 0.0);
+    const double* V = h->V_ocp.data() + P.ocp_x_off;
+    const double* r = h->r_ocp.data() + P.ocp_x_off;
+    int o = 0;
+    for (int b = 0; b < NZ; ++b) s[o++] = V[b];
+    for (int b = 0; b < NZ; ++b) s[o++] = r[b];
+    for (int m = 0; m < NQ; ++m) s[o++] = V[NZ + m];
+    for (int m = 0; m < NQ; ++m) s[o++] = r[NZ + m];
+    for (int j = 0; j < 2; ++j) s[o++] = j < P.n_t ? V[NZ + NQ + j] : 1.0;
+    for (int j = 0; j < 2; ++j) s[o++] = j < P.n_t ? r[NZ + NQ + j] : 0.0;
+    for (int l = 0; l < NS; ++l) s[o++] = h->V_ocp[Q.ocp_s_off + l];
+    for (int l = 0; l < NS; ++l) s[o++] = h->r_ocp[Q.ocp_s_off + l];
+    const double* W = h->W_ocp.data() + P.ocp_c_off;
+    for (int a = 0; a < NY + NP + NQ; ++a) s[o++] = W[a];
+    D.scal_host = s;
+    if (h->device >= 0) {
+      if (D.scal.n != s.size()) D.scal.alloc(s.size());
+      HIP_OK(hipMemcpy(D.scal.p, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
+  if (h->device >= 0) {
+    const size_t np = Q.point_x.size();
+    std::vector<double> pv(np), pr(np), we(Q.n_b);
+    for (size_t i = 0; i < np; ++i) {
+      pv[i] = h->V_ocp[Q.point_ocp[i]];
+      pr[i] = h->r_ocp[Q.point_ocp[i]];
+    }
+    for (int r = 0; r < Q.n_b; ++r) we[r] = h->W_ocp[Q.ocp_c_end_off + r];
+    h->d_pointV.upload(pv);
+    h->d_pointr.upload(pr);
+    h->d_Wend.upload(we);
+  }
+  h->have_cG = false;
+}
+
+void require_device(pc_handle* h) {
+  if (!h) throw std::runtime_error("null handle");
+  if (h->device < 0)
+    throw std::runtime_error("handle was created with device = -1 (structure only): no evaluation is possible "
+                             "without a GPU; this library has no CPU fallback");
+  if (!h->scaling_set) throw std::runtime_error("pc_set_scaling must be called before evaluating");
+  HIP_OK(hipSetDevice(h->device));
+}
+
+void set_params(pc_handle* h, double sigma) {
+  h->h_params.p[0] = sigma;
+  h->h_params.p[1] = h->w_J;
+  HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+}
+
+void copy_x_in(pc_handle* h, const double* x) {
+  std::memcpy(h->h_x.p, x, h->Q.num_x * sizeof(double));
+  HIP_OK(hipMemcpyAsync(h->d_x.p, h->h_x.p, h->Q.num_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 1;
+  } catch (const std::exception& e) {
+    set_err(e.what());
+    return 0;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pc_last_error(void) { return g_err.c_str(); }
+
+int pc_create(const pc_problem_desc* d, pc_handle** out) {
+  if (out) *out = nullptr;
+  std::unique_ptr<pc_handle> h;
+  const int ok = guarded([&] {
+    if (!d || !out) throw std::runtime_error("null descriptor or output pointer");
+    if (d->n_phases < 1 || d->n_phases > PC_MAX_PHASES) throw std::runtime_error("n_phases must be in [1, 16]");
+    h.reset(new pc_handle());
+    auto& Q = h->Q;
+    Q.n_s = d->n_s;
+    Q.n_b = d->n_b;
+    Q.ph.resize(d->n_phases);
+    for (int ip = 0; ip < d->n_phases; ++ip) {
+      const pc_phase_desc& s = d->phases[ip];
+      auto& P = Q.ph[ip];
+      P.n_y = s.n_y; P.n_u = s.n_u; P.n_q = s.n_q; P.n_p = s.n_p;
+      P.t_free[0] = s.t0_free != 0; P.t_free[1] = s.tF_free != 0;
+      P.t_fixed[0] = s.t0_fixed; P.t_fixed[1] = s.tF_fixed;
+      P.K = s.K;
+      if (s.K < 1 || !s.n_k || !s.h_k) throw std::runtime_error("phase mesh arrays missing");
+      P.n_k.assign(s.n_k, s.n_k + s.K);
+      P.h_k.assign(s.h_k, s.h_k + s.K);
+      P.jac_row.assign(s.jac_row, s.jac_row + s.n_jac);
+      P.jac_col.assign(s.jac_col, s.jac_col + s.n_jac);
+      P.hess_row.assign(s.hess_row, s.hess_row + s.n_hess);
+      P.hess_col.assign(s.hess_col, s.hess_col + s.n_hess);
+      P.bulk_kernel = s.bulk_kernel ? s.bulk_kernel : "";
+    }
+    Q.point_phase.assign(d->point_phase, d->point_phase + d->n_point);
+    Q.point_kind.assign(d->point_kind, d->point_kind + d->n_point);
+    Q.point_idx.assign(d->point_idx, d->point_idx + d->n_point);
+    Q.jgrad_col.assign(d->jgrad_col, d->jgrad_col + d->n_jgrad);
+    Q.bjac_row.assign(d->bjac_row, d->bjac_row + d->n_bjac);
+    Q.bjac_col.assign(d->bjac_col, d->bjac_col + d->n_bjac);
+    Q.pthess_row.assign(d->pthess_row, d->pthess_row + d->n_pthess);
+    Q.pthess_col.assign(d->pthess_col, d->pthess_col + d->n_pthess);
+    // quadrature tables
+    for (int i = 0; i <= PC_MAX_ORDER; ++i) h->qa_off[i] = h->qw_off[i] = -1;
+    {
+      size_t oa = 0, ow = 0;
+      for (int i = 0; i < d->n_orders; ++i) {
+        const int n = d->orders[i];
+        if (n < 2 || n > PC_MAX_ORDER) throw std::runtime_error("quadrature order outside [2, 20]");
+        h->qa_off[n] = (int32_t)oa;
+        h->qw_off[n] = (int32_t)ow;
+        oa += (size_t)(n - 1) * n;
+        ow += n;
+      }
+      h->qa.assign(d->quad_A, d->quad_A + oa);
+      h->qw.assign(d->quad_w, d->quad_w + ow);
+    }
+    // threads per block
+    int64_t Nmax = 0;
+    for (int ip = 0; ip < d->n_phases; ++ip) {
+      int64_t N = 1;
+      for (int k = 0; k < d->phases[ip].K; ++k) N += d->phases[ip].n_k[k] - 1;
+      Nmax = std::max(Nmax, N);
+    }
+    int TB = d->threads_per_block;
+    if (const char* env = std::getenv("PYCOLLO_AMD_TB")) TB = std::atoi(env);
+    if (TB == 0) TB = Nmax >= 262144 ? 256 : (Nmax >= 65536 ? 128 : 64);
+    if (TB != 64 && TB != 128 && TB != 256) throw std::runtime_error("threads_per_block must be 64, 128 or 256");
+    h->TB = TB;
+    pcp::build_all(Q, TB);
+    for (auto& P : Q.ph)
+      for (int k = 0; k < P.K; ++k)
+        if (h->qa_off[P.n_k[k]] < 0) throw std::runtime_error("no quadrature table for a section order in use");
+    h->device = d->device;
+    h->V_ocp.assign(Q.num_ocp_x, 1.0);
+    h->r_ocp.assign(Q.num_ocp_x, 0.0);
+    h->W_ocp.assign(Q.num_ocp_c, 1.0);
+    h->pd.resize(Q.ph.size());
+    for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+      h->pd[ip].reset(new PhaseDev());
+      auto& P = Q.ph[ip];
+      auto& D = *h->pd[ip];
+      D.n_tiles = (int)P.tile_k0.size() - 1;
+      int nfs = 0;
+      for (int a = 0; a < P.n_y; ++a)
+        for (int l = 0; l < Q.n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
+      D.nfs = nfs;
+      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred);
+      h->lds_max = std::max(h->lds_max, D.lds_bytes);
+      if (D.lds_bytes > 64 * 1024)
+        throw std::runtime_error("tile needs more than 64 KiB of dynamic LDS; use a smaller threads_per_block");
+    }
+    h->n_launches = (int)Q.ph.size() + 1;
+    if (h->device < 0) return;  // structure-only handle
+
+    // ---- device side ----------------------------------------------------------------------------
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= h->device)
+      throw std::runtime_error("requested HIP device is not available (no GPU visible?)");
+    HIP_OK(hipSetDevice(h->device));
+    if (!d->code_object || !d->tail_kernel) throw std::runtime_error("code_object and tail_kernel are required");
+    HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_OK(hipModuleLoad(&h->module, d->code_object));
+    HIP_OK(hipModuleGetFunction(&h->tail_fn, h->module, d->tail_kernel));
+    h->d_qa.upload(h->qa);
+    h->d_qw.upload(h->qw);
+    for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+      auto& P = Q.ph[ip];
+      auto& D = *h->pd[ip];
+      HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
+      D.tile_k0.upload(P.tile_k0);
+      D.sec_s.upload(P.sec_s);
+      D.sec_h.upload(P.h_k);
+      D.sec_E.upload(P.sec_E);
+      D.goff.upload(P.goff);
+      D.hoff.upload(P.hoff);
+      D.hslot0.upload(P.hslot0);
+      D.hslotN.upload(P.hslotN);
+      D.hsum_slot.upload(P.hsum_slot);
+      D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
+    }
+    h->d_point_x.upload(Q.point_x);
+    h->d_tail_owned.upload(Q.tail_owned);
+    h->d_pt_hslot.upload(Q.pt_hslot);
+    h->d_g_indptr.upload(Q.g_indptr);
+    const size_t nG = Q.g_row.size(), nH = Q.h_row.size();
+    h->d_x.alloc(Q.num_x); h->d_lam.alloc(Q.num_c); h->d_c.alloc(Q.num_c);
+    h->d_G.alloc(nG); h->d_H.alloc(nH); h->d_params.alloc(2); h->d_fobj.alloc(1);
+    h->d_grad.alloc(Q.num_x); h->d_norms.alloc(Q.num_c);
+    h->h_x.alloc(Q.num_x); h->h_lam.alloc(Q.num_c); h->h_c.alloc(Q.num_c);
+    h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_params.alloc(2); h->h_fobj.alloc(1);
+    h->h_grad.alloc(Q.num_x); h->h_norms.alloc(Q.num_c);
+    HIP_OK(hipMemset(h->d_lam.p, 0, Q.num_c * sizeof(double)));
+  });
+  if (!ok) return 0;
+  *out = h.release();
+  return 1;
+}
+
+void pc_destroy(pc_handle* h) {
+  if (!h) return;
+  if (h->device >= 0) {
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+  }
+  h->pd.clear();
+  if (h->module) (void)hipModuleUnload(h->module);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int pc_get_info(const pc_handle* h, pc_info* info) {
+  return guarded([&] {
+    if (!h || !info) throw std::runtime_error("null argument");
+    const auto& Q = h->Q;
+    info->n = (int32_t)Q.num_x;
+    info->m = (int32_t)Q.num_c;
+    info->nnz_jac = (int64_t)Q.g_row.size();
+    info->nnz_hess = (int64_t)Q.h_row.size();
+    info->algorithmic_bytes = 8 * (Q.num_x + Q.num_c) + 8 * (Q.num_c + info->nnz_jac + info->nnz_hess);
+    int nt = 0;
+    for (auto& D : h->pd) nt += D->n_tiles;
+    info->n_tiles_total = nt;
+    info->threads_per_block = h->TB;
+    info->lds_bytes_max = h->lds_max;
+    info->n_launches = h->n_launches;
+  });
+}
+
+int pc_sizes(const pc_handle* h, int32_t* n, int32_t* m, int64_t* nnz_jac, int64_t* nnz_hess) {
+  return guarded([&] {
+    if (!h) throw std::runtime_error("null handle");
+    if (n) *n = (int32_t)h->Q.num_x;
+    if (m) *m = (int32_t)h->Q.num_c;
+    if (nnz_jac) *nnz_jac = (int64_t)h->Q.g_row.size();
+    if (nnz_hess) *nnz_hess = (int64_t)h->Q.h_row.size();
+  });
+}
+
+int pc_jac_structure(const pc_handle* h, int32_t* iRow, int32_t* jCol) {
+  return guarded([&] {
+    if (!h || !iRow || !jCol) throw std::runtime_error("null argument");
+    std::memcpy(iRow, h->Q.g_row.data(), h->Q.g_row.size() * sizeof(int32_t));
+    std::memcpy(jCol, h->Q.g_col.data(), h->Q.g_col.size() * sizeof(int32_t));
+  });
+}
+
+int pc_hess_structure(const pc_handle* h, int32_t* iRow, int32_t* jCol) {
+  return guarded([&] {
+    if (!h || !iRow || !jCol) throw std::runtime_error("null argument");
+    std::memcpy(iRow, h->Q.h_row.data(), h->Q.h_row.size() * sizeof(int32_t));
+    std::memcpy(jCol, h->Q.h_col.data(), h->Q.h_col.size() * sizeof(int32_t));
+  });
+}
+
+int pc_set_scaling(pc_handle* h, const double* V, const double* r, const double* W, double w_J) {
+  return guarded([&] {
+    if (!h || !V || !r || !W) throw std::runtime_error("null argument");
+    if (h->device >= 0) {
+      HIP_OK(hipSetDevice(h->device));
+      HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    h->V_ocp.assign(V, V + h->Q.num_ocp_x);
+    h->r_ocp.assign(r, r + h->Q.num_ocp_x);
+    h->W_ocp.assign(W, W + h->Q.num_ocp_c);
+    h->w_J = w_J;
+    upload_scaling(h);
+    h->scaling_set = true;
+  });
+}
+
+int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
+                       double* d_jac, double* d_hess, void* stream) {
+  return guarded([&] {
+    require_device(h);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->h_params.p[0] = obj_factor;
+    h->h_params.p[1] = h->w_J;
+    HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st);
+  });
+}
+
+int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* g, double* jac,
+                double* hess) {
+  return guarded([&] {
+    require_device(h);
+    auto& Q = h->Q;
+    copy_x_in(h, x);
+    std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
+    HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    set_params(h, obj_factor);
+    launch_all(h, h->d_x.p, h->d_lam.p, h->d_c.p, h->d_G.p, h->d_H.p, h->d_fobj.p, nullptr,
+               PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, h->stream);
+    HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    std::memcpy(g, h->h_c.p, Q.num_c * sizeof(double));
+    std::memcpy(jac, h->h_G.p, h->d_G.n * sizeof(double));
+    std::memcpy(hess, h->h_H.p, h->d_H.n * sizeof(double));
+    h->have_cG = true;
+  });
+}
+
+// c and G are produced together on a new x and cached for the companion call (IPOPT evaluates
+// g and jac_g at the same x; pycollo/nlp.py:53-57)
+static void eval_cG(pc_handle* h, const double* x, int new_x) {
+  require_device(h);
+  if (!new_x && h->have_cG) return;
+  auto& Q = h->Q;
+  copy_x_in(h, x);
+  set_params(h, 1.0);
+  launch_all(h, h->d_x.p, nullptr, h->d_c.p, h->d_G.p, nullptr, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G, h->stream);
+  HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->have_cG = true;
+}
+
+int pc_eval_g(pc_handle* h, const double* x, int new_x, double* g) {
+  return guarded([&] {
+    eval_cG(h, x, new_x);
+    std::memcpy(g, h->h_c.p, h->Q.num_c * sizeof(double));
+  });
+}
+
+int pc_eval_jac_g(pc_handle* h, const double* x, int new_x, double* values) {
+  return guarded([&] {
+    eval_cG(h, x, new_x);
+    std::memcpy(values, h->h_G.p, h->d_G.n * sizeof(double));
+  });
+}
+
+int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const double* lambda, int new_lambda,
+              double* values) {
+  (void)new_lambda;
+  return guarded([&] {
+    require_device(h);
+    auto& Q = h->Q;
+    if (new_x) h->have_cG = false;
+    copy_x_in(h, x);
+    std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
+    HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    set_params(h, obj_factor);
+    launch_all(h, h->d_x.p, h->d_lam.p, nullptr, nullptr, h->d_H.p, h->d_fobj.p, nullptr, PC_FLAG_H, h->stream);
+    HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    std::memcpy(values, h->h_H.p, h->d_H.n * sizeof(double));
+  });
+}
+
+static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
+  require_device(h);
+  auto& Q = h->Q;
+  copy_x_in(h, x);
+  set_params(h, 1.0);
+  if (want_grad) HIP_OK(hipMemsetAsync(h->d_grad.p, 0, Q.num_x * sizeof(double), h->stream));
+  // flags = 0: the bulk kernels are skipped entirely, only the endpoint block runs
+  PcTailArgs t;
+  std::memset(&t, 0, sizeof(t));
+  t.x = h->d_x.p;
+  t.fobj = h->d_fobj.p;
+  t.grad = want_grad ? h->d_grad.p : nullptr;
+  t.params = h->d_params.p;
+  t.point_x = h->d_point_x.p;
+  t.point_V = h->d_pointV.p;
+  t.point_r = h->d_pointr.p;
+  t.W_end = h->d_Wend.p;
+  t.c_end_off = Q.c_end_off;
+  t.g_end_base = Q.g_end_base;
+  t.flags = 0;
+  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+    t.ph[ip].n_tiles = 0;
+    t.ph[ip].partials = h->pd[ip]->partials.p;
+    t.ph[ip].scal = h->pd[ip]->scal.p;
+    t.ph[ip].x_off = Q.ph[ip].x_off;
+    t.ph[ip].N = Q.ph[ip].N;
+    t.ph[ip].t_fixed[0] = Q.ph[ip].t_fixed[0];
+    t.ph[ip].t_fixed[1] = Q.ph[ip].t_fixed[1];
+  }
+  size_t sz = sizeof(t);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, h->stream, nullptr, cfg));
+  HIP_OK(hipMemcpyAsync(h->h_fobj.p, h->d_fobj.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (want_grad)
+    HIP_OK(hipMemcpyAsync(h->h_grad.p, h->d_grad.p, Q.num_x * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+}
+
+int pc_eval_f(pc_handle* h, const double* x, int new_x, double* f) {
+  (void)new_x;
+  return guarded([&] {
+    eval_obj(h, x, false);
+    *f = h->h_fobj.p[0];
+  });
+}
+
+int pc_eval_grad_f(pc_handle* h, const double* x, int new_x, double* grad) {
+  (void)new_x;
+  return guarded([&] {
+    eval_obj(h, x, true);
+    std::memcpy(grad, h->h_grad.p, h->Q.num_x * sizeof(double));
+  });
+}
+
+int pc_row_norms_jac(pc_handle* h, const double* x, double* norms) {
+  return guarded([&] {
+    eval_cG(h, x, 1);
+    const int64_t m = h->Q.num_c;
+    const int64_t threads = m * 64;
+    const int blocks = (int)((threads + 255) / 256);
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_g_indptr.p, h->d_G.p,
+                       h->d_norms.p, m);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(h->h_norms.p, h->d_norms.p, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    std::memcpy(norms, h->h_norms.p, m * sizeof(double));
+  });
+}
+
+int pc_synchronize(pc_handle* h) {
+  return guarded([&] {
+    require_device(h);
+    HIP_OK(hipStreamSynchronize(h->stream));
+  });
+}
+
+void* pc_stream(pc_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

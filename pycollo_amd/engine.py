@@ -1,0 +1,369 @@
+"""ctypes binding of the C-ABI engine + the Python-side mirror of pycollo's callback surfaces.
+
+Two reference surfaces are mirrored:
+
+* the legacy cyipopt object protocol ``IPOPTProblem`` (pycollo/nlp.py:36-76): ``objective``,
+  ``gradient``, ``constraints``, ``jacobian``, ``jacobianstructure``, ``hessian``,
+  ``hessianstructure``, ``intermediate`` -> :class:`PycolloGpuProblem`
+* the live CasADi probes ``evaluate_J/g/c/G/G_nonzeros/G_structure/G_num_nonzero`` and the
+  (unimplemented in the reference, implemented here) ``evaluate_H*`` (pycollo/backend.py:1713-1805)
+  -> the same methods on :class:`NlpEngine`
+
+There is no CPU fallback: without the HIP library, the code object or a GPU every evaluation raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import scipy.sparse as sparse
+
+from . import codegen
+from .layout import NlpLayout
+from .mesh import PhaseMesh, build_phase_mesh
+from .model import Model, compile_model
+from .problem import ProblemSpec
+from .quadrature import QuadratureTables
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpycollo_amd.so")
+
+_KIND = {"y0": 0, "yF": 1, "q": 2, "t0": 3, "tF": 4, "s": 5}
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class _PhaseDesc(C.Structure):
+    _fields_ = [("n_y", C.c_int32), ("n_u", C.c_int32), ("n_q", C.c_int32), ("n_p", C.c_int32),
+                ("t0_free", C.c_int32), ("tF_free", C.c_int32),
+                ("t0_fixed", C.c_double), ("tF_fixed", C.c_double),
+                ("K", C.c_int32), ("n_k", _i32p), ("h_k", _f64p),
+                ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
+                ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
+                ("bulk_kernel", C.c_char_p)]
+
+
+class _ProblemDesc(C.Structure):
+    _fields_ = [("n_phases", C.c_int32), ("phases", C.POINTER(_PhaseDesc)), ("n_s", C.c_int32),
+                ("n_point", C.c_int32), ("point_phase", _i32p), ("point_kind", _i32p), ("point_idx", _i32p),
+                ("n_b", C.c_int32),
+                ("n_jgrad", C.c_int32), ("jgrad_col", _i32p),
+                ("n_bjac", C.c_int32), ("bjac_row", _i32p), ("bjac_col", _i32p),
+                ("n_pthess", C.c_int32), ("pthess_row", _i32p), ("pthess_col", _i32p),
+                ("n_orders", C.c_int32), ("orders", _i32p), ("quad_A", _f64p), ("quad_w", _f64p),
+                ("code_object", C.c_char_p), ("tail_kernel", C.c_char_p),
+                ("device", C.c_int32), ("threads_per_block", C.c_int32)]
+
+
+class _Info(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("nnz_jac", C.c_int64), ("nnz_hess", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("n_tiles_total", C.c_int32), ("threads_per_block", C.c_int32),
+                ("lds_bytes_max", C.c_int32), ("n_launches", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libpycollo_amd.so (built in-tree by ``__graft_entry__.build``); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(hipcc required).  pycollo_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.pc_last_error.restype = C.c_char_p
+    lib.pc_create.argtypes = [C.POINTER(_ProblemDesc), C.POINTER(vp)]
+    lib.pc_destroy.argtypes = [vp]
+    lib.pc_destroy.restype = None
+    lib.pc_get_info.argtypes = [vp, C.POINTER(_Info)]
+    lib.pc_sizes.argtypes = [vp, _i32p, _i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.pc_jac_structure.argtypes = [vp, vp, vp]
+    lib.pc_hess_structure.argtypes = [vp, vp, vp]
+    lib.pc_set_scaling.argtypes = [vp, vp, vp, vp, C.c_double]
+    lib.pc_eval_f.argtypes = [vp, vp, C.c_int, vp]
+    lib.pc_eval_grad_f.argtypes = [vp, vp, C.c_int, vp]
+    lib.pc_eval_g.argtypes = [vp, vp, C.c_int, vp]
+    lib.pc_eval_jac_g.argtypes = [vp, vp, C.c_int, vp]
+    lib.pc_eval_h.argtypes = [vp, vp, C.c_int, C.c_double, vp, C.c_int, vp]
+    lib.pc_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.pc_synchronize.argtypes = [vp]
+    lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
+    lib.pc_stream.argtypes = [vp]
+    lib.pc_stream.restype = vp
+    _lib = lib
+    return lib
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+
+
+def _ptr(a, typ):
+    return a.ctypes.data_as(typ) if a.size else C.cast(None, typ)
+
+
+class NlpEngine:
+    """One transcribed NLP (model x meshes x scaling) bound to one GPU (or structure-only)."""
+
+    def __init__(self, problem: ProblemSpec | Model, meshes: list[PhaseMesh] | None = None, *, device: int | None = 0,
+                 threads_per_block: int = 0, quad: QuadratureTables | None = None, build: bool = True):
+        self.model = problem if isinstance(problem, Model) else compile_model(problem)
+        self.quad = quad or QuadratureTables(self.model.quadrature_method)
+        if meshes is None:
+            if isinstance(problem, Model):
+                raise ValueError("meshes are required when a compiled Model is passed")
+            meshes = [build_phase_mesh(self.quad, *ph.mesh.resolved()) for ph in problem.phases]
+        self.meshes = meshes
+        self.layout = NlpLayout(self.model, meshes)
+        self.device = -1 if device is None else int(device)
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self._keep = []
+        code_object = None
+        if self.device >= 0:
+            code_object = codegen.build_code_object(self.model) if build else codegen.code_object_path(self.model)
+            if not os.path.exists(code_object):
+                raise RuntimeError(f"code object {code_object} is missing")
+        self.code_object = code_object
+        desc = self._make_desc(code_object, threads_per_block)
+        if not self._lib.pc_create(C.byref(desc), C.byref(self._h)):
+            raise RuntimeError("pc_create failed: " + self._lib.pc_last_error().decode())
+        info = _Info()
+        self._check(self._lib.pc_get_info(self._h, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in _Info._fields_}
+        self.num_x, self.num_c = info.n, info.m
+        self.nnz_jac, self.nnz_hess = int(info.nnz_jac), int(info.nnz_hess)
+        if (self.num_x, self.num_c) != (self.layout.num_x, self.layout.num_c):
+            raise RuntimeError("layout mismatch between host library and Python bookkeeping")
+        self._jac_struct = None
+        self._hess_struct = None
+        # default scaling: base variable scaling from bounds, base constraint scaling, w_J = 1
+        V, r = self.layout.base_variable_scaling()
+        self.set_scaling(V, r, self.layout.base_constraint_scaling(V), 1.0)
+
+    # ---- descriptor ----------------------------------------------------------------------------
+    def _make_desc(self, code_object, tpb) -> _ProblemDesc:
+        m = self.model
+        keep = self._keep
+        phases = (_PhaseDesc * len(m.phases))()
+        for i, (pm, mesh) in enumerate(zip(m.phases, self.meshes)):
+            n_k = _i32(mesh.n)
+            h_k = np.ascontiguousarray(mesh.h, dtype=np.float64)
+            jr, jc = _i32([r for r, _, _ in pm.jac]), _i32([c for _, c, _ in pm.jac])
+            hr, hc = _i32([r for r, _, _ in pm.hess]), _i32([c for _, c, _ in pm.hess])
+            keep += [n_k, h_k, jr, jc, hr, hc]
+            d = phases[i]
+            d.n_y, d.n_u, d.n_q, d.n_p = pm.n_y, pm.n_u, pm.n_q, pm.n_p
+            d.t0_free, d.tF_free = int(pm.t_free[0]), int(pm.t_free[1])
+            d.t0_fixed, d.tF_fixed = float(pm.t_fixed[0]), float(pm.t_fixed[1])
+            d.K = mesh.K
+            d.n_k, d.h_k = _ptr(n_k, _i32p), _ptr(h_k, _f64p)
+            d.n_jac, d.jac_row, d.jac_col = len(jr), _ptr(jr, _i32p), _ptr(jc, _i32p)
+            d.n_hess, d.hess_row, d.hess_col = len(hr), _ptr(hr, _i32p), _ptr(hc, _i32p)
+            d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
+        pt = m.point
+        pp = _i32([v.phase for v in pt.vars])
+        pk = _i32([_KIND[v.kind] for v in pt.vars])
+        pi = _i32([v.idx for v in pt.vars])
+        jg = _i32([c for c, _ in pt.J_grad])
+        br, bc = _i32([r for r, _, _ in pt.b_jac]), _i32([c for _, c, _ in pt.b_jac])
+        phr, phc = _i32([r for r, _, _ in pt.hess]), _i32([c for _, c, _ in pt.hess])
+        orders = sorted({int(n) for mesh in self.meshes for n in np.unique(mesh.n)})
+        od = _i32(orders)
+        qa = np.ascontiguousarray(np.concatenate([self.quad.A(n).ravel() for n in orders]), dtype=np.float64)
+        qw = np.ascontiguousarray(np.concatenate([self.quad.weights(n).ravel() for n in orders]), dtype=np.float64)
+        keep += [phases, pp, pk, pi, jg, br, bc, phr, phc, od, qa, qw]
+        desc = _ProblemDesc()
+        desc.n_phases, desc.phases, desc.n_s = len(m.phases), phases, m.n_s
+        desc.n_point, desc.point_phase, desc.point_kind, desc.point_idx = len(pt.vars), _ptr(pp, _i32p), _ptr(pk, _i32p), _ptr(pi, _i32p)
+        desc.n_b = len(pt.b)
+        desc.n_jgrad, desc.jgrad_col = len(jg), _ptr(jg, _i32p)
+        desc.n_bjac, desc.bjac_row, desc.bjac_col = len(br), _ptr(br, _i32p), _ptr(bc, _i32p)
+        desc.n_pthess, desc.pthess_row, desc.pthess_col = len(phr), _ptr(phr, _i32p), _ptr(phc, _i32p)
+        desc.n_orders, desc.orders, desc.quad_A, desc.quad_w = len(orders), _ptr(od, _i32p), _ptr(qa, _f64p), _ptr(qw, _f64p)
+        desc.code_object = code_object.encode() if code_object else None
+        desc.tail_kernel = b"pc_tail"
+        desc.device = self.device
+        desc.threads_per_block = int(tpb)
+        return desc
+
+    def _check(self, ok):
+        if not ok:
+            raise RuntimeError(self._lib.pc_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scaling -------------------------------------------------------------------------------
+    def set_scaling(self, V_ocp, r_ocp, W_ocp, w_J: float = 1.0):
+        """V, r per OCP variable; W per OCP constraint; objective weight (backend.py:1459-1463,1684-1689)."""
+        self.V_ocp = np.ascontiguousarray(V_ocp, dtype=np.float64)
+        self.r_ocp = np.ascontiguousarray(r_ocp, dtype=np.float64)
+        self.W_ocp = np.ascontiguousarray(W_ocp, dtype=np.float64)
+        self.w_J = float(w_J)
+        if self.V_ocp.shape != (self.layout.num_ocp_x,) or self.r_ocp.shape != (self.layout.num_ocp_x,):
+            raise ValueError(f"V_ocp / r_ocp must have {self.layout.num_ocp_x} entries")
+        if self.W_ocp.shape != (self.layout.num_ocp_c,):
+            raise ValueError(f"W_ocp must have {self.layout.num_ocp_c} entries")
+        self._check(self._lib.pc_set_scaling(self._h, self.V_ocp.ctypes.data, self.r_ocp.ctypes.data,
+                                             self.W_ocp.ctypes.data, self.w_J))
+
+    # ---- structure -----------------------------------------------------------------------------
+    def evaluate_G_structure(self):
+        """(row_indices, col_indices), CSR row-major (backend.py:1747-1761 returns CCS order)."""
+        if self._jac_struct is None:
+            r = np.empty(self.nnz_jac, dtype=np.int32)
+            c = np.empty(self.nnz_jac, dtype=np.int32)
+            self._check(self._lib.pc_jac_structure(self._h, r.ctypes.data, c.ctypes.data))
+            self._jac_struct = (r, c)
+        return self._jac_struct
+
+    def evaluate_H_structure(self):
+        if self._hess_struct is None:
+            r = np.empty(self.nnz_hess, dtype=np.int32)
+            c = np.empty(self.nnz_hess, dtype=np.int32)
+            self._check(self._lib.pc_hess_structure(self._h, r.ctypes.data, c.ctypes.data))
+            self._hess_struct = (r, c)
+        return self._hess_struct
+
+    def evaluate_G_num_nonzero(self):
+        return self.nnz_jac
+
+    def evaluate_H_num_nonzero(self):
+        return self.nnz_hess
+
+    def csr_to_ccs_permutation(self):
+        """Permutation p with ``values_ccs = values_csr[p]`` (CasADi column-major order, backend.py:1754-1761)."""
+        r, c = self.evaluate_G_structure()
+        return np.lexsort((r, c))
+
+    # ---- evaluation (host pointers) ------------------------------------------------------------
+    def _x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        if x.shape[0] != self.num_x:
+            raise ValueError(f"x must have {self.num_x} entries")
+        return x
+
+    def evaluate_J(self, x):
+        x = self._x(x)
+        out = C.c_double()
+        self._check(self._lib.pc_eval_f(self._h, x.ctypes.data, 1, C.addressof(out)))
+        return out.value
+
+    def evaluate_g(self, x):
+        x = self._x(x)
+        g = np.empty(self.num_x)
+        self._check(self._lib.pc_eval_grad_f(self._h, x.ctypes.data, 1, g.ctypes.data))
+        return g
+
+    def evaluate_c(self, x, new_x=True):
+        x = self._x(x)
+        c = np.empty(self.num_c)
+        self._check(self._lib.pc_eval_g(self._h, x.ctypes.data, int(new_x), c.ctypes.data))
+        return c
+
+    def evaluate_G_nonzeros(self, x, new_x=True):
+        x = self._x(x)
+        v = np.empty(self.nnz_jac)
+        self._check(self._lib.pc_eval_jac_g(self._h, x.ctypes.data, int(new_x), v.ctypes.data))
+        return v
+
+    def evaluate_G(self, x):
+        r, c = self.evaluate_G_structure()
+        return sparse.coo_matrix((self.evaluate_G_nonzeros(x), (r, c)), shape=(self.num_c, self.num_x))
+
+    def evaluate_H_nonzeros(self, x, obj_factor, lagrange, new_x=True):
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64).reshape(-1)
+        if lam.shape[0] != self.num_c:
+            raise ValueError(f"lagrange must have {self.num_c} entries")
+        v = np.empty(self.nnz_hess)
+        self._check(self._lib.pc_eval_h(self._h, x.ctypes.data, int(new_x), float(obj_factor), lam.ctypes.data, 1,
+                                        v.ctypes.data))
+        return v
+
+    def evaluate_H(self, x, obj_factor, lagrange):
+        r, c = self.evaluate_H_structure()
+        return sparse.coo_matrix((self.evaluate_H_nonzeros(x, obj_factor, lagrange), (r, c)),
+                                 shape=(self.num_x, self.num_x))
+
+    def evaluate_all(self, x, obj_factor, lagrange):
+        """Fused c, G values, H values at one point (one launch sequence, one round trip)."""
+        x = self._x(x)
+        lam = np.ascontiguousarray(lagrange, dtype=np.float64).reshape(-1)
+        c, g, h = np.empty(self.num_c), np.empty(self.nnz_jac), np.empty(self.nnz_hess)
+        self._check(self._lib.pc_eval_all(self._h, x.ctypes.data, float(obj_factor), lam.ctypes.data, c.ctypes.data,
+                                          g.ctypes.data, h.ctypes.data))
+        return c, g, h
+
+    def G_row_norms(self, x):
+        x = self._x(x)
+        out = np.empty(self.num_c)
+        self._check(self._lib.pc_row_norms_jac(self._h, x.ctypes.data, out.ctypes.data))
+        return out
+
+    # ---- evaluation (device pointers; torch tensors or raw addresses) ---------------------------
+    def evaluate_all_device(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None):
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._check(self._lib.pc_eval_all_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
+                                                 addr(d_G), addr(d_H), stream))
+
+    def synchronize(self):
+        self._check(self._lib.pc_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return self._lib.pc_stream(self._h)
+
+
+class PycolloGpuProblem:
+    """cyipopt ``problem_obj`` with the method names of ``IPOPTProblem`` (pycollo/nlp.py:36-76).
+
+    ``ipopt.problem(n=p.n, m=p.m, problem_obj=p, lb=..., ub=..., cl=..., cu=...)`` works wherever
+    cyipopt exists; x, lagrange and obj_factor are in IPOPT's (scaled) space like the reference's."""
+
+    def __init__(self, engine: NlpEngine):
+        self.engine = engine
+        self.n, self.m = engine.num_x, engine.num_c
+        self.obj_func_eval_counter = 0  # nlp.py:45
+
+    def objective(self, x):
+        self.obj_func_eval_counter += 1
+        return self.engine.evaluate_J(x)
+
+    def gradient(self, x):
+        return self.engine.evaluate_g(x)
+
+    def constraints(self, x):
+        return self.engine.evaluate_c(x)
+
+    def jacobian(self, x):
+        return self.engine.evaluate_G_nonzeros(x)
+
+    def jacobianstructure(self):
+        return self.engine.evaluate_G_structure()
+
+    def hessian(self, x, lagrange, obj_factor):
+        return self.engine.evaluate_H_nonzeros(x, obj_factor, lagrange)
+
+    def hessianstructure(self):
+        return self.engine.evaluate_H_structure()
+
+    def intermediate(self, alg_mod, iter_count, obj_value, inf_pr, inf_du, mu, d_norm, regularization_size,
+                     alpha_du, alpha_pr, ls_trials):
+        pass

@@ -57,6 +57,9 @@ class PhaseModel:
     mp: list[sym.Symbol]
     mg: list[sym.Symbol]
     hess: list[tuple[int, int, sym.Expr]]
+    # named numeric constants (auxiliary data / eliminated variables) kept symbolic so that SymPy
+    # never folds them into the expressions (exp(R_E/h_0) style overflow, evaluation-order drift)
+    consts: list[tuple[sym.Symbol, float]] = field(default_factory=list)
     # bounds of the needed variables in x order: y, u, q, t (for scaling)
     x_bounds: list[tuple[float, float]] = field(default_factory=list)
     p_bounds: list[tuple[float, float]] = field(default_factory=list)
@@ -112,6 +115,7 @@ class PointModel:
     sigma: sym.Symbol                      # objective factor (already multiplied by w_J by caller)
     lam: list[sym.Symbol]                  # endpoint multipliers (already multiplied by W_e)
     hess: list[tuple[int, int, sym.Expr]]  # lower triangle in xb index of sigma*J + lam.b
+    consts: list[tuple[sym.Symbol, float]] = field(default_factory=list)
     b_bounds: list[tuple[float, float]] = field(default_factory=list)
 
 
@@ -150,6 +154,42 @@ def _resolve_aux(aux: dict, primitives: set[sym.Symbol]) -> dict:
     if pending:
         raise ValueError("auxiliary data substitution exceeded the maximum depth")
     return resolved
+
+
+class _ConstPool:
+    """Maps numeric auxiliary data / eliminated variables to canonical constant symbols K<i>.
+
+    0 and +-1 are substituted as numbers (CasADi's SX constructors simplify x*0, x*1 and x+0 the same
+    way, so they never reach the structural pattern); every other value stays a named constant."""
+
+    def __init__(self, prefix: str):
+        self.prefix = prefix
+        self.table: list[tuple[sym.Symbol, float]] = []
+        self._by_key: dict = {}
+
+    def get(self, name: str, value: float):
+        value = float(value)
+        if value in (0.0, 1.0, -1.0):
+            return sym.Integer(int(value))
+        key = (name, value)
+        k = self._by_key.get(key)
+        if k is None:
+            k = sym.Symbol(f"{self.prefix}{len(self.table)}", real=True)
+            self.table.append((k, value))
+            self._by_key[key] = k
+        return k
+
+
+def _split_aux(aux: dict, pool: _ConstPool) -> tuple[dict, dict]:
+    """(expression aux, constant map) -- numeric leaves become pooled constant symbols."""
+    expr_aux, const_map = {}, {}
+    for k, v in aux.items():
+        v = sym.sympify(v)
+        if v.is_number:
+            const_map[k] = pool.get(str(k), float(v))
+        else:
+            expr_aux[k] = v
+    return expr_aux, const_map
 
 
 def _check_free(expr: sym.Expr, allowed: set, what: str):
@@ -193,9 +233,10 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
 
         y_used = [y for y, nd in zip(ph._y, y_need) if nd]
         u_used = [u for u, nd in zip(ph._u, u_need) if nd]
-        consts = dict(s_const)
-        consts.update({y: 0.5 * (lo + hi) for y, (lo, hi), nd in zip(ph._y, y_b, y_need) if not nd})
-        consts.update({u: 0.5 * (lo + hi) for u, (lo, hi), nd in zip(ph._u, u_b, u_need) if not nd})
+        pool = _ConstPool("K")
+        consts = {s: pool.get(str(s), val) for s, val in s_const.items()}
+        consts.update({y: pool.get(str(y), 0.5 * (lo + hi)) for y, (lo, hi), nd in zip(ph._y, y_b, y_need) if not nd})
+        consts.update({u: pool.get(str(u), 0.5 * (lo + hi)) for u, (lo, hi), nd in zip(ph._u, u_b, u_need) if not nd})
         z_user = y_used + u_used
         z_canon = [sym.Symbol(f"z{i}", real=True) for i in range(len(z_user))]
         var_map = dict(zip(z_user, z_canon))
@@ -207,11 +248,12 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
         clash = set(aux) & primitives
         if clash:
             raise ValueError(f"auxiliary data redefines variables {sorted(map(str, clash))}")
-        aux_res = _resolve_aux(aux, primitives)
+        aux_expr, const_map = _split_aux(aux, pool)
+        aux_res = _resolve_aux(aux_expr, primitives)
 
         def lower(e, what):
-            e = sym.sympify(e).xreplace(aux_res).xreplace(consts)
-            _check_free(e, primitives, what)
+            e = sym.sympify(e).xreplace(aux_res).xreplace(const_map).xreplace(consts)
+            _check_free(e, primitives | {k for k, _ in pool.table}, what)
             return e.xreplace(var_map)
 
         # equations of eliminated states are dropped together with the state (backend keeps
@@ -270,7 +312,7 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
                         t_free=(bool(t_need[0]), bool(t_need[1])),
                         t_fixed=(0.5 * sum(t0_b), 0.5 * sum(tF_b)),
                         z=z_canon, s=s_canon, f=f, p=p, g=g, jac=jac, mf=mf, mp=mp, mg=mg, hess=hess,
-                        x_bounds=x_bounds, p_bounds=p_bounds,
+                        consts=list(pool.table), x_bounds=x_bounds, p_bounds=p_bounds,
                         y_t0_bounds=[b for b, nd in zip(y0_b, y_need) if nd],
                         y_tF_bounds=[b for b, nd in zip(yF_b, y_need) if nd])
         phases.append(pm)
@@ -286,7 +328,7 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
                     point_subs[usym] = cs
                 k += 1
             else:
-                point_subs[y0] = point_subs[yF] = consts[y]
+                point_subs[y0] = point_subs[yF] = 0.5 * sum(y_b[i])
         k = 0
         for i, nd in enumerate(q_need):
             usym = ph.integral_variables[i]
@@ -313,13 +355,16 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
     point_subs.update(s_const)
 
     # ---- endpoint functions ---------------------------------------------------------------------
-    aux_pt = _resolve_aux(dict(prob.auxiliary_data), set(point_subs))
+    ppool = _ConstPool("K")
+    point_subs = {k: (ppool.get(str(k), v) if isinstance(v, (int, float)) else v) for k, v in point_subs.items()}
+    aux_pt_expr, pt_const_map = _split_aux(dict(prob.auxiliary_data), ppool)
+    aux_pt = _resolve_aux(aux_pt_expr, set(point_subs))
     xb = [pv.symbol for pv in point_vars]
     xb_set = set(xb)
 
     def lower_pt(e, what):
-        e = sym.sympify(e).xreplace(aux_pt).xreplace(point_subs)
-        _check_free(e, xb_set, what)
+        e = sym.sympify(e).xreplace(aux_pt).xreplace(pt_const_map).xreplace(point_subs)
+        _check_free(e, xb_set | {k for k, _ in ppool.table}, what)
         return e
 
     J = lower_pt(prob.objective_function, "objective function")
@@ -357,7 +402,7 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
     b_bounds = _pb._bounds_for(list(range(len(b))), prob.bounds.endpoint_constraints, "endpoint constraint") if b else []
 
     point = PointModel(vars=point_vars, J=J, b=b, J_grad=J_grad, b_jac=b_jac, sigma=sigma, lam=lam,
-                       hess=pt_hess, b_bounds=b_bounds)
+                       hess=pt_hess, consts=list(ppool.table), b_bounds=b_bounds)
     model = Model(name=prob.name, phases=phases, point=point, n_s=len(s_canon), s_bounds=s_bounds,
                   scaling_method=prob.scaling_method, quadrature_method=prob.quadrature_method)
     model.digest = model_digest(model)
@@ -374,12 +419,12 @@ def model_digest(model: Model) -> str:
             h.update(b"|")
 
     for pm in model.phases:
-        put("phase", pm.n_y, pm.n_u, pm.n_q, pm.n_p, pm.n_s, pm.t_free)
+        put("phase", pm.n_y, pm.n_u, pm.n_q, pm.n_p, pm.n_s, pm.t_free, [(str(k), v) for k, v in pm.consts])
         put([sym.srepr(e) for e in pm.f + pm.p + pm.g])
         put([(r, c, sym.srepr(e)) for r, c, e in pm.jac])
         put([(r, c, sym.srepr(e)) for r, c, e in pm.hess])
     pt = model.point
-    put("point", [(v.phase, v.kind, v.idx) for v in pt.vars], sym.srepr(pt.J), [sym.srepr(e) for e in pt.b])
+    put("point", [(str(k), v) for k, v in pt.consts], [(v.phase, v.kind, v.idx) for v in pt.vars], sym.srepr(pt.J), [sym.srepr(e) for e in pt.b])
     put([(c, sym.srepr(e)) for c, e in pt.J_grad], [(r, c, sym.srepr(e)) for r, c, e in pt.b_jac])
     put([(r, c, sym.srepr(e)) for r, c, e in pt.hess])
     return h.hexdigest()[:16]
