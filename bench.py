@@ -1,0 +1,174 @@
+"""Headline benchmark: NLP-callback evaluations per second (c + jac_g + hess at one (x, sigma, lambda)).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused ``pc_eval_all_device`` over the whole transcribed NLP with x~ and lambda already
+resident in HBM and c~, G~, H~ left in HBM.  N = 1: BASELINE.json configs[1] -- hypersensitive problem,
+1 phase, 2000 mesh sections x 6 Lobatto nodes = 10 001 collocation nodes.  N > 1: the mesh grows to
+2000*N sections and is sharded by contiguous section ranges, one rank per GPU (weak scaling: 10 001
+nodes per GPU); every step ends with the path's exchange (integral partial sums all-reduced, shard
+outputs all-gathered) -- see pycollo_amd/sharding.py.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(K_sections: int, order: int, budget_s: float = 15.0):
+    """Time the oracle's C restatement (single thread) on the GPU box's host cores."""
+    try:
+        from oracle import cport
+        return cport.time_hypersensitive(K_sections, order, budget_s)
+    except Exception as exc:  # the baseline is reported, never required for the GPU number
+        return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": f"unavailable: {exc}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--sections", type=int, default=2000, help="mesh sections per GPU")
+    ap.add_argument("--order", type=int, default=6, help="nodes per section")
+    ap.add_argument("--problem", default="hypersensitive")
+    ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: pycollo_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pycollo_amd import problems
+    from pycollo_amd.engine import NlpEngine
+
+    K_total = args.sections * world
+    prob = problems.REGISTRY[args.problem](K=K_total, order=args.order)
+    # a dedicated (non-default) stream: the library treats a NULL stream as "use the handle's own stream",
+    # and torch events only see the stream they are recorded on
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
+
+    if world == 1:
+        eng = NlpEngine(prob, device=local_rank, threads_per_block=args.tpb)
+        rng = np.random.default_rng(1234)
+        x = torch.from_numpy(rng.uniform(-0.45, 0.45, eng.num_x)).to(dev)
+        lam = torch.from_numpy(np.random.default_rng(1235).normal(size=eng.num_c)).to(dev)
+        c = torch.empty(eng.num_c, dtype=torch.float64, device=dev)
+        G = torch.empty(eng.nnz_jac, dtype=torch.float64, device=dev)
+        H = torch.empty(eng.nnz_hess, dtype=torch.float64, device=dev)
+
+        def step():
+            eng.evaluate_all_device(x, 1.0, lam, c, G, H, stream)
+
+        def bulk_only():
+            eng.launch_bulk_only(x, lam, c, G, H, stream)
+
+        info = eng.info
+        alg_bytes = info["algorithmic_bytes"]
+        workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes "
+                    f"= {eng.layout.phases[0].N} collocation nodes")
+        extra = {"num_x": eng.num_x, "num_c": eng.num_c, "nnz_jac": eng.nnz_jac, "nnz_hess": eng.nnz_hess,
+                 "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"],
+                 "launches_per_eval": info["n_launches"]}
+    else:
+        from pycollo_amd.sharding import ShardedNlp
+        sh = ShardedNlp(prob, device=local_rank, threads_per_block=args.tpb)
+        rng = np.random.default_rng(1234)
+        x = torch.from_numpy(rng.uniform(-0.45, 0.45, sh.num_x)).to(dev)
+        lam = torch.from_numpy(np.random.default_rng(1235).normal(size=sh.num_c)).to(dev)
+
+        def step():
+            sh.evaluate_all_device(x, 1.0, lam, stream)
+
+        bulk_only = None
+        alg_bytes = sh.local_algorithmic_bytes
+        workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes sharded by "
+                    f"section over {world} GPUs ({args.sections} sections = {args.sections * (args.order - 1) + 1} "
+                    f"nodes per GPU)")
+        extra = {"num_x": sh.num_x, "num_c": sh.num_c, "nnz_jac": sh.nnz_jac, "nnz_hess": sh.nnz_hess,
+                 "exchange": "all_reduce(partial sums) + all_gather(c, G, H shards)"}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    evals_per_s = args.steps * world / dt if world > 1 else args.steps / dt
+
+    # ---- dominant kernel (bulk): K back-to-back launches between two HIP events on the launch stream
+    roofline = None
+    if bulk_only is not None:
+        for _ in range(20):
+            bulk_only()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            bulk_only()
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / args.steps
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(k_ms * 1e3, 3),
+                    "method": f"{args.steps} back-to-back bulk-kernel launches between two HIP events on the launch stream"}
+
+    if rank == 0:
+        out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": workload, **extra}}
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu:
+            cb = cpu_baseline(args.sections, args.order)
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

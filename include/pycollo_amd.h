@@ -125,6 +125,10 @@ int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* 
  * the handle's stream).  No host synchronisation is performed. */
 int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda,
                        double* d_g, double* d_jac, double* d_hess, void* stream);
+/* profiling aid: launches only the per-phase bulk kernels of pc_eval_all_device (no tail kernel),
+ * so that bench.py can time the dominant kernel between two HIP events */
+int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,
+                          double* d_hess, void* stream);
 int pc_synchronize(pc_handle* h);
 
 /* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling

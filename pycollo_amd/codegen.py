@@ -198,6 +198,7 @@ def _kernels_stamp() -> str:
     for fn in ("pc_kernels.hpp", "pc_args.h"):
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())
+    h.update(b"flags:-O3 -ffp-contract=off")
     return h.hexdigest()[:12]
 
 
@@ -224,7 +225,9 @@ def build_code_object(model: Model, force: bool = False, verbose: bool = False) 
     src = out[:-6] + ".hip"
     with open(src, "w") as f:
         f.write(generate_source(model))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17",
+    # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
+    # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
            f"-I{CSRC}", "-o", out + ".tmp", src]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -133,9 +133,9 @@ struct pc_handle {
 namespace {
 
 void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
-                double* d_fobj, double* d_grad, int flags, hipStream_t st) {
+                double* d_fobj, double* d_grad, int flags, hipStream_t st, bool bulk = true, bool tail = true) {
   auto& Q = h->Q;
-  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+  for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
     PcPhaseArgs a;
@@ -176,6 +176,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
     HIP_OK(hipModuleLaunchKernel(D.fn, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
   }
+  if (!tail) return;
   PcTailArgs t;
   std::memset(&t, 0, sizeof(t));
   t.x = d_x;
@@ -508,6 +509,16 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
     h->h_params.p[1] = h->w_J;
     HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, st));
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st);
+  });
+}
+
+int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,
+                          double* d_hess, void* stream) {
+  return guarded([&] {
+    require_device(h);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, true,
+               false);
   });
 }
 

@@ -74,6 +74,13 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"(hipcc required).  pycollo_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.
+    # Importing torch first makes the dynamic loader resolve this library's libamdhip64.so.7 to the copy
+    # torch already mapped; the other order leaves two HSA runtimes fighting over the device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     lib.pc_last_error.restype = C.c_char_p
@@ -92,6 +99,7 @@ def load_library() -> C.CDLL:
     lib.pc_eval_h.argtypes = [vp, vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.pc_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.pc_launch_bulk_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_stream.argtypes = [vp]
@@ -322,6 +330,13 @@ class NlpEngine:
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
         self._check(self._lib.pc_eval_all_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
                                                  addr(d_G), addr(d_H), stream))
+
+    def launch_bulk_only(self, d_x, d_lam, d_c, d_G, d_H, stream=None):
+        """Profiling aid: only the bulk kernels of :meth:`evaluate_all_device`."""
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._check(self._lib.pc_launch_bulk_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
+                                                    stream))
 
     def synchronize(self):
         self._check(self._lib.pc_synchronize(self._h))

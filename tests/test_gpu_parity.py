@@ -1,0 +1,242 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on identical seeded inputs, the reference's known answers, and size-independent properties
+at BASELINE.json's full sizes.
+
+Tolerance (north_star): index arrays bit-exact; floating-point values within 1e-10 relative.  "Relative"
+is taken per output block against the block's largest magnitude (rel_err in conftest.py): single entries
+that are sums of large cancelling terms (a defect near convergence) cannot be compared entry-wise.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle.ref_numpy import OracleNlp
+from pycollo_amd import problems
+from pycollo_amd.quadrature import QuadratureTables
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def tab():
+    return QuadratureTables("lobatto")
+
+
+def _engine(prob, **kw):
+    from pycollo_amd.engine import NlpEngine
+    return NlpEngine(prob, device=0, **kw)
+
+
+def _check_all(eng, ora, seed=1, xlo=-0.45, xhi=0.45):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(xlo, xhi, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    sigma = 0.6
+    c, G, H = eng.evaluate_all(x, sigma, lam)
+    cr, Gr, Hr = ora.c(x), ora.G(x), ora.H(x, sigma, lam)
+    assert rel_err(c, cr) < TOL
+    assert rel_err(G, Gr) < TOL
+    assert rel_err(H, Hr) < TOL
+    # the separate IPOPT callbacks agree with the fused call
+    assert rel_err(eng.evaluate_c(x), cr) < TOL
+    assert rel_err(eng.evaluate_G_nonzeros(x, new_x=False), Gr) < TOL
+    assert rel_err(eng.evaluate_H_nonzeros(x, sigma, lam), Hr) < TOL
+    assert abs(eng.evaluate_J(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+    assert rel_err(eng.evaluate_g(x), ora.grad_J(x)) < TOL
+    for got, ref in ((eng.evaluate_G_structure(), ora.G_structure()), (eng.evaluate_H_structure(), ora.H_structure())):
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+    return x, lam
+
+
+CASES = [("brachistochrone", {}), ("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=500, order=4)),
+         ("shuttle", dict(K=60, order=5)), ("double_pendulum", {}), ("two_phase_transfer", {}),
+         ("delta_iii", dict(K=9, order=4))]
+
+
+@pytest.mark.parametrize("tpb", [64, 256])
+@pytest.mark.parametrize("name,kw", CASES)
+def test_parity_with_oracle(built, tab, name, kw, tpb):
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob, threads_per_block=tpb)
+    rng = np.random.default_rng(11)
+    W = rng.uniform(0.5, 2.0, eng.layout.num_ocp_c)
+    eng.set_scaling(eng.V_ocp, eng.r_ocp, W, 1.7)
+    ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=W, w_J=1.7)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)   # keep |r| away from 0 for mu/r^3
+    _check_all(eng, ora, xlo=lo, xhi=hi)
+    eng.close()
+
+
+def test_known_answers_brachistochrone(built, known_answers):
+    """tests/unit/test_iteration.py:305-318, 339-354, 371-385 evaluated by the HIP path."""
+    eng = _engine(problems.brachistochrone())
+    x = known_answers["EXPECT_X_TILDE_BR"]
+    np.testing.assert_almost_equal(eng.evaluate_J(x), 0.8243386694458454)
+    g = np.zeros(125); g[124] = 10
+    np.testing.assert_allclose(eng.evaluate_g(x), g)
+    c = eng.evaluate_c(x)
+    np.testing.assert_allclose(c, np.zeros(90), atol=10e-2)
+    assert np.max(np.abs(c)) < 1e-8
+    eng.close()
+
+
+def test_known_answers_double_pendulum(built, known_answers):
+    """tests/unit/test_iteration.py:290-302, 321-336."""
+    eng = _engine(problems.double_pendulum())
+    x = known_answers["EXPECT_X_TILDE_DP"]
+    assert eng.evaluate_J(x) == 100
+    g = np.zeros(190); g[186] = 1000
+    np.testing.assert_allclose(eng.evaluate_g(x), g)
+    eng.close()
+
+
+def test_ragged_and_mixed_order_mesh(built, tab):
+    """ph-refined style mesh: non-uniform section sizes, orders 2..10 mixed, tile boundaries anywhere."""
+    rng = np.random.default_rng(5)
+    K = 157
+    prob = problems.two_phase_transfer()
+    A, B = prob.phases
+    A.mesh.number_mesh_sections = K
+    A.mesh.mesh_section_sizes = rng.uniform(0.2, 1.0, K)
+    A.mesh.number_mesh_section_nodes = rng.integers(2, 11, K)
+    B.mesh.number_mesh_sections = 3
+    B.mesh.mesh_section_sizes = [0.2, 0.5, 0.3]
+    B.mesh.number_mesh_section_nodes = [10, 2, 7]
+    for tpb in (64, 128):
+        eng = _engine(prob, threads_per_block=tpb)
+        ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+        _check_all(eng, ora, seed=tpb)
+        eng.close()
+
+
+def test_smallest_meshes(built, tab):
+    """K = 1 with n = 2 (N = 2: both nodes are endpoints) and K = 1, n = 3."""
+    for K, n in ((1, 2), (1, 3), (2, 2)):
+        prob = problems.two_phase_transfer(K=K, order=n)
+        prob.phases[1].mesh.number_mesh_sections = K
+        prob.phases[1].mesh.number_mesh_section_nodes = n
+        eng = _engine(prob)
+        ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+        _check_all(eng, ora, seed=K * 10 + n)
+        eng.close()
+
+
+def test_radau_tables_as_data(built):
+    """tables are data -- the Radau scheme (weights summing to 2) runs through unchanged."""
+    prob = problems.cart_pole(K=12, order=5)
+    prob.quadrature_method = "radau"
+    eng = _engine(prob)
+    ora = OracleNlp(prob, QuadratureTables("radau"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    _check_all(eng, ora)
+    eng.close()
+
+
+def test_scaling_none_and_reset(built, tab):
+    prob = problems.cart_pole(K=20, order=4)
+    prob.scaling_method = None
+    eng = _engine(prob)
+    assert np.all(eng.V_ocp == 1) and np.all(eng.r_ocp == 0)
+    ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    x, lam = _check_all(eng, ora)
+    # changing the scaling invalidates the cached c / G of the previous x
+    W2 = 2.0 * eng.W_ocp
+    c1 = eng.evaluate_c(x)
+    eng.set_scaling(eng.V_ocp, eng.r_ocp, W2, 1.0)
+    assert rel_err(eng.evaluate_c(x, new_x=False), 2.0 * c1) < TOL
+    eng.close()
+
+
+def test_row_norms_and_constraint_scaling(built, tab):
+    """pycollo/scaling.py:370-430: W from the row norms of G evaluated with W = 1, without densifying."""
+    from pycollo_amd.scaling import constraint_scaling
+    prob = problems.two_phase_transfer(K=9, order=4)
+    eng = _engine(prob)
+    ones = np.ones(eng.layout.num_ocp_c)
+    eng.set_scaling(eng.V_ocp, eng.r_ocp, ones, 1.0)
+    ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=ones, w_J=1.0)
+    x = np.random.default_rng(2).uniform(-0.4, 0.4, eng.num_x)
+    rn = eng.G_row_norms(x)
+    assert rel_err(rn, ora.G_row_norms(x)) < TOL
+    W = constraint_scaling(eng, x)
+    # reference formula restated with the oracle's norms
+    lay = eng.layout
+    ref = np.empty(lay.num_ocp_c)
+    for pl, pm in zip(lay.phases, eng.model.phases):
+        o = pl.ocp_c_off
+        ref[o:o + pm.n_y] = 1.0 / eng.V_ocp[pl.ocp_x_off:pl.ocp_x_off + pm.n_y]
+        pn = ora.G_row_norms(x)[pl.c_path_off:pl.c_int_off].reshape(pm.n_p, pl.N)
+        ref[o + pm.n_y:o + pm.n_y + pm.n_p] = 1.0 / pn.mean(axis=1)
+        ref[o + pm.n_y + pm.n_p:o + pm.n_y + pm.n_p + pm.n_q] = 1.0 / eng.V_ocp[pl.ocp_x_off + pm.n_z:pl.ocp_x_off + pm.n_z + pm.n_q]
+    ref[lay.ocp_c_end_off:] = 1.0 / ora.G_row_norms(x)[lay.c_end_off:]
+    np.testing.assert_allclose(W, ref, rtol=1e-10)
+    eng.close()
+
+
+def test_nan_inf_pass_through(built):
+    """IPOPT semantics: NaN / Inf are written through, never trapped."""
+    eng = _engine(problems.hypersensitive(K=8, order=4))
+    x = np.zeros(eng.num_x)
+    x[3] = np.nan
+    c = eng.evaluate_c(x)
+    assert np.isnan(c).any() and np.isfinite(c).any()
+    eng.close()
+
+
+def test_device_resident_api_matches_host_api(built):
+    import torch
+    eng = _engine(problems.cart_pole(K=300, order=4))
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-0.4, 0.4, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    c, G, H = eng.evaluate_all(x, 0.3, lam)
+    dev = torch.device("cuda", 0)
+    dx, dl = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    dc = torch.empty(eng.num_c, dtype=torch.float64, device=dev)
+    dG = torch.empty(eng.nnz_jac, dtype=torch.float64, device=dev)
+    dH = torch.empty(eng.nnz_hess, dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    eng.evaluate_all_device(dx, 0.3, dl, dc, dG, dH, s.cuda_stream)
+    s.synchronize()
+    # bitwise: same kernels, same inputs, fixed reduction order
+    assert np.array_equal(dc.cpu().numpy(), c) and np.array_equal(dG.cpu().numpy(), G) and np.array_equal(dH.cpu().numpy(), H)
+    eng.close()
+
+
+# ---- BASELINE.json full sizes: size-independent properties --------------------------------------
+FULL = [("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=5000, order=4)),
+        ("shuttle", dict(K=20000, order=4))]
+
+
+@pytest.mark.parametrize("name,kw", FULL)
+def test_full_size_properties(built, tab, name, kw):
+    """configs[1..3] at full size: (1) parity with the vectorised oracle (it still finishes in seconds),
+    (2) run-to-run bit reproducibility, (3) linearity of H in (sigma, lambda), (4) G^T lambda contraction
+    equals the directional derivative of lambda.c (checksum of the whole Jacobian against c alone)."""
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    rng = np.random.default_rng(1234)
+    x = rng.uniform(-0.45, 0.45, eng.num_x)
+    lam = np.random.default_rng(1235).normal(size=eng.num_c)
+    c, G, H = eng.evaluate_all(x, 1.0, lam)
+    assert rel_err(c, ora.c(x)) < TOL and rel_err(G, ora.G(x)) < TOL and rel_err(H, ora.H(x, 1.0, lam)) < TOL
+    c2, G2, H2 = eng.evaluate_all(x, 1.0, lam)
+    assert np.array_equal(c, c2) and np.array_equal(G, G2) and np.array_equal(H, H2)
+    # linearity: H(2 sigma, 2 lam) = 2 H(sigma, lam);  H(s1+s2, l1+l2) = H(s1,l1) + H(s2,l2)
+    lam2 = rng.normal(size=eng.num_c)
+    Ha = eng.evaluate_H_nonzeros(x, 0.25, lam2)
+    Hs = eng.evaluate_H_nonzeros(x, 1.25, lam + lam2)
+    assert rel_err(Hs, H + Ha) < 1e-9
+    # checksum: d/d eps [lam . c(x + eps d)] = lam^T G d
+    import scipy.sparse as sp
+    r, cc = eng.evaluate_G_structure()
+    d = rng.normal(size=eng.num_x)
+    Gm = sp.csr_matrix((G, (r, cc)), shape=(eng.num_c, eng.num_x))
+    eps = 1e-7
+    fd = (lam @ eng.evaluate_c(x + eps * d) - lam @ eng.evaluate_c(x - eps * d)) / (2 * eps)
+    an = lam @ (Gm @ d)
+    assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)) + 1e3 * np.finfo(float).eps * np.abs(lam @ c) / eps
+    eng.close()

@@ -1,0 +1,80 @@
+"""Model compiler + code generator (host logic, no GPU)."""
+import numpy as np
+import pytest
+import sympy as sym
+
+from pycollo_amd import codegen, problems
+from pycollo_amd.model import compile_model
+from pycollo_amd.problem import ProblemSpec
+
+
+def test_counts_match_reference_fixtures():
+    m = compile_model(problems.brachistochrone())
+    p = m.phases[0]
+    assert (p.n_y, p.n_u, p.n_q, p.n_p, p.n_t, m.n_s) == (3, 1, 0, 0, 1, 0)     # t0 eliminated (bounds.py:456-480)
+    assert p.t_free == (False, True) and p.t_fixed[0] == 0.0
+    m = compile_model(problems.double_pendulum())
+    p = m.phases[0]
+    assert (p.n_y, p.n_u, p.n_q, p.n_t, m.n_s) == (4, 2, 1, 1, 2)
+    m = compile_model(problems.hypersensitive())
+    assert m.phases[0].n_t == 0                                                # both times fixed
+
+
+def test_phase_aux_overrides_problem_aux():
+    # conftest.py:118-124,127: phase-level g = -9.81 wins over problem-level g = 0
+    m = compile_model(problems.double_pendulum())
+    vals = [v for _, v in m.phases[0].consts]
+    assert -9.81 in vals and 0.0 not in vals
+
+
+def test_numeric_constants_are_not_folded():
+    """exp(-(r - R_E)/h_0) must not become exp(R_E/h_0) * exp(-r/h_0) (= inf * 0 in fp64)."""
+    m = compile_model(problems.delta_iii())
+    src = codegen.generate_source(m)
+    assert "inf" not in src and "nan" not in src
+    assert "constexpr double K0" in src
+
+
+def test_structural_masks_hypersensitive():
+    p = compile_model(problems.hypersensitive()).phases[0]
+    assert [(r, c) for r, c, _ in p.jac] == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    assert [(r, c) for r, c, _ in p.hess] == [(0, 0), (1, 1)]
+
+
+def test_errors():
+    y, u, k = sym.symbols("y u k")
+    prob = ProblemSpec("bad")
+    ph = prob.new_phase("A")
+    ph.state_variables = [y]
+    ph.control_variables = [u]
+    ph.state_equations = [k * y + u]          # k is undefined
+    ph.bounds.initial_time = 0
+    ph.bounds.final_time = 1
+    ph.bounds.state_variables = [[0, 1]]
+    ph.bounds.control_variables = [[0, 1]]
+    prob.objective_function = ph.final_state_variables[0]
+    with pytest.raises(ValueError, match="neither variables nor auxiliary data"):
+        compile_model(prob)
+    prob.auxiliary_data = {k: k + 1}
+    with pytest.raises(ValueError, match="cyclic"):
+        compile_model(prob)
+    prob.auxiliary_data = {k: 2.0}
+    prob.endpoint_constraints = [ph.final_state_variables[0]]
+    prob.bounds.endpoint_constraints = [[0, 1]]
+    with pytest.raises(ValueError, match="bare point variable"):       # backend.py:764-770
+        compile_model(prob)
+
+
+def test_digest_tracks_model():
+    a = compile_model(problems.hypersensitive()).digest
+    b = compile_model(problems.hypersensitive(K=99, order=7)).digest     # mesh does not enter the kernels
+    c = compile_model(problems.hypersensitive(test_fixture_bounds=True)).digest
+    assert a == b == c                                                    # bounds only affect scaling data
+    assert a != compile_model(problems.cart_pole()).digest
+
+
+def test_generated_source_is_straight_line_fp64():
+    src = codegen.generate_source(compile_model(problems.shuttle()))
+    assert "pow(" not in src            # integer powers expanded to multiplications
+    assert "float " not in src
+    assert src.count("__global__") == 2
