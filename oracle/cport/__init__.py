@@ -1,0 +1,281 @@
+"""C port of the oracle (TEST INFRASTRUCTURE / CPU BASELINE ONLY).
+
+``CPort`` generates one C translation unit per problem from the oracle's own lowered SymPy expressions
+(``OracleNlp.P[i].F / dF / d2F`` and the endpoint expressions), ``#include``s ``colloc_cpu.c`` (the
+hand-written restatement of the reference formulas), compiles it with ``gcc -O3 -march=native -fopenmp``
+into ``oracle/_build/`` and drives it through ctypes.  It is what ``bench.py`` times as
+``cpu_baseline`` (kind "port"); tests check it against ``ref_numpy``.  The product never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import time
+
+import numpy as np
+import sympy as sym
+from sympy.printing.c import C99CodePrinter
+
+from ..ref_numpy import OracleNlp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(os.path.dirname(HERE), "_build")
+
+
+class _P(C99CodePrinter):
+    def _print_Pow(self, expr):
+        b, e = expr.base, expr.exp
+        if e.is_Integer and 0 < abs(int(e)) <= 4:
+            s = "*".join([f"({self._print(b)})"] * abs(int(e)))
+            return f"({s})" if e > 0 else f"(1.0/({s}))"
+        if e == sym.Rational(1, 2):
+            return f"sqrt({self._print(b)})"
+        if e == sym.Rational(-1, 2):
+            return f"(1.0/sqrt({self._print(b)}))"
+        return f"pow({self._print(b)}, {self._print(e)})"
+
+
+_pr = _P()
+
+
+def _block(inputs, consts, outs, tag):
+    lines = [f"  const double {sym.Symbol(f'C{tag}_{i}')} = {float(v)!r};" for i, (k, v) in enumerate(consts.items())]
+    sub = dict(inputs)
+    sub.update({k: sym.Symbol(f"C{tag}_{i}") for i, k in enumerate(consts)})
+    exprs = [sym.sympify(e) for _, e in outs]
+    if exprs:
+        repl, red = sym.cse(exprs, symbols=sym.numbered_symbols(f"t{tag}_"), order="none")
+        for s_, e in repl:
+            lines.append(f"  const double {s_} = {_pr.doprint(e.xreplace(sub))};")
+        for (lhs, _), e in zip(outs, red):
+            lines.append(f"  {lhs} = {_pr.doprint(e.xreplace(sub))};")
+    return lines
+
+
+def _ia(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+
+
+def _la(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int64).reshape(-1))
+
+
+class _Phase(C.Structure):
+    _fields_ = [("n_y", C.c_int), ("n_u", C.c_int), ("n_q", C.c_int), ("n_p", C.c_int), ("n_t", C.c_int),
+                ("t_free", C.c_int * 2), ("t_fixed", C.c_double * 2), ("K", C.c_int), ("N", C.c_int),
+                ("n_k", C.c_void_p), ("s_k", C.c_void_p), ("h_k", C.c_void_p), ("w", C.c_void_p),
+                ("x_off", C.c_long), ("q_off", C.c_long), ("t_off", C.c_long), ("c_off", C.c_long),
+                ("c_path", C.c_long), ("c_int", C.c_long), ("ox", C.c_int), ("oc", C.c_int),
+                ("nj", C.c_int), ("jr", C.c_void_p), ("jc", C.c_void_p),
+                ("nh2", C.c_int), ("h2r", C.c_void_p), ("h2c1", C.c_void_p), ("h2c2", C.c_void_p),
+                ("eval", C.c_void_p)]
+
+
+class _Problem(C.Structure):
+    _fields_ = [("n_phases", C.c_int), ("ph", C.POINTER(_Phase)), ("n_s", C.c_int), ("s_off", C.c_long),
+                ("ocp_s", C.c_int), ("num_x", C.c_long), ("num_c", C.c_long), ("c_end", C.c_long),
+                ("ocp_c_end", C.c_int), ("V", C.c_void_p), ("r", C.c_void_p), ("W", C.c_void_p), ("wJ", C.c_double),
+                ("A", C.c_void_p * 21),
+                ("n_pt", C.c_int), ("pt_x", C.c_void_p), ("pt_ocp", C.c_void_p),
+                ("n_b", C.c_int), ("n_gJ", C.c_int), ("n_jb", C.c_int), ("n_hJ", C.c_int), ("n_hb", C.c_int),
+                ("gJ_c", C.c_void_p), ("jb_r", C.c_void_p), ("jb_c", C.c_void_p), ("hJ_c1", C.c_void_p),
+                ("hJ_c2", C.c_void_p), ("hb_r", C.c_void_p), ("hb_c1", C.c_void_p), ("hb_c2", C.c_void_p),
+                ("point", C.c_void_p)]
+
+
+class CPort:
+    def __init__(self, prob, tables, V_ocp=None, r_ocp=None, W_ocp=None, w_J=1.0, threads: int | None = None):
+        self.ora = o = OracleNlp(prob, tables, V_ocp=V_ocp, r_ocp=r_ocp, W_ocp=W_ocp, w_J=w_J)
+        self._keep = []
+        src = ['#include "colloc_cpu.c"', ""]
+        phase_meta = []
+        for ip, P in enumerate(o.P):
+            vin = {s: sym.Symbol(f"v[{i}]") for i, s in enumerate(P.v)}
+            jac = sorted(P.dF)                                   # (r, c)
+            h2 = sorted(k for k in P.d2F if k[2] <= k[1])        # (r, c1, c2), c2 <= c1
+            outs = [(f"F[{i}]", e) for i, e in enumerate(P.F)]
+            outs += [(f"J[{i}]", P.dF[k][0]) for i, k in enumerate(jac)]
+            outs += [(f"H2[{i}]", P.d2F[k][0]) for i, k in enumerate(h2)]
+            src.append(f"static void node_p{ip}(const double* v, double* F, double* J, double* H2) {{")
+            src.append("  (void)v; (void)F; (void)J; (void)H2;")
+            src += _block(vin, P.consts, outs, f"p{ip}")
+            src.append("}")
+            phase_meta.append((jac, h2))
+        ps = o.point_syms
+        xin = {s: sym.Symbol(f"xb[{i}]") for i, s in enumerate(ps)}
+        gJ = sorted(o.dJ)
+        jb = sorted(o.db)
+        hJ = sorted(k for k in o.d2J if k[1] <= k[0])
+        hb = sorted(k for k in o.d2b if k[2] <= k[1])
+        outs = [("*J", o.J_expr)]
+        outs += [(f"gJ[{i}]", sym.diff(o.J_expr, ps[c])) for i, c in enumerate(gJ)]
+        outs += [(f"b[{i}]", e) for i, e in enumerate(o.b_expr)]
+        outs += [(f"jb[{i}]", sym.diff(o.b_expr[r], ps[c])) for i, (r, c) in enumerate(jb)]
+        outs += [(f"hJ[{i}]", sym.diff(o.J_expr, ps[c1], ps[c2])) for i, (c1, c2) in enumerate(hJ)]
+        outs += [(f"hb[{i}]", sym.diff(o.b_expr[r], ps[c1], ps[c2])) for i, (r, c1, c2) in enumerate(hb)]
+        src.append("static void point_fn_(const double* xb, double* J, double* gJ, double* b, double* jb, double* hJ, double* hb) {")
+        src.append("  (void)xb; (void)J; (void)gJ; (void)b; (void)jb; (void)hJ; (void)hb;")
+        src += _block(xin, o.point_consts, outs, "pt")
+        src.append("}")
+        for ip in range(len(o.P)):
+            src.append(f"void* get_node_p{ip}(void) {{ return (void*)node_p{ip}; }}")
+        src.append("void* get_point(void) { return (void*)point_fn_; }")
+        text = "\n".join(src) + "\n"
+        with open(os.path.join(HERE, "colloc_cpu.c"), "rb") as f:
+            digest = hashlib.sha256(text.encode() + f.read()).hexdigest()[:16]
+        os.makedirs(BUILD, exist_ok=True)
+        so = os.path.join(BUILD, f"cport_{digest}.so")
+        if not os.path.exists(so):
+            cfile = so[:-3] + ".c"
+            with open(cfile, "w") as f:
+                f.write(text)
+            cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", f"-I{HERE}", "-o", so + ".tmp", cfile, "-lm"]
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError("gcc failed:\n" + res.stderr[-3000:])
+            os.replace(so + ".tmp", so)
+        self.lib = lib = C.CDLL(so)
+        if threads is not None:
+            os.environ["OMP_NUM_THREADS"] = str(threads)
+        lib.cp_threads.restype = C.c_int
+        vp = C.c_void_p
+        lib.cp_counts.argtypes = [vp, vp, vp]
+        lib.cp_eval.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.cp_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, C.c_long, vp, C.c_long, vp, vp, C.c_long, vp, vp, C.c_long]
+        # ---- fill structs
+        keep = self._keep
+        phs = (_Phase * len(o.P))()
+        for ip, (P, (jac, h2)) in enumerate(zip(o.P, phase_meta)):
+            d = phs[ip]
+            m = P.mesh
+            n_k, s_k = _ia(m.nodes), _ia(m.bnd)
+            h_k = np.ascontiguousarray(m.h, float)
+            w = np.ascontiguousarray(m.w, float)
+            jr, jc = _ia([k[0] for k in jac]), _ia([k[1] for k in jac])
+            h2r, h2c1, h2c2 = _ia([k[0] for k in h2]), _ia([k[1] for k in h2]), _ia([k[2] for k in h2])
+            keep += [n_k, s_k, h_k, w, jr, jc, h2r, h2c1, h2c2]
+            d.n_y, d.n_u, d.n_q, d.n_p, d.n_t = P.n_y, P.n_u, P.n_q, P.n_p, P.n_t
+            d.t_free[0], d.t_free[1] = int(P.t_free[0]), int(P.t_free[1])
+            d.t_fixed[0], d.t_fixed[1] = P.t_fixed
+            d.K, d.N = m.K, m.N
+            d.n_k, d.s_k, d.h_k, d.w = n_k.ctypes.data, s_k.ctypes.data, h_k.ctypes.data, w.ctypes.data
+            d.x_off, d.q_off, d.t_off, d.c_off, d.c_path, d.c_int = P.x_off, P.q_off, P.t_off, P.c_off, P.c_path, P.c_int
+            d.ox, d.oc = P.ox, P.oc
+            d.nj, d.jr, d.jc = len(jac), jr.ctypes.data, jc.ctypes.data
+            d.nh2, d.h2r, d.h2c1, d.h2c2 = len(h2), h2r.ctypes.data, h2c1.ctypes.data, h2c2.ctypes.data
+            fn = getattr(lib, f"get_node_p{ip}")
+            fn.restype = C.c_void_p
+            d.eval = fn()
+        Q = _Problem()
+        Q.n_phases, Q.ph = len(o.P), phs
+        Q.n_s, Q.s_off, Q.ocp_s = o.n_s, o.s_off, o.ocp_s
+        Q.num_x, Q.num_c, Q.c_end, Q.ocp_c_end = o.num_x, o.num_c, o.c_end, o.ocp_c_end
+        self._V = np.ascontiguousarray(o.V_ocp, float)
+        self._r = np.ascontiguousarray(o.r_ocp, float)
+        self._W = np.ascontiguousarray(o.W_ocp, float)
+        Q.V, Q.r, Q.W, Q.wJ = self._V.ctypes.data, self._r.ctypes.data, self._W.ctypes.data, float(o.w_J)
+        orders = sorted({int(n) for P in o.P for n in np.unique(P.mesh.nodes)})
+        for n in orders:
+            A = np.ascontiguousarray(tables.A(n), float)
+            keep.append(A)
+            Q.A[n] = A.ctypes.data
+        ptx, pto = _la(o.point_x), _ia(o.point_ocp)
+        arrs = dict(gJ_c=_ia(gJ), jb_r=_ia([k[0] for k in jb]), jb_c=_ia([k[1] for k in jb]),
+                    hJ_c1=_ia([k[0] for k in hJ]), hJ_c2=_ia([k[1] for k in hJ]),
+                    hb_r=_ia([k[0] for k in hb]), hb_c1=_ia([k[1] for k in hb]), hb_c2=_ia([k[2] for k in hb]))
+        keep += [phs, ptx, pto] + list(arrs.values())
+        Q.n_pt, Q.pt_x, Q.pt_ocp = len(ps), ptx.ctypes.data, pto.ctypes.data
+        Q.n_b, Q.n_gJ, Q.n_jb, Q.n_hJ, Q.n_hb = o.n_b, len(gJ), len(jb), len(hJ), len(hb)
+        for k, a in arrs.items():
+            setattr(Q, k, a.ctypes.data)
+        gp = lib.get_point
+        gp.restype = C.c_void_p
+        Q.point = gp()
+        self.Q = Q
+        nG, nH = C.c_long(), C.c_long()
+        lib.cp_counts(C.byref(Q), C.byref(nG), C.byref(nH))
+        self.nG, self.nH = nG.value, nH.value
+        self.num_x, self.num_c = o.num_x, o.num_c
+        # ---- structure mode: query the emission order once, map it onto the oracle's CSR patterns
+        gr, gc = o.G_structure()
+        hr, hc = o.H_structure()
+        self.nnzG, self.nnzH = len(gr), len(hr)
+        self.gv, self.hv = np.zeros(self.nG), np.zeros(self.nH)
+        gi, gj = np.zeros(self.nG, np.int64), np.zeros(self.nG, np.int64)
+        hi, hj = np.zeros(self.nH, np.int64), np.zeros(self.nH, np.int64)
+        x0 = np.full(o.num_x, 0.1)
+        lam0 = np.ones(o.num_c)
+        c0 = np.zeros(o.num_c)
+        lib.cp_eval(C.byref(Q), x0.ctypes.data, 1.0, lam0.ctypes.data, c0.ctypes.data,
+                    self.gv.ctypes.data, gi.ctypes.data, gj.ctypes.data, self.hv.ctypes.data, hi.ctypes.data, hj.ctypes.data)
+
+        def slots(pr, pc, ti, tj, ncols):
+            key = pr.astype(np.int64) * ncols + pc.astype(np.int64)
+            tk = ti * ncols + tj
+            pos = np.searchsorted(key, tk)
+            if np.any(pos >= len(key)) or np.any(key[np.minimum(pos, len(key) - 1)] != tk):
+                raise AssertionError("C port emitted a triplet outside the oracle's pattern")
+            return np.ascontiguousarray(pos, dtype=np.int64)
+        self.gslot = slots(gr, gc, gi, gj, o.num_x)
+        self.hslot = slots(hr, hc, hi, hj, o.num_x)
+        self.c = np.zeros(o.num_c)
+        self.G = np.zeros(self.nnzG)
+        self.H = np.zeros(self.nnzH)
+
+    @property
+    def threads(self):
+        return int(self.lib.cp_threads())
+
+    def eval_all(self, x, sigma, lam):
+        x = np.ascontiguousarray(x, float)
+        lam = np.ascontiguousarray(lam, float)
+        self.lib.cp_eval_all(C.byref(self.Q), x.ctypes.data, float(sigma), lam.ctypes.data,
+                             self.c.ctypes.data, self.G.ctypes.data, self.nnzG, self.H.ctypes.data,
+                             self.nnzH, self.gv.ctypes.data, self.gslot.ctypes.data, self.nG,
+                             self.hv.ctypes.data, self.hslot.ctypes.data, self.nH)
+        return self.c, self.G, self.H
+
+
+def build_all():
+    """Pre-compile the C port for the benchmark problem (called by __graft_entry__.build)."""
+    from pycollo_amd import problems
+    from pycollo_amd.quadrature import QuadratureTables
+    cp = CPort(problems.hypersensitive(K=4, order=6), QuadratureTables("lobatto"))
+    return cp.lib._name
+
+
+def time_hypersensitive(K: int, order: int, budget_s: float = 15.0) -> dict:
+    """Time cp_eval_all on the bench workload: single thread and all host cores (same process)."""
+    from pycollo_amd import problems
+    from pycollo_amd.quadrature import QuadratureTables
+    out = {}
+    ncpu = os.cpu_count() or 1
+    for label, thr in (("1", 1), ("all", ncpu)):
+        os.environ["OMP_NUM_THREADS"] = str(thr)
+        cp = CPort(problems.hypersensitive(K=K, order=order), QuadratureTables("lobatto"))
+        try:
+            cp.lib.omp_set_num_threads(thr)
+        except AttributeError:
+            pass
+        x = np.random.default_rng(1234).uniform(-0.45, 0.45, cp.num_x)
+        lam = np.random.default_rng(1235).normal(size=cp.num_c)
+        for _ in range(5):
+            cp.eval_all(x, 1.0, lam)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(20):
+                cp.eval_all(x, 1.0, lam)
+            n += 20
+            dt = time.perf_counter() - t0
+            if dt > budget_s / 2 or n >= 20000:
+                break
+        out[label] = (n / dt, n, dt, thr)
+    best = max(out.values(), key=lambda t: t[0])
+    one = out["1"]
+    return {"value": round(one[0], 2), "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{one[1]} fused c+G+H evaluations of the same {K}x{order} hypersensitive NLP in {one[2]:.1f} s, "
+                      f"oracle C port (gcc -O3 -march=native), 1 thread",
+            "all_cores": {"value": round(out['all'][0], 2), "cores": out["all"][3], "evals": out["all"][1]},
+            "host_cpus": ncpu, "best_value": round(best[0], 2)}
