@@ -129,6 +129,19 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
  * so that bench.py can time the dominant kernel between two HIP events */
 int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,
                           double* d_hess, void* stream);
+/* ---- multi-GPU sharding by contiguous mesh-section ranges ---------------------
+ * A phase is cut into tiles of whole sections; a rank launches the bulk kernels over its tile range only
+ * (pc_set_tile_range + pc_launch_bulk_device), the ranks exchange their output segments and per-tile
+ * partial sums (one all-gather), and every rank finishes with pc_launch_tail_device over the complete
+ * partials.  The reference has no counterpart (single process). */
+int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end);
+/* n_tiles, number of partial sums per tile, and (optional) first section of every tile [n_tiles+1] */
+int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nred, int32_t* tile_k0);
+/* redirect the per-tile partial sums of one phase, double [n_tiles][nred], into caller-owned device
+ * memory so that they can travel in the same all-gather as the output segments (NULL = internal) */
+int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials);
+int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
+                          double* d_jac, double* d_hess, void* stream);
 int pc_synchronize(pc_handle* h);
 
 /* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling

@@ -38,6 +38,7 @@ struct PcPhaseArgs {
   double t_fixed[2];
   int32_t N, K, n_tiles, flags;
   int32_t qa_total, qw_total;
+  int32_t tile_begin, pad0;   // first tile of this launch (section-range sharding across GPUs)
   int32_t qa_off[PC_MAX_ORDER + 1];
   int32_t qw_off[PC_MAX_ORDER + 1];
 };

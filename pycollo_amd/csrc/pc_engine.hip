@@ -89,6 +89,8 @@ struct PhaseDev {
   DevBuf<int64_t> sec_E, goff, hoff, hslot0, hslotN, hsum_slot;
   hipFunction_t fn = nullptr;
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
+  int tile_begin = 0, tile_end = 0;  // launched tile range (whole phase unless sharded)
+  double* partials_ext = nullptr;    // caller-owned partial-sum buffer (sharded exchange), else `partials`
   std::vector<double> scal_host;
 };
 
@@ -156,7 +158,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     a.hoff = D.hoff.p;
     a.hslot0 = D.hslot0.p;
     a.hslotN = D.hslotN.p;
-    a.partials = D.partials.p;
+    a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
     a.x_off = P.x_off;
     a.s_off = Q.s_off;
     a.c_off = P.c_off;
@@ -168,13 +170,15 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     a.K = P.K;
     a.n_tiles = D.n_tiles;
     a.flags = flags;
+    a.tile_begin = D.tile_begin;
     a.qa_total = (int32_t)h->qa.size();
     a.qw_total = (int32_t)h->qw.size();
     std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
     std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
     size_t sz = sizeof(a);
     void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    HIP_OK(hipModuleLaunchKernel(D.fn, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
+    if (D.tile_end > D.tile_begin)
+      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
   }
   if (!tail) return;
   PcTailArgs t;
@@ -201,7 +205,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
     PcTailPhase& tp = t.ph[ip];
-    tp.partials = D.partials.p;
+    tp.partials = D.partials_ext ? D.partials_ext : D.partials.p;
     tp.scal = D.scal.p;
     tp.x_off = P.x_off;
     tp.s_off = Q.s_off;
@@ -372,6 +376,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       auto& P = Q.ph[ip];
       auto& D = *h->pd[ip];
       D.n_tiles = (int)P.tile_k0.size() - 1;
+      D.tile_begin = 0;
+      D.tile_end = D.n_tiles;
       int nfs = 0;
       for (int a = 0; a < P.n_y; ++a)
         for (int l = 0; l < Q.n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
@@ -519,6 +525,47 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, true,
                false);
+  });
+}
+
+int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
+                          double* d_jac, double* d_hess, void* stream) {
+  return guarded([&] {
+    require_device(h);
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    h->h_params.p[0] = obj_factor;
+    h->h_params.p[1] = h->w_J;
+    HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, st));
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, false,
+               true);
+  });
+}
+
+int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end) {
+  return guarded([&] {
+    if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
+    auto& D = *h->pd[phase];
+    if (tile_begin < 0 || tile_end < tile_begin || tile_end > D.n_tiles) throw std::runtime_error("tile range out of range");
+    D.tile_begin = tile_begin;
+    D.tile_end = tile_end;
+    h->have_cG = false;
+  });
+}
+
+int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nred, int32_t* tile_k0) {
+  return guarded([&] {
+    if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
+    const auto& P = h->Q.ph[phase];
+    if (n_tiles) *n_tiles = (int32_t)P.tile_k0.size() - 1;
+    if (nred) *nred = P.nred;
+    if (tile_k0) std::memcpy(tile_k0, P.tile_k0.data(), P.tile_k0.size() * sizeof(int32_t));
+  });
+}
+
+int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials) {
+  return guarded([&] {
+    if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
+    h->pd[phase]->partials_ext = d_partials;
   });
 }
 

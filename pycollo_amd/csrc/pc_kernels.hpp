@@ -196,7 +196,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
   const int N = A.N;
-  const int k0 = A.tile_k0[blockIdx.x], k1 = A.tile_k0[blockIdx.x + 1];
+  const int tile = blockIdx.x + A.tile_begin;
+  const int k0 = A.tile_k0[tile], k1 = A.tile_k0[tile + 1];
   const bool has_prev = k0 > 0;
   const int kp = has_prev ? k0 - 1 : 0;  // first staged section
   const int nsec = k1 - kp;              // staged sections (previous one included)
@@ -504,7 +505,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
     if (tid < NRED) {
       double s = 0.0;
       for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
-      A.partials[(int64_t)blockIdx.x * NRED + tid] = s;
+      A.partials[(int64_t)tile * NRED + tid] = s;
     }
   }
 }

@@ -100,6 +100,10 @@ def load_library() -> C.CDLL:
     lib.pc_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.pc_launch_bulk_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    lib.pc_launch_tail_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.pc_set_tile_range.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.pc_phase_tiles.argtypes = [vp, C.c_int, _i32p, _i32p, vp]
+    lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_stream.argtypes = [vp]
@@ -337,6 +341,27 @@ class NlpEngine:
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
         self._check(self._lib.pc_launch_bulk_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
                                                     stream))
+
+    def launch_tail_only(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None):
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._check(self._lib.pc_launch_tail_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
+                                                    addr(d_G), addr(d_H), stream))
+
+    def set_tile_range(self, phase: int, begin: int, end: int):
+        self._check(self._lib.pc_set_tile_range(self._h, phase, begin, end))
+
+    def phase_tiles(self, phase: int):
+        """(tile_k0 [n_tiles+1], nred): first section of every tile and partial sums per tile."""
+        n, r = C.c_int32(), C.c_int32()
+        self._check(self._lib.pc_phase_tiles(self._h, phase, C.byref(n), C.byref(r), None))
+        k0 = np.empty(n.value + 1, dtype=np.int32)
+        self._check(self._lib.pc_phase_tiles(self._h, phase, C.byref(n), C.byref(r), k0.ctypes.data))
+        return k0, r.value
+
+    def set_partials_buffer(self, phase: int, d_partials):
+        ptr = d_partials.data_ptr() if hasattr(d_partials, "data_ptr") else d_partials
+        self._check(self._lib.pc_set_partials_buffer(self._h, phase, ptr))
 
     def synchronize(self):
         self._check(self._lib.pc_synchronize(self._h))

@@ -1,0 +1,189 @@
+"""Multi-GPU evaluation: shard every phase's mesh by contiguous section ranges, one rank per GPU.
+
+SURVEY.md section 8e.  A defect row of section k reads only that section's nodes, path rows and the
+Hessian node blocks are per node, so a rank that owns the tile range [tb, te) of a phase produces a
+handful of *contiguous CSR runs* of c~, G~ and H~ (one per state / path constraint / variable block /
+strip) plus its tiles' partial sums.  One evaluation is
+
+    bulk kernels over the local tiles  ->  pack the local runs  ->  ONE all-gather (RCCL over xGMI)
+    ->  unpack the other ranks' runs   ->  tail kernel on every rank over the complete partial sums
+
+so every rank ends with the complete, bit-identical c~, G~, H~ (the integral rows, the (q,t,s) Jacobian
+columns, the Hessian sums and the endpoint block are finished redundantly by each rank's tail kernel
+from the gathered per-tile partials -- no separate all-reduce, and the summation order does not depend on
+the number of ranks).  x~ and lambda are replicated (a few MB at most).
+
+``ShardPlan`` is pure NumPy (testable on a CPU); ``SegmentExchange`` moves tensors with torch ops only
+and therefore runs unchanged over gloo on the CPU (tests) and over RCCL on GPUs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _indptr(rows: np.ndarray, n_rows: int) -> np.ndarray:
+    out = np.zeros(n_rows + 1, dtype=np.int64)
+    np.add.at(out, rows.astype(np.int64) + 1, 1)
+    return np.cumsum(out)
+
+
+class ShardPlan:
+    """Which positions of the combined buffer [c | G | H | partials_p0 | partials_p1 | ...] each rank produces."""
+
+    def __init__(self, engine, world: int):
+        self.world = world
+        lay, model = engine.layout, engine.model
+        self.num_c, self.nnz_G, self.nnz_H = engine.num_c, engine.nnz_jac, engine.nnz_hess
+        g_rows, g_cols = engine.evaluate_G_structure()
+        h_rows, h_cols = engine.evaluate_H_structure()
+        gp = _indptr(g_rows, engine.num_c)
+        hp = _indptr(h_rows, engine.num_x)
+        oG, oH = self.num_c, self.num_c + self.nnz_G
+        self.part_off = []
+        off = oH + self.nnz_H
+        self.tiles = []
+        for ip in range(len(model.phases)):
+            k0, nred = engine.phase_tiles(ip)
+            self.tiles.append((k0, nred))
+            self.part_off.append(off)
+            off += (len(k0) - 1) * nred
+        self.total = off
+        self.tile_ranges = [[None] * len(model.phases) for _ in range(world)]
+        self.segments = [[] for _ in range(world)]   # (start, stop) in the combined buffer
+
+        def h_slot(row, col):
+            a, b = hp[row], hp[row + 1]
+            j = a + np.searchsorted(h_cols[a:b], col)
+            assert j < b and h_cols[j] == col
+            return int(j)
+
+        for ip, (pm, pl, mesh) in enumerate(zip(model.phases, lay.phases, engine.meshes)):
+            k0s, nred = self.tiles[ip]
+            n_tiles = len(k0s) - 1
+            N = pl.N
+            jmask = pm.jac_mask()
+            hmask = pm.hess_mask()
+            tz = [any(jmask[r, b] for r in range(pm.n_fn) if not (pm.n_y <= r < pm.n_y + pm.n_p)) for b in range(pm.n_v)]
+            for r in range(world):
+                tb, te = (n_tiles * r) // world, (n_tiles * (r + 1)) // world
+                self.tile_ranges[r][ip] = (tb, te)
+                if te <= tb:
+                    continue
+                seg = self.segments[r]
+                ka, kb = int(k0s[tb]), int(k0s[te])
+                n0, n1 = int(mesh.s[ka]), int(mesh.s[kb])
+                n1o = n1 + (1 if kb == mesh.K else 0)          # owned nodes [n0, n1o)
+                for a in range(pm.n_y):                         # defect rows n0 .. n1-1 of every state
+                    r0 = pl.c_off + a * (N - 1)
+                    seg.append((r0 + n0, r0 + n1))
+                    seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1]))
+                for m in range(pm.n_p):                         # path rows of the owned nodes
+                    r0 = pl.c_path_off + m * N
+                    seg.append((r0 + n0, r0 + n1o))
+                    seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1o]))
+                for m in range(pm.n_q):                         # z entries of the integral rows
+                    row = pl.c_int_off + m
+                    rank_b = 0
+                    for b in range(pm.n_z):
+                        if jmask[pm.n_y + pm.n_p + m, b]:
+                            base = oG + gp[row] + rank_b * N
+                            seg.append((base + n0, base + n1o))
+                            rank_b += 1
+                for b in range(pm.n_z):                         # Hessian rows of the owned nodes
+                    if hmask[b, :pm.n_z].any():
+                        r0 = pl.x_off + b * N
+                        seg.append((oH + hp[r0 + n0], oH + hp[r0 + n1o]))
+                for jt in range(pm.n_t):                        # t strips
+                    for b in range(pm.n_z):
+                        if tz[b]:
+                            base = oH + h_slot(pl.t_off + jt, pl.x_off + b * N)
+                            seg.append((base + n0, base + n1o))
+                for l in range(model.n_s):                      # s strips
+                    for b in range(pm.n_z):
+                        if hmask[pm.n_z + l, b]:
+                            base = oH + h_slot(lay.s_off + l, pl.x_off + b * N)
+                            seg.append((base + n0, base + n1o))
+                if nred:
+                    seg.append((self.part_off[ip] + tb * nred, self.part_off[ip] + te * nred))
+        self.segments = [[(int(a), int(b)) for a, b in s if b > a] for s in self.segments]
+        self.index = [np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in s]) if s else np.zeros(0, np.int64)
+                      for s in self.segments]
+        self.lengths = [len(i) for i in self.index]
+        self.maxlen = max(self.lengths) if self.lengths else 0
+
+
+class SegmentExchange:
+    """pack -> all_gather_into_tensor -> unpack on one combined buffer; torch ops only."""
+
+    def __init__(self, plan: ShardPlan, rank: int, device, group=None):
+        import torch
+        self.torch = torch
+        self.plan, self.rank, self.group = plan, rank, group
+        self.world = plan.world
+        self.idx_me = torch.from_numpy(plan.index[rank]).to(device)
+        self.send = torch.zeros(max(plan.maxlen, 1), dtype=torch.float64, device=device)
+        self.recv = torch.zeros(self.world * max(plan.maxlen, 1), dtype=torch.float64, device=device)
+        src, dst = [], []
+        for r in range(self.world):
+            if r == rank:
+                continue
+            src.append(np.arange(plan.lengths[r], dtype=np.int64) + r * max(plan.maxlen, 1))
+            dst.append(plan.index[r])
+        self.unpack_src = torch.from_numpy(np.concatenate(src) if src else np.zeros(0, np.int64)).to(device)
+        self.unpack_dst = torch.from_numpy(np.concatenate(dst) if dst else np.zeros(0, np.int64)).to(device)
+
+    def run(self, buf):
+        import torch.distributed as dist
+        torch = self.torch
+        n = self.idx_me.numel()
+        if n:
+            torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if self.unpack_dst.numel():
+            buf.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+        return buf
+
+
+class ShardedNlp:
+    """One rank of a section-sharded NLP evaluation (GPU).  Every rank holds the complete outputs."""
+
+    def __init__(self, problem, device: int = 0, threads_per_block: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        from .engine import NlpEngine
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.engine = eng = NlpEngine(problem, device=device, threads_per_block=threads_per_block)
+        self.plan = plan = ShardPlan(eng, self.world)
+        dev = torch.device("cuda", device)
+        self.buf = torch.zeros(plan.total, dtype=torch.float64, device=dev)
+        oG, oH = plan.num_c, plan.num_c + plan.nnz_G
+        self.c = self.buf[:oG]
+        self.G = self.buf[oG:oH]
+        self.H = self.buf[oH:oH + plan.nnz_H]
+        for ip, ((k0, nred), off) in enumerate(zip(plan.tiles, plan.part_off)):
+            if nred:
+                eng.set_partials_buffer(ip, self.buf[off:off + (len(k0) - 1) * nred])
+            tb, te = plan.tile_ranges[self.rank][ip]
+            eng.set_tile_range(ip, tb, te)
+        self.exchange = SegmentExchange(plan, self.rank, dev, group)
+        # kernels, torch pack/unpack ops and the collective must share ONE non-default stream (the C ABI maps a
+        # NULL stream to the handle's private stream)
+        self.tstream = torch.cuda.Stream(device=dev)
+        self.num_x, self.num_c, self.nnz_jac, self.nnz_hess = eng.num_x, eng.num_c, eng.nnz_jac, eng.nnz_hess
+        # algorithmic bytes this rank's kernels move per evaluation: its share of the outputs + the inputs it reads
+        self.local_algorithmic_bytes = 8 * (plan.lengths[self.rank] + (eng.num_x + eng.num_c) // self.world)
+
+    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None):
+        """Asynchronous on the torch stream that is current when called (must not be the default stream);
+        falls back to this object's own stream."""
+        import torch
+        cur = torch.cuda.current_stream()
+        ts = cur if cur.cuda_stream != 0 else self.tstream
+        eng = self.engine
+        with torch.cuda.stream(ts):
+            eng.launch_bulk_only(d_x, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+            if self.world > 1:
+                self.exchange.run(self.buf)
+            eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+        return self.c, self.G, self.H

@@ -240,3 +240,75 @@ def test_full_size_properties(built, tab, name, kw):
     an = lam @ (Gm @ d)
     assert abs(fd - an) <= 1e-5 * max(1.0, abs(an)) + 1e3 * np.finfo(float).eps * np.abs(lam @ c) / eps
     eng.close()
+
+
+@pytest.mark.parametrize("name,kw,world", [("two_phase_transfer", dict(K=40, order=4), 3),
+                                           ("hypersensitive", dict(K=2000, order=6), 8),
+                                           ("delta_iii", dict(K=40, order=4), 2)])
+def test_sharded_ranks_reassemble_bitwise(built, name, kw, world):
+    """Emulate `world` ranks on one GPU: each rank's bulk kernels run over its tile range into a NaN-filled
+    buffer, the plan's segments are merged (what the all-gather + unpack do), the tail runs on the merged
+    buffer -- the result must equal the unsharded evaluation bit for bit."""
+    import torch
+    from pycollo_amd.sharding import ShardPlan
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob)
+    rng = np.random.default_rng(4)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+    x = rng.uniform(lo, hi, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    c, G, H = (a.copy() for a in eng.evaluate_all(x, 0.9, lam))
+    plan = ShardPlan(eng, world)
+    dev = torch.device("cuda", 0)
+    dx, dl = torch.from_numpy(x).to(dev), torch.from_numpy(lam).to(dev)
+    oG, oH = plan.num_c, plan.num_c + plan.nnz_G
+    s = torch.cuda.Stream(device=dev)
+    merged = torch.full((plan.total,), float("nan"), dtype=torch.float64, device=dev)
+    with torch.cuda.stream(s):
+        for r in range(world):
+            buf = torch.full((plan.total,), float("nan"), dtype=torch.float64, device=dev)
+            for ip, ((k0, nred), off) in enumerate(zip(plan.tiles, plan.part_off)):
+                if nred:
+                    eng.set_partials_buffer(ip, buf[off:off + (len(k0) - 1) * nred])
+                eng.set_tile_range(ip, *plan.tile_ranges[r][ip])
+            eng.launch_bulk_only(dx, dl, buf[:oG], buf[oG:oH], buf[oH:oH + plan.nnz_H], s.cuda_stream)
+            idx = torch.from_numpy(plan.index[r]).to(dev)
+            merged[idx] = buf[idx]
+            s.synchronize()
+        for ip, ((k0, nred), off) in enumerate(zip(plan.tiles, plan.part_off)):
+            if nred:
+                eng.set_partials_buffer(ip, merged[off:off + (len(k0) - 1) * nred])
+            eng.set_tile_range(ip, 0, len(k0) - 1)
+        eng.launch_tail_only(dx, 0.9, dl, merged[:oG], merged[oG:oH], merged[oH:oH + plan.nnz_H], s.cuda_stream)
+        s.synchronize()
+    out = merged.cpu().numpy()
+    assert np.array_equal(out[:oG], c)
+    assert np.array_equal(out[oG:oH], G)
+    assert np.array_equal(out[oH:oH + plan.nnz_H], H)
+    for ip in range(len(plan.tiles)):
+        eng.set_partials_buffer(ip, 0)
+    eng.close()
+
+
+def test_sharded_world1_nccl(built):
+    """ShardedNlp end to end with a 1-rank RCCL group (the only group size one GPU allows)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from pycollo_amd.sharding import ShardedNlp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        prob = problems.cart_pole(K=400, order=4)
+        sh = ShardedNlp(prob, device=0)
+        eng = _engine(prob)
+        rng = np.random.default_rng(8)
+        x, lam = rng.uniform(-0.4, 0.4, eng.num_x), rng.normal(size=eng.num_c)
+        c, G, H = eng.evaluate_all(x, 1.0, lam)
+        dc, dG, dH = sh.evaluate_all_device(torch.from_numpy(x).to(dev), 1.0, torch.from_numpy(lam).to(dev))
+        torch.cuda.synchronize()
+        assert np.array_equal(dc.cpu().numpy(), c) and np.array_equal(dG.cpu().numpy(), G) and np.array_equal(dH.cpu().numpy(), H)
+    finally:
+        dist.destroy_process_group()
