@@ -46,6 +46,8 @@ typedef struct {
   const int32_t* hess_row;
   const int32_t* hess_col;
   const char* bulk_kernel;         /* kernel symbol inside the code object */
+  int32_t compiled_order;          /* 0: the kernel handles any mesh; n > 0: it was compiled for sections of
+                                      exactly n nodes (every n_k must equal n) */
 } pc_phase_desc;
 
 typedef struct {
@@ -142,6 +144,8 @@ int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nre
 int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials);
 int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
                           double* d_jac, double* d_hess, void* stream);
+/* diagnostic builds only (PYCOLLO_AMD_DBG_STAGE=9): per-tile s_memtime stamps of the last bulk launch */
+int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles);
 int pc_synchronize(pc_handle* h);
 
 /* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling

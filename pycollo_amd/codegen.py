@@ -163,7 +163,8 @@ def _point_struct(pt: PointModel) -> str:
     return "\n".join(lines)
 
 
-def generate_source(model: Model) -> str:
+def generate_source(model: Model, orders=None) -> str:
+    orders = tuple(orders) if orders is not None else tuple(0 for _ in model.phases)
     parts = [f"// generated by pycollo_amd.codegen for model '{model.name}' digest {model.digest} -- do not edit",
              '#include "pc_kernels.hpp"',
              "",
@@ -181,7 +182,7 @@ def generate_source(model: Model) -> str:
     parts.append("}  // namespace gen\n")
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{pm.index}(PcPhaseArgs a) '
-                     f'{{ pc::bulk<gen::Phase{pm.index}>(a); }}')
+                     f'{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a); }}')
     parts.append("")
     parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) {')
     parts.append("  pc::tail_begin(a);")
@@ -209,14 +210,24 @@ def hipcc_path() -> str | None:
     return None
 
 
-def code_object_path(model: Model) -> str:
-    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}.hsaco")
+def _orders_tag(model: Model, orders) -> str:
+    orders = tuple(int(o) for o in orders) if orders is not None else tuple(0 for _ in model.phases)
+    if len(orders) != len(model.phases):
+        raise ValueError("one section order (or 0) per phase is required")
+    return "n" + "_".join(str(o) for o in orders)
 
 
-def build_code_object(model: Model, force: bool = False, verbose: bool = False) -> str:
-    """Return the path of the gfx950 code object for ``model``, compiling it if it is not cached."""
+def code_object_path(model: Model, orders=None) -> str:
+    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}.hsaco")
+
+
+def build_code_object(model: Model, orders=None, force: bool = False, verbose: bool = False) -> str:
+    """Return the path of the gfx950 code object for ``model``, compiling it if it is not cached.
+
+    ``orders[p] = n > 0`` specialises phase p's kernel for meshes whose sections all have n nodes;
+    0 keeps it generic (any mesh)."""
     os.makedirs(CACHE, exist_ok=True)
-    out = code_object_path(model)
+    out = code_object_path(model, orders)
     if os.path.exists(out) and not force:
         return out
     hipcc = hipcc_path()
@@ -224,7 +235,7 @@ def build_code_object(model: Model, force: bool = False, verbose: bool = False) 
         raise RuntimeError(f"code object {out} is not built and hipcc is not available to build it")
     src = out[:-6] + ".hip"
     with open(src, "w") as f:
-        f.write(generate_source(model))
+        f.write(generate_source(model, orders))
     # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
     # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
     cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",

@@ -10,7 +10,12 @@
 #define PC_FLAG_G 2
 #define PC_FLAG_H 4
 
-// Per-phase arguments of the bulk kernel.
+#define PC_MAX_GOFF 32
+#define PC_MAX_HOFF 96
+#define PC_MAX_SCAL 96
+
+// Per-phase arguments of the bulk kernel (passed by value in the kernarg segment: everything a wave
+// needs before its first global load -- offsets, geometry -- arrives with the dispatch packet).
 struct PcPhaseArgs {
   // NLP vectors (device)
   const double* x;      // [num_x] scaled variables
@@ -18,29 +23,36 @@ struct PcPhaseArgs {
   double* c;            // [num_c]
   double* G;            // [nnz_G]
   double* H;            // [nnz_H]
-  // mesh (device)
+  // mesh (device); tile_* / sec_s / sec_E are only read when the section orders differ (uni_n == 0)
   const int32_t* tile_k0;  // [n_tiles+1] first section of every tile
+  const int32_t* tile_n0;  // [n_tiles+1] first node of every tile
   const int32_t* sec_s;    // [K+1] first node of every section; sec_s[K] = N-1
   const double* sec_h;     // [K] section widths in tau
   const int64_t* sec_E;    // [K+1] prefix sum of (n_k-1)*n_k
   const double* qa;        // packed A tables of the orders in use
   const double* qw;        // packed weight tables
-  // packed scaling doubles: Vz[NZ] rz[NZ] Vq[NQ] rq[NQ] Vt[2] rt[2] Vs[NS] rs[NS] Wd[NY] Wp[NP] Wi[NQ]
-  const double* scal;
-  // CSR value offsets (device)
-  const int64_t* goff;    // [NY] defect block bases | [NP] path bases | [NQ] integral bases
-  const int64_t* hoff;    // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
   const int64_t* hslot0;  // [NHZZ] slots of the node block at node 0
   const int64_t* hslotN;  // [NHZZ] slots of the node block at node N-1
   double* partials;       // [n_tiles][NRED] per-tile partial sums
+  long long* dbg;         // diagnostic builds only: [n_tiles][16] s_memtime stamps (dbg_stage == 9)
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
   int64_t c_off, c_path_off, c_int_off;
   double t_fixed[2];
   int32_t N, K, n_tiles, flags;
   int32_t qa_total, qw_total;
-  int32_t tile_begin, pad0;   // first tile of this launch (section-range sharding across GPUs)
+  int32_t tile_begin;     // first tile of this launch (section-range sharding across GPUs)
+  int32_t uni_n;          // > 0: every section has uni_n nodes (index arithmetic replaces the section tables)
+  int32_t spt;            // sections per tile when uniform
+  int32_t lds_out;        // doubles of the output staging buffer
+  int32_t dbg_stage;      // 0 = normal; k > 0: diagnostic build of the timeline, return after stage k
+  int32_t pad1;
   int32_t qa_off[PC_MAX_ORDER + 1];
   int32_t qw_off[PC_MAX_ORDER + 1];
+  // packed scaling doubles: Vz[NZ] rz[NZ] Vq[NQ] rq[NQ] Vt[2] rt[2] Vs[NS] rs[NS] Wd[NY] Wp[NP] Wi[NQ]
+  double scal[PC_MAX_SCAL];
+  // CSR value offsets
+  int64_t goff[PC_MAX_GOFF];  // [NY] defect block bases | [NP] path bases | [NQ] integral bases
+  int64_t hoff[PC_MAX_HOFF];  // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
 };
 
 #define PC_MAX_PHASES 16
@@ -63,7 +75,7 @@ struct PcTailArgs {
   double* H;
   double* fobj;                 // [1] objective value (scaled by w_J)
   double* grad;                 // [num_x] or null (caller zero-fills)
-  const double* params;         // [0] = sigma (objective factor), [1] = w_J
+  double sigma, wJ;             // objective factor and objective scaling
   const int64_t* point_x;       // [n_point] x index of every point variable
   const double* point_V;        // [n_point]
   const double* point_r;        // [n_point]

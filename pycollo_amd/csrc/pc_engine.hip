@@ -29,10 +29,11 @@ void set_err(const std::string& s) { g_err = s; }
 
 // LDS plan must match pc_kernels.hpp::lds_plan (kept in one place there; mirrored here because this
 // TU does not include device templates).
-int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED) {
-  int o = 0;
+int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
+  int o = lds_out;
   o += qa_total;
   o += qw_total;
+  o += PC_MAX_ORDER + 1;
   o += TB + 2;
   o += TB + 2;
   o += (TB + 4) / 2 + 1;
@@ -43,6 +44,33 @@ int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED) {
   o += NY * (TB + PC_MAX_ORDER);
   o += (NRED > 0 ? NRED : 1) * 16;
   return o;
+}
+
+// doubles of the output staging buffer of one phase: the longest CSR run a tile emits in one piece
+int phase_lds_out(const pcp::Phase& P, int n_s, int TB) {
+  int nmax = 0;
+  for (int k = 0; k < P.K; ++k) nmax = std::max(nmax, (int)P.n_k[k]);
+  int out = 0;
+  for (int a = 0; a < P.n_y; ++a) {
+    int Da = 0, Ca = P.n_t + (P.dep(a, a) ? 0 : 2);
+    for (int b = 0; b < P.n_z; ++b) Da += P.dep(a, b) ? 1 : 0;
+    for (int l = 0; l < n_s; ++l) Ca += P.dep(a, P.n_z + l) ? 1 : 0;
+    out = std::max(out, (Da * nmax + Ca) * (TB - 1));
+  }
+  for (int m = 0; m < P.n_p; ++m) {
+    int R = 0;
+    for (int c = 0; c < P.n_v; ++c) R += P.dep(P.n_y + m, c) ? 1 : 0;
+    out = std::max(out, R * TB);
+  }
+  for (int b = 0; b < P.n_z; ++b) out = std::max(out, P.hrow_count(b) * TB);
+  return out;
+}
+
+int phase_lds_bytes(const pcp::Phase& P, int n_s, int TB, int qa_total, int qw_total) {
+  int nfs = 0;
+  for (int a = 0; a < P.n_y; ++a)
+    for (int l = 0; l < n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
+  return 8 * lds_doubles(TB, qa_total, qw_total, P.n_y, nfs, P.nred, phase_lds_out(P, n_s, TB));
 }
 
 template <class T>
@@ -84,9 +112,11 @@ struct PinBuf {
 };
 
 struct PhaseDev {
-  DevBuf<int32_t> tile_k0, sec_s;
+  DevBuf<int32_t> tile_k0, tile_n0, sec_s;
   DevBuf<double> sec_h, scal, partials;
-  DevBuf<int64_t> sec_E, goff, hoff, hslot0, hslotN, hsum_slot;
+  DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
+  DevBuf<long long> dbg;
+  int uni_n = 0, spt = 0, lds_out = 0;
   hipFunction_t fn = nullptr;
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
   int tile_begin = 0, tile_end = 0;  // launched tile range (whole phase unless sharded)
@@ -122,20 +152,23 @@ struct pc_handle {
   hipModule_t module = nullptr;
   hipFunction_t tail_fn = nullptr;
   std::vector<std::unique_ptr<PhaseDev>> pd;
-  DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_params, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
+  DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
-  PinBuf<double> h_x, h_lam, h_c, h_G, h_H, h_params, h_fobj, h_grad, h_norms;
+  PinBuf<double> h_x, h_lam, h_c, h_G, h_H, h_fobj, h_grad, h_norms;
   std::vector<double> V_ocp, r_ocp, W_ocp;
   // cache for new_x == 0
   bool have_cG = false;
   int n_launches = 0;
+  int dbg_stage = 0;  // PYCOLLO_AMD_DBG_STAGE: diagnostic timeline build (profiling only)
   int lds_max = 0;
+  int lds_limit = 64 * 1024;  // dynamic LDS a workgroup may request (queried from the device)
 };
 
 namespace {
 
 void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
-                double* d_fobj, double* d_grad, int flags, hipStream_t st, bool bulk = true, bool tail = true) {
+                double* d_fobj, double* d_grad, int flags, hipStream_t st, double sigma, bool bulk = true,
+                bool tail = true) {
   auto& Q = h->Q;
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
@@ -148,17 +181,24 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     a.G = d_G;
     a.H = d_H;
     a.tile_k0 = D.tile_k0.p;
+    a.tile_n0 = D.tile_n0.p;
     a.sec_s = D.sec_s.p;
     a.sec_h = D.sec_h.p;
     a.sec_E = D.sec_E.p;
     a.qa = h->d_qa.p;
     a.qw = h->d_qw.p;
-    a.scal = D.scal.p;
-    a.goff = D.goff.p;
-    a.hoff = D.hoff.p;
+    if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
+    for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
+    for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
+    for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
+    a.uni_n = D.uni_n;
+    a.spt = D.spt;
+    a.lds_out = D.lds_out;
+    a.dbg_stage = h->dbg_stage;
     a.hslot0 = D.hslot0.p;
     a.hslotN = D.hslotN.p;
     a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
+    a.dbg = D.dbg.p;
     a.x_off = P.x_off;
     a.s_off = Q.s_off;
     a.c_off = P.c_off;
@@ -190,7 +230,8 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   t.H = d_H;
   t.fobj = d_fobj;
   t.grad = d_grad;
-  t.params = h->d_params.p;
+  t.sigma = sigma;
+  t.wJ = h->w_J;
   t.point_x = h->d_point_x.p;
   t.point_V = h->d_pointV.p;
   t.point_r = h->d_pointr.p;
@@ -272,12 +313,6 @@ void require_device(pc_handle* h) {
   HIP_OK(hipSetDevice(h->device));
 }
 
-void set_params(pc_handle* h, double sigma) {
-  h->h_params.p[0] = sigma;
-  h->h_params.p[1] = h->w_J;
-  HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-}
-
 void copy_x_in(pc_handle* h, const double* x) {
   std::memcpy(h->h_x.p, x, h->Q.num_x * sizeof(double));
   HIP_OK(hipMemcpyAsync(h->d_x.p, h->h_x.p, h->Q.num_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
@@ -326,6 +361,9 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       P.hess_row.assign(s.hess_row, s.hess_row + s.n_hess);
       P.hess_col.assign(s.hess_col, s.hess_col + s.n_hess);
       P.bulk_kernel = s.bulk_kernel ? s.bulk_kernel : "";
+      for (int k = 0; k < s.K; ++k)
+        if (s.compiled_order > 0 && s.n_k[k] != s.compiled_order)
+          throw std::runtime_error("phase kernel was compiled for a fixed section order that the mesh does not have");
     }
     Q.point_phase.assign(d->point_phase, d->point_phase + d->n_point);
     Q.point_kind.assign(d->point_kind, d->point_kind + d->n_point);
@@ -359,9 +397,25 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     }
     int TB = d->threads_per_block;
     if (const char* env = std::getenv("PYCOLLO_AMD_TB")) TB = std::atoi(env);
-    if (TB == 0) TB = Nmax >= 262144 ? 256 : (Nmax >= 65536 ? 128 : 64);
+    if (d->device >= 0) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, d->device) == hipSuccess && v > 0)
+        h->lds_limit = v;
+    }
+    const bool auto_tb = (TB == 0);
+    if (auto_tb) TB = Nmax >= 262144 ? 256 : (Nmax >= 65536 ? 128 : 64);
     if (TB != 64 && TB != 128 && TB != 256) throw std::runtime_error("threads_per_block must be 64, 128 or 256");
+    for (auto& P : Q.ph) pcp::finalize_phase_tables(P, Q.n_s);
+    if (auto_tb) {  // largest tile whose staging fits the 64 KiB of dynamic LDS a module kernel may request
+      auto fits = [&](int tb) {
+        for (auto& P : Q.ph)
+          if (phase_lds_bytes(P, Q.n_s, tb, (int)h->qa.size(), (int)h->qw.size()) > h->lds_limit) return false;
+        return true;
+      };
+      while (TB > 64 && !fits(TB)) TB /= 2;
+    }
     h->TB = TB;
+    if (const char* env = std::getenv("PYCOLLO_AMD_DBG_STAGE")) h->dbg_stage = std::atoi(env);
     pcp::build_all(Q, TB);
     for (auto& P : Q.ph)
       for (int k = 0; k < P.K; ++k)
@@ -382,10 +436,21 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       for (int a = 0; a < P.n_y; ++a)
         for (int l = 0; l < Q.n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
       D.nfs = nfs;
-      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred);
+      // uniform section order: index arithmetic replaces the section tables
+      bool same = true;
+      for (int k = 0; k < P.K; ++k) same = same && P.n_k[k] == P.n_k[0];
+      D.uni_n = same ? P.n_k[0] : 0;
+      D.spt = same ? (TB - 1) / (P.n_k[0] - 1) : 0;
+      if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
+        throw std::runtime_error("internal error: uniform tiling mismatch");
+      D.lds_out = phase_lds_out(P, Q.n_s, TB);
+      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred, D.lds_out);
       h->lds_max = std::max(h->lds_max, D.lds_bytes);
-      if (D.lds_bytes > 64 * 1024)
-        throw std::runtime_error("tile needs more than 64 KiB of dynamic LDS; use a smaller threads_per_block");
+      if (D.lds_bytes > h->lds_limit)
+        throw std::runtime_error("tile needs more dynamic LDS than a workgroup may request; use a smaller "
+                                 "threads_per_block");
+      if ((int)P.goff.size() > PC_MAX_GOFF || (int)P.hoff.size() > PC_MAX_HOFF)
+        throw std::runtime_error("too many variables/constraints per phase for the kernel argument block");
     }
     h->n_launches = (int)Q.ph.size() + 1;
     if (h->device < 0) return;  // structure-only handle
@@ -406,15 +471,19 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       auto& D = *h->pd[ip];
       HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
       D.tile_k0.upload(P.tile_k0);
+      {
+        std::vector<int32_t> tn(P.tile_k0.size());
+        for (size_t i = 0; i < tn.size(); ++i) tn[i] = P.sec_s[P.tile_k0[i]];
+        D.tile_n0.upload(tn);
+      }
       D.sec_s.upload(P.sec_s);
       D.sec_h.upload(P.h_k);
       D.sec_E.upload(P.sec_E);
-      D.goff.upload(P.goff);
-      D.hoff.upload(P.hoff);
       D.hslot0.upload(P.hslot0);
       D.hslotN.upload(P.hslotN);
       D.hsum_slot.upload(P.hsum_slot);
       D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
+      if (h->dbg_stage == 9) D.dbg.alloc((size_t)16 * D.n_tiles);
     }
     h->d_point_x.upload(Q.point_x);
     h->d_tail_owned.upload(Q.tail_owned);
@@ -422,10 +491,10 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->d_g_indptr.upload(Q.g_indptr);
     const size_t nG = Q.g_row.size(), nH = Q.h_row.size();
     h->d_x.alloc(Q.num_x); h->d_lam.alloc(Q.num_c); h->d_c.alloc(Q.num_c);
-    h->d_G.alloc(nG); h->d_H.alloc(nH); h->d_params.alloc(2); h->d_fobj.alloc(1);
+    h->d_G.alloc(nG); h->d_H.alloc(nH); h->d_fobj.alloc(1);
     h->d_grad.alloc(Q.num_x); h->d_norms.alloc(Q.num_c);
     h->h_x.alloc(Q.num_x); h->h_lam.alloc(Q.num_c); h->h_c.alloc(Q.num_c);
-    h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_params.alloc(2); h->h_fobj.alloc(1);
+    h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_fobj.alloc(1);
     h->h_grad.alloc(Q.num_x); h->h_norms.alloc(Q.num_c);
     HIP_OK(hipMemset(h->d_lam.p, 0, Q.num_c * sizeof(double)));
   });
@@ -511,10 +580,8 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    h->h_params.p[0] = obj_factor;
-    h->h_params.p[1] = h->w_J;
-    HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, st));
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st);
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
+               obj_factor);
   });
 }
 
@@ -523,8 +590,8 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, true,
-               false);
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, 1.0,
+               true, false);
   });
 }
 
@@ -533,11 +600,8 @@ int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, co
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    h->h_params.p[0] = obj_factor;
-    h->h_params.p[1] = h->w_J;
-    HIP_OK(hipMemcpyAsync(h->d_params.p, h->h_params.p, 2 * sizeof(double), hipMemcpyHostToDevice, st));
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, false,
-               true);
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
+               obj_factor, false, true);
   });
 }
 
@@ -577,9 +641,8 @@ int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* 
     copy_x_in(h, x);
     std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
     HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    set_params(h, obj_factor);
     launch_all(h, h->d_x.p, h->d_lam.p, h->d_c.p, h->d_G.p, h->d_H.p, h->d_fobj.p, nullptr,
-               PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, h->stream);
+               PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, h->stream, obj_factor);
     HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -598,8 +661,8 @@ static void eval_cG(pc_handle* h, const double* x, int new_x) {
   if (!new_x && h->have_cG) return;
   auto& Q = h->Q;
   copy_x_in(h, x);
-  set_params(h, 1.0);
-  launch_all(h, h->d_x.p, nullptr, h->d_c.p, h->d_G.p, nullptr, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G, h->stream);
+  launch_all(h, h->d_x.p, nullptr, h->d_c.p, h->d_G.p, nullptr, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G, h->stream,
+             1.0);
   HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -630,8 +693,8 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
     copy_x_in(h, x);
     std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
     HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    set_params(h, obj_factor);
-    launch_all(h, h->d_x.p, h->d_lam.p, nullptr, nullptr, h->d_H.p, h->d_fobj.p, nullptr, PC_FLAG_H, h->stream);
+    launch_all(h, h->d_x.p, h->d_lam.p, nullptr, nullptr, h->d_H.p, h->d_fobj.p, nullptr, PC_FLAG_H, h->stream,
+               obj_factor);
     HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     std::memcpy(values, h->h_H.p, h->d_H.n * sizeof(double));
@@ -642,7 +705,6 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   require_device(h);
   auto& Q = h->Q;
   copy_x_in(h, x);
-  set_params(h, 1.0);
   if (want_grad) HIP_OK(hipMemsetAsync(h->d_grad.p, 0, Q.num_x * sizeof(double), h->stream));
   // flags = 0: the bulk kernels are skipped entirely, only the endpoint block runs
   PcTailArgs t;
@@ -650,7 +712,8 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   t.x = h->d_x.p;
   t.fobj = h->d_fobj.p;
   t.grad = want_grad ? h->d_grad.p : nullptr;
-  t.params = h->d_params.p;
+  t.sigma = 1.0;
+  t.wJ = h->w_J;
   t.point_x = h->d_point_x.p;
   t.point_V = h->d_pointV.p;
   t.point_r = h->d_pointr.p;
@@ -704,6 +767,16 @@ int pc_row_norms_jac(pc_handle* h, const double* x, double* norms) {
     HIP_OK(hipMemcpyAsync(h->h_norms.p, h->d_norms.p, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     std::memcpy(norms, h->h_norms.p, m * sizeof(double));
+  });
+}
+
+int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles) {
+  return guarded([&] {
+    require_device(h);
+    auto& D = *h->pd.at(phase);
+    if (!D.dbg.p) throw std::runtime_error("no stamps: create the handle with PYCOLLO_AMD_DBG_STAGE=9");
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, D.dbg.p, sizeof(long long) * 16 * std::min(n_tiles, D.n_tiles), hipMemcpyDeviceToHost));
   });
 }
 

@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 
 #include "pc_args.h"
 
@@ -144,13 +145,14 @@ struct S {
 
 // LDS carve-up, shared by host (size query) and device.  All offsets in doubles.
 struct LdsPlan {
-  int qa, qw, h, E, s, kr, f, yu, fs, lam, red, total;
+  int qa, qw, off, h, E, s, kr, f, yu, fs, lam, red, out, total;
 };
-__host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED) {
+__host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
   LdsPlan p;
   int o = 0;
   p.qa = o; o += qa_total;
   p.qw = o; o += qw_total;
+  p.off = o; o += PC_MAX_ORDER + 1;     // int32 x 2 x (PC_MAX_ORDER+1): table offsets by order
   p.h = o; o += TB + 2;
   p.E = o; o += TB + 2;                 // int64 entries
   p.s = o; o += (TB + 4) / 2 + 1;       // int32 entries, (TB+3) of them
@@ -160,6 +162,7 @@ __host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, 
   p.fs = o; o += NFS * TB;
   p.lam = o; o += NY * (TB + PC_MAX_ORDER);
   p.red = o; o += (NRED > 0 ? NRED : 1) * 16;
+  p.out = o; o += lds_out;              // output staging: CSR runs are written to HBM fully coalesced
   p.total = o;
   return p;
 }
@@ -170,20 +173,95 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
+// every global store the wave has in flight -- a micro-second stall per use once the kernel has started
+// writing its outputs.  Here only lgkmcnt (LDS) is waited for; global stores keep streaming.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Cooperative, fully coalesced copy of a staged CSR run from LDS to HBM (512 B per wave instruction).
+__device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
+                                          int TB) {
+  int e = tid;
+  for (; e + 3 * TB < len; e += 4 * TB) {   // four LDS reads in flight before the first store issues
+    const double a0 = src[e], a1 = src[e + TB], a2 = src[e + 2 * TB], a3 = src[e + 3 * TB];
+    dst[e] = a0;
+    dst[e + TB] = a1;
+    dst[e + 2 * TB] = a2;
+    dst[e + 3 * TB] = a3;
+  }
+  for (; e < len; e += TB) dst[e] = src[e];
+}
+
 // ---------------------------------------------------------------------------------------------
 // bulk kernel
 // ---------------------------------------------------------------------------------------------
-template <class M>
-__device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
+// Every uniform kernel input, copied out of the kernarg segment in the entry block.  hipcc otherwise
+// loads each field lazily (s_load + s_waitcnt right before its first use, behind whatever branch that is
+// in): dozens of serial scalar-cache round trips, which is most of the run time of a one-wave tile.
+template <class St>
+struct BulkIn {
+  const double* x; const double* lam; double* c; double* G; double* H;
+  const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
+  const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials; long long* dbg;
+  int64_t x_off, s_off, c_off, c_path_off, c_int_off;
+  double t_fixed[2];
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage;
+  double scal[St::NSCAL > 0 ? St::NSCAL : 1];
+  int64_t goff[St::NFN > 0 ? St::NFN : 1];
+  int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
+};
+
+#define PC_PIN(v) asm volatile("" ::"s"(v))
+template <class T>
+__device__ __forceinline__ void pin_one(T v) {
+  asm volatile("" ::"s"(v));
+}
+template <class T, int N, int... I>
+__device__ __forceinline__ void pin_array_impl(const T (&a)[N], std::integer_sequence<int, I...>) {
+  (pin_one(a[I]), ...);
+}
+template <int CNT, class T, int N>
+__device__ __forceinline__ void pin_array(const T (&a)[N]) {
+  pin_array_impl(a, std::make_integer_sequence<int, CNT>{});
+}
+
+// UN > 0: the phase's mesh has UN nodes in every section and the kernel is compiled for exactly that
+// order (loops over section rows / nodes unroll, their LDS reads issue back to back, index arithmetic
+// divides by constants).  UN == 0: any mesh (orders may differ section by section).
+template <class M, int UN>
+__device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
+  BulkIn<St> A;
+  A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
+  A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; A.sec_h = KA.sec_h; A.sec_E = KA.sec_E;
+  A.qa = KA.qa; A.qw = KA.qw; A.hslot0 = KA.hslot0; A.hslotN = KA.hslotN; A.partials = KA.partials; A.dbg = KA.dbg;
+  A.x_off = KA.x_off; A.s_off = KA.s_off; A.c_off = KA.c_off; A.c_path_off = KA.c_path_off; A.c_int_off = KA.c_int_off;
+  A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
+  A.N = KA.N; A.K = KA.K; A.flags = KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
+  A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
+  static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
+  static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
+  static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
+  PC_PIN(A.x); PC_PIN(A.lam); PC_PIN(A.c); PC_PIN(A.G); PC_PIN(A.H); PC_PIN(A.tile_k0); PC_PIN(A.tile_n0);
+  PC_PIN(A.sec_s); PC_PIN(A.sec_h); PC_PIN(A.sec_E); PC_PIN(A.qa); PC_PIN(A.qw); PC_PIN(A.hslot0); PC_PIN(A.hslotN);
+  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
+  PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
+  PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
+  PC_PIN(A.dbg_stage);
+  pin_array<St::NSCAL>(A.scal);
+  pin_array<NFN>(A.goff);
+  pin_array<3 * NZ + NS * NZ>(A.hoff);
 
   extern __shared__ double smem[];
   const int tid = threadIdx.x, TB = blockDim.x;
-  const LdsPlan lp = lds_plan(TB, A.qa_total, A.qw_total, NY, NFS, NRED);
+  const LdsPlan lp = lds_plan(TB, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
+  int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off
   double* s_h = smem + lp.h;
   long long* s_E = reinterpret_cast<long long*>(smem + lp.E);
   int* s_s = reinterpret_cast<int*>(smem + lp.s);
@@ -193,47 +271,134 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
   double* s_fs = smem + lp.fs;
   double* s_lam = smem + lp.lam;
   double* s_red = smem + lp.red;
+  double* s_out = smem + lp.out;
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
   const int N = A.N;
   const int tile = blockIdx.x + A.tile_begin;
-  const int k0 = A.tile_k0[tile], k1 = A.tile_k0[tile + 1];
+  if (A.dbg_stage == 1) return;
+  // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of every tile
+  // stamps s_memtime at the phase boundaries into a buffer of its own
+  const bool stamping = (A.dbg_stage == 9) && threadIdx.x == 0;
+  auto STAMP = [&](int k) {
+    if (stamping) {
+      unsigned long long tm;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
+      A.dbg[(int64_t)tile * 16 + k] = (long long)tm;
+    }
+  };
+  STAMP(0);
+
+  // ---- tile geometry: index arithmetic on a uniform mesh, two small tables otherwise ----------------
+  const int un = UN > 0 ? UN : A.uni_n;
+  const bool uni = UN > 0 || un > 0;
+  int k0, k1, n0, n1;
+  if (uni) {
+    k0 = tile * A.spt;
+    k1 = min(k0 + A.spt, A.K);
+    n0 = k0 * (un - 1);
+    n1 = k1 * (un - 1);
+  } else {
+    k0 = A.tile_k0[tile];
+    k1 = A.tile_k0[tile + 1];
+    n0 = A.tile_n0[tile];
+    n1 = A.tile_n0[tile + 1];
+  }
   const bool has_prev = k0 > 0;
   const int kp = has_prev ? k0 - 1 : 0;  // first staged section
   const int nsec = k1 - kp;              // staged sections (previous one included)
   const bool last_tile = (k1 == A.K);
+  const int T = n1 - n0;                 // defect rows per state in this tile; nodes n0 .. n0+T
 
-  for (int i = tid; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
-  for (int i = tid; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
-  for (int i = tid; i <= nsec; i += TB) s_s[i] = A.sec_s[kp + i];
-  for (int i = tid; i < nsec; i += TB) {
-    s_h[i] = A.sec_h[kp + i];
-    s_E[i] = A.sec_E[kp + i];
-  }
-  __syncthreads();
-  const int n0 = s_s[has_prev ? 1 : 0], n1 = s_s[nsec];
-  const int T = n1 - n0;  // defect rows per state in this tile; nodes n0 .. n0+T
-  const int lam0 = s_s[0];  // first staged defect row
-  for (int ls = tid; ls < nsec; ls += TB) {
-    const int sb = s_s[ls], se = s_s[ls + 1];
-    for (int node = sb + 1; node <= se; ++node) {
-      const int tt = node - n0;
-      if (tt >= 0 && tt <= T) s_kr[tt] = ls;
-    }
-  }
-  if (tid == 0 && n0 == 0) s_kr[0] = -1;
-  if (wantH) {
-    const int cnt = n1 - lam0;
-    static_for<0, NY>([&](auto a_) {
-      constexpr int a = decltype(a_)::value;
-      for (int i = tid; i < cnt; i += TB)
-        s_lam[a * (TB + PC_MAX_ORDER) + i] = A.lam[A.c_off + (int64_t)a * (N - 1) + lam0 + i];
+  // ---- per-node loads are issued before any staging so that their latency overlaps it -------------
+  const double* sc = A.scal;   // kernarg-resident: scalar loads, no global round trip
+  const int t = tid;
+  const bool active = t <= T;
+  const int node = n0 + t;
+  const bool owns = active && (t < T || last_tile);
+  double v[NV > 0 ? NV : 1], F[NFN > 0 ? NFN : 1], Jv[NJ > 0 ? NJ : 1], Hv[NH > 0 ? NH : 1], mu[NFN > 0 ? NFN : 1];
+  double red[NRED > 0 ? NRED : 1];
+  static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });
+  if (active) {
+    static_for<0, NZ>([&](auto b_) {
+      constexpr int b = decltype(b_)::value;
+      v[b] = A.x[A.x_off + (int64_t)b * N + node];
+    });
+    static_for<0, NS>([&](auto l_) {
+      constexpr int l = decltype(l_)::value;
+      v[NZ + l] = A.x[A.s_off + l];
     });
   }
+  double lam_p[NP > 0 ? NP : 1], lam_q[NQ > 0 ? NQ : 1];
+  if (owns && wantH) {
+    static_for<0, NP>([&](auto m_) { lam_p[decltype(m_)::value] = A.lam[A.c_path_off + (int64_t) decltype(m_)::value * N + node]; });
+    static_for<0, NQ>([&](auto m_) { lam_q[decltype(m_)::value] = A.lam[A.c_int_off + decltype(m_)::value]; });
+  }
+
+  // ---- staging: every table's first chunk is loaded into registers before anything is written to LDS,
+  //      so the global-load latencies overlap instead of queueing behind one loop after another ----------
+  const int r_off = tid < 2 * (PC_MAX_ORDER + 1) ? reinterpret_cast<const int32_t*>(&KA.qa_off[0])[tid] : 0;   // qa_off, qw_off adjacent
+  const double r_qa = tid < A.qa_total ? A.qa[tid] : 0.0;
+  const double r_qw = tid < A.qw_total ? A.qw[tid] : 0.0;
+  const double r_h = tid < nsec ? A.sec_h[kp + tid] : 0.0;   // widths are data even on a uniform-order mesh
+  int lam0;  // first staged defect row
+  if (uni) {
+    lam0 = kp * (un - 1);
+  } else {
+    lam0 = A.sec_s[kp];
+  }
+  double r_lam[2 * (NY > 0 ? NY : 1)];
+  const int lam_cnt = n1 - lam0;   // <= TB + PC_MAX_ORDER - 2: two chunks
+  if (wantH) {
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      const double* src = A.lam + A.c_off + (int64_t)a * (N - 1) + lam0;
+      r_lam[2 * a] = tid < lam_cnt ? src[tid] : 0.0;
+      r_lam[2 * a + 1] = tid + TB < lam_cnt ? src[tid + TB] : 0.0;
+    });
+  }
+  if (!uni) {
+    for (int i = tid; i <= nsec; i += TB) {
+      s_s[i] = A.sec_s[kp + i];
+      s_E[i] = A.sec_E[kp + i];
+    }
+  }
+  if (tid < 2 * (PC_MAX_ORDER + 1)) s_off[tid] = r_off;
+  if (tid < A.qa_total) s_qa[tid] = r_qa;
+  if (tid < A.qw_total) s_qw[tid] = r_qw;
+  if (tid < nsec) s_h[tid] = r_h;
+  for (int i = tid + TB; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
+  for (int i = tid + TB; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
+  for (int i = tid + TB; i < nsec; i += TB) s_h[i] = A.sec_h[kp + i];
+  if (wantH) {
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      if (tid < lam_cnt) s_lam[a * (TB + PC_MAX_ORDER) + tid] = r_lam[2 * a];
+      if (tid + TB < lam_cnt) s_lam[a * (TB + PC_MAX_ORDER) + tid + TB] = r_lam[2 * a + 1];
+    });
+  }
+  if (!uni) {
+    __syncthreads();
+    for (int ls = tid; ls < nsec; ls += TB) {
+      const int sb = s_s[ls], se = s_s[ls + 1];
+      for (int nd = sb + 1; nd <= se; ++nd) {
+        const int tt = nd - n0;
+        if (tt >= 0 && tt <= T) s_kr[tt] = ls;
+      }
+    }
+    if (tid == 0 && n0 == 0) s_kr[0] = -1;
+  }
   __syncthreads();
+  STAMP(1);
+  if (A.dbg_stage == 2) { if (active && v[0] == 1.2345e300) A.c[0] = v[0]; return; }
+
+  // section accessors (local index ls counts from section kp)
+  auto S_s = [&](int ls) -> int { return uni ? (kp + ls) * (un - 1) : s_s[ls]; };
+  auto S_n = [&](int ls) -> int { return uni ? un : s_s[ls + 1] - s_s[ls] + 1; };
+  auto S_h = [&](int ls) -> double { return s_h[ls]; };
+  auto S_E = [&](int ls) -> long long { return uni ? (long long)(kp + ls) * (un - 1) * un : s_E[ls]; };
 
   // ---- uniform scalars ------------------------------------------------------------------------
-  const double* sc = A.scal;
   double t0 = A.t_fixed[0], tF = A.t_fixed[1];
   double dst[2] = {0.0, 0.0};  // d stretch / d t~_j for the free times, in x order
   {
@@ -251,39 +416,36 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
   }
   const double stretch = 0.5 * (tF - t0);
 
-  // ---- per-node state -------------------------------------------------------------------------
-  const int t = tid;
-  const bool active = t <= T;
-  const int node = n0 + t;
-  const bool owns = active && (t < T || last_tile);
-  double v[NV > 0 ? NV : 1], F[NFN > 0 ? NFN : 1], Jv[NJ > 0 ? NJ : 1], Hv[NH > 0 ? NH : 1], mu[NFN > 0 ? NFN : 1];
-  double red[NRED > 0 ? NRED : 1];
-  static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });
-
-  int ls_r = -1, pos_r = 0, n_r = 2, ls_s = 0, n_s = 2;
+  // ---- where the node sits in the mesh ----------------------------------------------------------
+  int ls_r = -1, pos_r = 0, n_r = UN > 0 ? UN : 2, ls_s = 0, n_s = UN > 0 ? UN : 2;
   bool has_start = false;
   double w_node = 0.0;
   if (active) {
     static_for<0, NZ>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
-      v[b] = sc[St::O_VZ + b] * A.x[A.x_off + (int64_t)b * N + node] + sc[St::O_RZ + b];
+      v[b] = sc[St::O_VZ + b] * v[b] + sc[St::O_RZ + b];
     });
     static_for<0, NS>([&](auto l_) {
       constexpr int l = decltype(l_)::value;
-      v[NZ + l] = sc[St::O_VS + l] * A.x[A.s_off + l] + sc[St::O_RS + l];
+      v[NZ + l] = sc[St::O_VS + l] * v[NZ + l] + sc[St::O_RS + l];
     });
-    ls_r = s_kr[t];
+    if (uni) {
+      const int g = node - kp * (un - 1);           // node index relative to the first staged section
+      ls_r = (node == 0) ? -1 : (g - 1) / (un - 1);
+    } else {
+      ls_r = s_kr[t];
+    }
     ls_s = ls_r + 1;
     // the node opens section ls_s only if it is that section's first node (staged in this tile)
-    has_start = (node < N - 1) && (ls_s < nsec) && (s_s[ls_s] == node);
+    has_start = (node < N - 1) && (ls_s < nsec) && (S_s(ls_s) == node);
     if (ls_r >= 0) {
-      n_r = s_s[ls_r + 1] - s_s[ls_r] + 1;
-      pos_r = node - s_s[ls_r];
-      w_node = s_h[ls_r] * s_qw[A.qw_off[n_r] + pos_r];
+      n_r = S_n(ls_r);
+      pos_r = node - S_s(ls_r);
+      w_node = S_h(ls_r) * s_qw[s_off[PC_MAX_ORDER + 1 + n_r] + pos_r];
     }
     if (has_start) {
-      n_s = s_s[ls_s + 1] - s_s[ls_s] + 1;
-      w_node += s_h[ls_s] * s_qw[A.qw_off[n_s]];
+      n_s = S_n(ls_s);
+      w_node += S_h(ls_s) * s_qw[s_off[PC_MAX_ORDER + 1 + n_s]];
     }
   }
 
@@ -295,31 +457,34 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
       const double* la = s_lam + a * (TB + PC_MAX_ORDER);
       double acc = 0.0;
       if (ls_r >= 0) {
-        const double* At = s_qa + A.qa_off[n_r];
-        const int base = s_s[ls_r] - lam0;
+        const double* At = s_qa + s_off[n_r];
+        const int base = S_s(ls_r) - lam0;
         double a2 = 0.0;
+#pragma unroll
         for (int j = 1; j < n_r; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_r + pos_r];
-        acc += s_h[ls_r] * a2;
+        acc += S_h(ls_r) * a2;
       }
       if (has_start) {
-        const double* At = s_qa + A.qa_off[n_s];
-        const int base = s_s[ls_s] - lam0;
+        const double* At = s_qa + s_off[n_s];
+        const int base = S_s(ls_s) - lam0;
         double a2 = 0.0;
+#pragma unroll
         for (int j = 1; j < n_s; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_s];
-        acc += s_h[ls_s] * a2;
+        acc += S_h(ls_s) * a2;
       }
       mu[a] = sc[St::O_WD + a] * acc;
     });
     static_for<0, NP>([&](auto m_) {
       constexpr int m = decltype(m_)::value;
-      mu[NY + m] = sc[St::O_WP + m] * A.lam[A.c_path_off + (int64_t)m * N + node];
+      mu[NY + m] = sc[St::O_WP + m] * lam_p[m];
     });
     static_for<0, NQ>([&](auto m_) {
       constexpr int m = decltype(m_)::value;
-      mu[NY + NP + m] = -sc[St::O_WI + m] * A.lam[A.c_int_off + m] * w_node;
+      mu[NY + NP + m] = -sc[St::O_WI + m] * lam_q[m] * w_node;
     });
   }
 
+  STAMP(2);
   // ---- model evaluation -----------------------------------------------------------------------
   if (active) {
     double mult[NFN > 0 ? NFN : 1];
@@ -339,30 +504,39 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
     });
   }
   __syncthreads();
+  STAMP(3);
+  if (A.dbg_stage == 3) { if (active && F[0] == 1.2345e300) A.c[0] = F[0]; return; }
 
-  // ---- node-owned outputs ---------------------------------------------------------------------
-  if (owns) {
-    // path rows (backend.py:1612-1614, compiled.py:336-355)
-    static_for<0, NP>([&](auto m_) {
-      constexpr int m = decltype(m_)::value;
-      constexpr int r = NY + m;
-      const double Wp = sc[St::O_WP + m];
-      if (wantC) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
-      if (wantG) {
-        constexpr int R = St::nzdep(r) + St::nsdep(r);
-        const int64_t rs = A.goff[St::GO_P + m] + (int64_t)node * R;
+  // number of nodes this tile owns, and the first one (for the staged per-node runs)
+  const int n_own = T + (last_tile ? 1 : 0);
+
+  // ---- path rows (backend.py:1612-1614, compiled.py:336-355) ------------------------------------
+  static_for<0, NP>([&](auto m_) {
+    constexpr int m = decltype(m_)::value;
+    constexpr int r = NY + m;
+    constexpr int R = St::nzdep(r) + St::nsdep(r);
+    const double Wp = sc[St::O_WP + m];
+    if (owns && wantC) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
+    if (wantG && R > 0) {
+      if (owns) {
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
-          if constexpr (St::dep(r, b)) A.G[rs + St::zrank(r, b)] = Wp * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
+          if constexpr (St::dep(r, b)) s_out[t * R + St::zrank(r, b)] = Wp * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
         });
         static_for<0, NS>([&](auto l_) {
           constexpr int l = decltype(l_)::value;
           if constexpr (St::dep(r, NZ + l))
-            A.G[rs + St::nzdep(r) + St::srank(r, l)] = Wp * sc[St::O_VS + l] * Jv[St::jidx(r, NZ + l)];
+            s_out[t * R + St::nzdep(r) + St::srank(r, l)] = Wp * sc[St::O_VS + l] * Jv[St::jidx(r, NZ + l)];
         });
       }
-    });
-    // integral rows: z entries and partial sums (backend.py:1645-1647, compiled.py:357-379)
+      lds_barrier();
+      flush_run(A.G + A.goff[St::GO_P + m] + (int64_t)n0 * R, s_out, n_own * R, tid, TB);
+      lds_barrier();
+    }
+  });
+
+  // ---- integral rows: z entries and partial sums (backend.py:1645-1647, compiled.py:357-379) -----
+  if (owns) {
     static_for<0, NQ>([&](auto m_) {
       constexpr int m = decltype(m_)::value;
       constexpr int r = NY + NP + m;
@@ -380,22 +554,50 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
         });
       }
     });
-    // Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums
-    if (wantH) {
-      const bool edge0 = (node == 0), edgeN = (node == N - 1);
+  }
+
+  STAMP(4);
+  // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
+  if (wantH) {
+    const bool edge0 = (node == 0), edgeN = (node == N - 1);
+    // bands: one variable block row at a time; rows with several entries go through the staging buffer
+    static_for<0, NZ>([&](auto rv_) {
+      constexpr int rv = decltype(rv_)::value;
+      constexpr int MB = St::hrow_count(rv);
+      if constexpr (MB > 0) {
+        double vals[MB];
+        static_for<0, NH>([&](auto e_) {
+          constexpr int e = decltype(e_)::value;
+          if constexpr (M::hr(e) == rv)
+            vals[St::hpos(e)] = sc[St::O_VZ + rv] * sc[St::O_VZ + M::hc(e)] * Hv[e];
+        });
+        if (owns && (edge0 || edgeN)) {   // edge rows may interleave endpoint entries: explicit slots
+          static_for<0, NH>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr (M::hr(e) == rv)
+              A.H[(edge0 ? A.hslot0 : A.hslotN)[St::hzz_index(e)]] = vals[St::hpos(e)];
+          });
+        }
+        if constexpr (MB == 1) {
+          if (owns && !edge0 && !edgeN) A.H[A.hoff[St::HO_Z + rv] + (int64_t)node] = vals[0];
+        } else {
+          if (owns) static_for<0, MB>([&](auto q_) { s_out[t * MB + decltype(q_)::value] = vals[decltype(q_)::value]; });
+          lds_barrier();
+          // interior nodes of the tile: [lo, hi)
+          const int lo = (n0 == 0) ? 1 : 0, hi = (last_tile ? n_own - 1 : n_own);
+          if (hi > lo)
+            flush_run(A.H + A.hoff[St::HO_Z + rv] + (int64_t)(n0 + lo) * MB, s_out + lo * MB, (hi - lo) * MB, tid, TB);
+          lds_barrier();
+        }
+      }
+    });
+    if (owns) {
       static_for<0, NH>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
         constexpr int rv = M::hr(e), cv = M::hc(e);
-        if constexpr (rv < NZ) {
-          const double val = sc[St::O_VZ + rv] * sc[St::O_VZ + cv] * Hv[e];
-          int64_t dst_i;
-          if (edge0) dst_i = A.hslot0[St::hzz_index(e)];
-          else if (edgeN) dst_i = A.hslotN[St::hzz_index(e)];
-          else dst_i = A.hoff[St::HO_Z + rv] + (int64_t)node * St::hrow_count(rv) + St::hpos(e);
-          A.H[dst_i] = val;
-        } else if constexpr (cv < NZ) {
+        if constexpr (rv >= NZ && cv < NZ) {
           A.H[A.hoff[St::HO_S + (rv - NZ) * NZ + cv] + node] = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
-        } else {
+        } else if constexpr (rv >= NZ) {
           constexpr int l = rv - NZ, l2 = cv - NZ;
           red[St::R_SS + l * (l + 1) / 2 + l2] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
         }
@@ -424,75 +626,100 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
     }
   }
 
-  // ---- Jacobian of the defect rows, written column-wise (compiled.py:305-334) -----------------
-  if (active && wantG) {
-    auto write_cols = [&](int ls, int pos, int n) {
-      const double h = s_h[ls];
-      const int sk = s_s[ls];
-      const long long E = s_E[ls];
-      const double* At = s_qa + A.qa_off[n];
-      for (int j = 1; j < n; ++j) {
-        const double coef = stretch * h * At[(j - 1) * n + pos];
-        static_for<0, NY>([&](auto a_) {
-          constexpr int a = decltype(a_)::value;
-          const double Wd = sc[St::O_WD + a];
-          const int64_t rs = A.goff[St::GO_D + a] + (int64_t)St::D(a) * (E + (long long)(j - 1) * n) +
-                             (int64_t)St::C(a) * (sk + j - 1);
-          static_for<0, NZ>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            if constexpr (St::dep(a, b)) {
-              constexpr int before = St::ndep_before(a, b);
-              constexpr int extra = (St::own_sparse(a) && a < b) ? 2 : 0;
-              double val = coef * Jv[St::jidx(a, b)] * sc[St::O_VZ + b];
-              if constexpr (a == b) val += sc[St::O_VZ + a] * ((pos == 0 ? 1.0 : 0.0) - (pos == j ? 1.0 : 0.0));
-              A.G[rs + (int64_t)before * n + extra + pos] = Wd * val;
-            }
-          });
-          if constexpr (St::own_sparse(a)) {
-            const int64_t o = rs + (int64_t)St::ndep_before(a, a) * n;
-            if (pos == 0) A.G[o] = Wd * sc[St::O_VZ + a];
-            if (pos == j) A.G[o + 1] = -(Wd * sc[St::O_VZ + a]);
-          }
-        });
-      }
-    };
-    if (ls_r >= (has_prev ? 1 : 0)) write_cols(ls_r, pos_r, n_r);
-    if (has_start) write_cols(ls_s, 0, n_s);
-  }
-
-  // ---- defect rows: value, t and s columns (row-wise; backend.py:1601-1603, compiled.py:324-334)
-  if (active && t >= 1 && (wantC || wantG)) {
-    const int n = n_r, j = pos_r, sk = s_s[ls_r] - n0;
-    const double h = s_h[ls_r];
-    const double* Arow = s_qa + A.qa_off[n] + (j - 1) * n;
+  STAMP(5);
+  if (A.dbg_stage == 4) return;
+  // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
+  double accf[NY > 0 ? NY : 1];
+  const bool rowthr = active && t >= 1;
+  if (rowthr && (wantC || wantG)) {
+    const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
+    const double h = S_h(ls_r);
+    const double* Arow = s_qa + s_off[n] + (j - 1) * n;
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       double acc = 0.0;
+#pragma unroll
       for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TB + sk + i];
-      const double Wd = sc[St::O_WD + a];
+      accf[a] = h * acc;
       if (wantC)
-        A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = Wd * ((s_yu[a * TB + sk] - v[a]) + stretch * (h * acc));
-      if (wantG) {
-        if constexpr (NT + St::nsdep(a) > 0) {
-          const int64_t rs = A.goff[St::GO_D + a] + (int64_t)St::D(a) * (s_E[ls_r] + (long long)(j - 1) * n) +
-                             (int64_t)St::C(a) * (node - 1) + (int64_t)St::D(a) * n + (St::own_sparse(a) ? 2 : 0);
-          static_for<0, NT>([&](auto jt_) {
-            constexpr int jt = decltype(jt_)::value;
-            A.G[rs + jt] = Wd * dst[jt] * (h * acc);
-          });
-          static_for<0, NS>([&](auto l_) {
-            constexpr int l = decltype(l_)::value;
-            if constexpr (St::dep(a, NZ + l)) {
-              double as = 0.0;
-              for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[St::fs_slot(a, l) * TB + sk + i];
-              A.G[rs + NT + St::srank(a, l)] = Wd * stretch * sc[St::O_VS + l] * (h * as);
-            }
-          });
-        }
-      }
+        A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TB + sk] - v[a]) + stretch * accf[a]);
     });
   }
 
+  STAMP(6);
+  if (A.dbg_stage == 5) return;
+  // ---- Jacobian of the defect rows (compiled.py:305-334), one state at a time:
+  //      entries are produced column-wise / row-wise into the staging buffer, then the tile's
+  //      contiguous CSR run of that state is written to HBM fully coalesced
+  if (wantG) {
+    const int lsA = has_prev ? 1 : 0;                       // first section of the tile (local index)
+    const long long E0 = S_E(lsA), E1 = S_E(nsec);
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      constexpr int Da = St::D(a), Ca = St::C(a);
+      const double Wd = sc[St::O_WD + a];
+      // local offset of row (section ls, row j) inside the run: rows before it in the tile
+      auto row_off = [&](int ls, int j, int n) -> int {
+        return (int)((long long)Da * (S_E(ls) - E0 + (long long)(j - 1) * n)) + Ca * (S_s(ls) + j - 1 - n0);
+      };
+      if (active) {
+        auto write_cols = [&](int ls, int pos, int n) {
+          const double h = S_h(ls);
+          const double* At = s_qa + s_off[n];
+#pragma unroll
+          for (int j = 1; j < n; ++j) {
+            const double coef = stretch * h * At[(j - 1) * n + pos];
+            const int rs = row_off(ls, j, n);
+            static_for<0, NZ>([&](auto b_) {
+              constexpr int b = decltype(b_)::value;
+              if constexpr (St::dep(a, b)) {
+                constexpr int before = St::ndep_before(a, b);
+                constexpr int extra = (St::own_sparse(a) && a < b) ? 2 : 0;
+                double val = coef * Jv[St::jidx(a, b)] * sc[St::O_VZ + b];
+                if constexpr (a == b) val += sc[St::O_VZ + a] * ((pos == 0 ? 1.0 : 0.0) - (pos == j ? 1.0 : 0.0));
+                s_out[rs + before * n + extra + pos] = Wd * val;
+              }
+            });
+            if constexpr (St::own_sparse(a)) {
+              const int o = rs + St::ndep_before(a, a) * n;
+              if (pos == 0) s_out[o] = Wd * sc[St::O_VZ + a];
+              if (pos == j) s_out[o + 1] = -(Wd * sc[St::O_VZ + a]);
+            }
+          }
+        };
+        if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r);
+        if (has_start) write_cols(ls_s, 0, n_s);
+        if constexpr (NT + St::nsdep(a) > 0) {
+          if (rowthr) {   // t and s columns of this lane's own row
+            const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
+            const int rs = row_off(ls_r, j, n) + Da * n + (St::own_sparse(a) ? 2 : 0);
+            static_for<0, NT>([&](auto jt_) {
+              constexpr int jt = decltype(jt_)::value;
+              s_out[rs + jt] = Wd * dst[jt] * accf[a];
+            });
+            static_for<0, NS>([&](auto l_) {
+              constexpr int l = decltype(l_)::value;
+              if constexpr (St::dep(a, NZ + l)) {
+                const double* Arow = s_qa + s_off[n] + (j - 1) * n;
+                double as = 0.0;
+#pragma unroll
+                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[St::fs_slot(a, l) * TB + sk + i];
+                s_out[rs + NT + St::srank(a, l)] = Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
+              }
+            });
+          }
+        }
+      }
+      lds_barrier();
+      const int len = (int)((long long)Da * (E1 - E0)) + Ca * T;
+      const int64_t g0 = A.goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
+      flush_run(A.G + g0, s_out, len, tid, TB);
+      lds_barrier();
+    });
+  }
+
+  STAMP(7);
+  if (A.dbg_stage == 6) return;
   // ---- per-tile partial sums (fixed order: lanes -> waves -> tile) ------------------------------
   if constexpr (NRED > 0) {
     const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
@@ -501,13 +728,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& A) {
       const double s = wave_sum(red[r]);
       if (lane == 0) s_red[r * 16 + wave] = s;
     });
-    __syncthreads();
+    lds_barrier();
     if (tid < NRED) {
       double s = 0.0;
       for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
       A.partials[(int64_t)tile * NRED + tid] = s;
     }
   }
+  STAMP(8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,22 +753,22 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
   using St = S<M>;
   constexpr int NZ = St::NZ, NQ = St::NQ, NP = St::NP, NY = St::NY, NS = St::NS, NT = St::NT, NRED = St::NRED;
   if constexpr (NRED > 0) {
-    __shared__ double s_part[256];
+    __shared__ double s_part[NRED * 4];
     __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = blockDim.x;  // TB <= 256
-    for (int r = 0; r < NRED; ++r) {
-      double acc = 0.0;
-      for (int b = tid; b < P.n_tiles; b += TB) acc += P.partials[(int64_t)b * NRED + r];
-      s_part[tid] = acc;
-      __syncthreads();
-      for (int off = TB >> 1; off > 0; off >>= 1) {
-        if (tid < off) s_part[tid] += s_part[tid + off];
-        __syncthreads();
-      }
-      if (tid == 0) s_sum[r] = s_part[0];
-      __syncthreads();
-    }
+    const int tid = threadIdx.x, TB = blockDim.x;  // TB == 256: 4 waves
+    double acc[NRED];
+    static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
+    for (int b = tid; b < P.n_tiles; b += TB)
+      static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += P.partials[(int64_t)b * NRED + decltype(r_)::value]; });
+    static_for<0, NRED>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      const double w = wave_sum(acc[r]);
+      if ((tid & 63) == 0) s_part[r * 4 + (tid >> 6)] = w;
+    });
+    __syncthreads();
+    if (tid < NRED) s_sum[tid] = ((s_part[tid * 4] + s_part[tid * 4 + 1]) + s_part[tid * 4 + 2]) + s_part[tid * 4 + 3];
+    __syncthreads();
     if (tid == 0) {
       const double* sc = P.scal;
       const int N = P.N;
@@ -608,7 +836,7 @@ __device__ __forceinline__ void tail_point(const PcTailArgs& A) {
     constexpr int i = decltype(i_)::value;
     xb[i] = A.point_V[i] * A.x[A.point_x[i]] + A.point_r[i];
   });
-  const double sigma = A.params[0], wJ = A.params[1];
+  const double sigma = A.sigma, wJ = A.wJ;
   const bool wantH = A.flags & PC_FLAG_H;
   static_for<0, NB>([&](auto r_) {
     constexpr int r = decltype(r_)::value;

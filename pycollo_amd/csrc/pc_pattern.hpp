@@ -462,7 +462,7 @@ inline void build_H(Problem& Q) {
 
 inline void build_all(Problem& Q, int TB) {
   for (auto& P : Q.ph) {
-    finalize_phase_tables(P, Q.n_s);
+    if (P.sec_s.empty()) finalize_phase_tables(P, Q.n_s);
     build_tiles(P, TB);
   }
   build_layout(Q);

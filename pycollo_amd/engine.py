@@ -42,7 +42,7 @@ class _PhaseDesc(C.Structure):
                 ("K", C.c_int32), ("n_k", _i32p), ("h_k", _f64p),
                 ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
-                ("bulk_kernel", C.c_char_p)]
+                ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32)]
 
 
 class _ProblemDesc(C.Structure):
@@ -124,7 +124,8 @@ class NlpEngine:
     """One transcribed NLP (model x meshes x scaling) bound to one GPU (or structure-only)."""
 
     def __init__(self, problem: ProblemSpec | Model, meshes: list[PhaseMesh] | None = None, *, device: int | None = 0,
-                 threads_per_block: int = 0, quad: QuadratureTables | None = None, build: bool = True):
+                 threads_per_block: int = 0, quad: QuadratureTables | None = None, build: bool = True,
+                 specialise: bool = True):
         self.model = problem if isinstance(problem, Model) else compile_model(problem)
         self.quad = quad or QuadratureTables(self.model.quadrature_method)
         if meshes is None:
@@ -138,8 +139,13 @@ class NlpEngine:
         self._h = C.c_void_p()
         self._keep = []
         code_object = None
+        # kernels are specialised for the section order of every phase whose mesh has a single order
+        self.orders = tuple(int(m.n[0]) if np.all(m.n == m.n[0]) else 0 for m in meshes)
+        if not specialise:
+            self.orders = tuple(0 for _ in meshes)
         if self.device >= 0:
-            code_object = codegen.build_code_object(self.model) if build else codegen.code_object_path(self.model)
+            code_object = (codegen.build_code_object(self.model, self.orders) if build
+                           else codegen.code_object_path(self.model, self.orders))
             if not os.path.exists(code_object):
                 raise RuntimeError(f"code object {code_object} is missing")
         self.code_object = code_object
@@ -179,6 +185,7 @@ class NlpEngine:
             d.n_jac, d.jac_row, d.jac_col = len(jr), _ptr(jr, _i32p), _ptr(jc, _i32p)
             d.n_hess, d.hess_row, d.hess_col = len(hr), _ptr(hr, _i32p), _ptr(hc, _i32p)
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
+            d.compiled_order = self.orders[i] if self.device >= 0 else 0
         pt = m.point
         pp = _i32([v.phase for v in pt.vars])
         pk = _i32([_KIND[v.kind] for v in pt.vars])

@@ -1,0 +1,31 @@
+"""Diagnostic: in-kernel phase timeline of the bulk kernel (PYCOLLO_AMD_DBG_STAGE=9)."""
+import os, sys, ctypes as C
+os.environ["PYCOLLO_AMD_DBG_STAGE"] = "9"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pycollo_amd import problems
+from pycollo_amd.engine import NlpEngine
+name = sys.argv[1] if len(sys.argv) > 1 else "hypersensitive"
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+order = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+tpb = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+eng = NlpEngine(problems.REGISTRY[name](K=K, order=order), device=0, threads_per_block=tpb)
+dev = torch.device("cuda", 0)
+x = torch.rand(eng.num_x, dtype=torch.float64, device=dev) - 0.5
+lam = torch.randn(eng.num_c, dtype=torch.float64, device=dev)
+c = torch.empty(eng.num_c, dtype=torch.float64, device=dev); G = torch.empty(eng.nnz_jac, dtype=torch.float64, device=dev); H = torch.empty(eng.nnz_hess, dtype=torch.float64, device=dev)
+s = torch.cuda.Stream(device=dev)
+for _ in range(200):
+    eng.evaluate_all_device(x, 1.0, lam, c, G, H, s.cuda_stream)
+torch.cuda.synchronize()
+nt = eng.info["n_tiles_total"]
+out = np.zeros((nt, 16), dtype=np.int64)
+eng._lib.pc_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+assert eng._lib.pc_debug_stamps(eng._h, 0, out.ctypes.data, nt)
+d = np.diff(out[:, :9], axis=1)
+names = ["loads+staging+sync", "geometry+mu", "eval+LDS f+sync", "path+integral", "hessian", "defect c", "defect G", "partials"]
+print(f"{name} K={K} n={order} TB={tpb}: tiles {nt}; cycles per phase (median over tiles; each stamp costs ~250-500 cycles itself)")
+for i, nm in enumerate(names):
+    print(f"  {nm:22s} {np.median(d[:, i]):8.0f}   (min {d[:, i].min():6d}, max {d[:, i].max():6d})")
+print(f"  total                  {np.median(out[:, 8] - out[:, 0]):8.0f} cycles = {np.median(out[:, 8] - out[:, 0]) / 100:.2f} us at 100 MHz stamp clock")
+print("  kernel span (first start -> last end):", (out[:, 8].max() - out[:, 0].min()) / 100, "us")
