@@ -150,8 +150,19 @@ def main():
         torch.cuda.synchronize()
         k_ms = e0.elapsed_time(e1) / args.steps
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+        # this process); only quoted when the workload is the one those passes profiled
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                pmc = json.load(f)
+            key = f"{args.problem}_K{K_total}_n{args.order}_{eng.layout.phases[0].N}_nodes"
+            if key in pmc:
+                traffic = pmc[key]["pc_bulk_p0"]["hbm_bytes_per_launch"]
+        except OSError:
+            pass
         roofline = {"bound": "hbm", "kernel": "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(k_ms * 1e3, 3),
                     "method": f"{args.steps} back-to-back bulk-kernel launches between two HIP events on the launch stream"}
 

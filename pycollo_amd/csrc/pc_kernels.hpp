@@ -167,10 +167,31 @@ __host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, 
   return p;
 }
 
+// Sum over the 64 lanes of a wave in a fixed order; the result is valid in lane 0.
+// Steps 1..16 use DPP row shifts / a row mirror-free butterfly inside 16-lane rows (VALU speed), the last
+// two steps cross rows with v_readlane.  (A chain of six ds_bpermute shuffles costs ~130 cycles a step.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __builtin_bit_cast(double, ((long long)(unsigned)hi << 32) | (long long)(unsigned)lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
+  // row_shr:n (0x110 + n) with bound_ctrl: lanes shifted in from outside the row read 0
+  v += dpp_mov<0x111>(v);   // lane i += lane i-1
+  v += dpp_mov<0x112>(v);   // += lane i-2 (of the partial sums)
+  v += dpp_mov<0x114>(v);   // += i-4
+  v += dpp_mov<0x118>(v);   // += i-8 : lane 15 of every row holds the row total
+  const long long b = __builtin_bit_cast(long long, v);
+  double tot = 0.0;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  for (int r = 0; r < 4; ++r) {
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 16 * r + 15);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 16 * r + 15);
+    tot += __builtin_bit_cast(double, ((long long)(unsigned)hi << 32) | (long long)(unsigned)lo);
+  }
+  return tot;   // uniform: every lane holds the wave total
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits for
@@ -659,8 +680,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
       constexpr int Da = St::D(a), Ca = St::C(a);
       const double Wd = sc[St::O_WD + a];
       // local offset of row (section ls, row j) inside the run: rows before it in the tile
+      // all offsets inside a tile fit 32 bits: section base + (j-1) * row length
       auto row_off = [&](int ls, int j, int n) -> int {
-        return (int)((long long)Da * (S_E(ls) - E0 + (long long)(j - 1) * n)) + Ca * (S_s(ls) + j - 1 - n0);
+        const int eloc = uni ? (ls - lsA) * (n - 1) * n : (int)(S_E(ls) - E0);
+        return Da * eloc + Ca * (S_s(ls) - n0) + (j - 1) * (Da * n + Ca);
       };
       if (active) {
         auto write_cols = [&](int ls, int pos, int n) {
