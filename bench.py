@@ -7,8 +7,9 @@ A "step" is one fused ``pc_eval_all_device`` over the whole transcribed NLP with
 resident in HBM and c~, G~, H~ left in HBM.  N = 1: BASELINE.json configs[1] -- hypersensitive problem,
 1 phase, 2000 mesh sections x 6 Lobatto nodes = 10 001 collocation nodes.  N > 1: the mesh grows to
 2000*N sections and is sharded by contiguous section ranges, one rank per GPU (weak scaling: 10 001
-nodes per GPU); every step ends with the path's exchange (integral partial sums all-reduced, shard
-outputs all-gathered) -- see pycollo_amd/sharding.py.
+nodes per GPU); every step contains the path's exchange -- one all-gather of the ranks' CSR runs and
+per-tile partial sums, after which every rank holds the complete c~, G~, H~ (pycollo_amd/sharding.py).
+``value`` counts 10 001-node shard evaluations per second over the whole job (N x sharded evals/s).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`.
 """
@@ -45,6 +46,8 @@ def main():
     ap.add_argument("--problem", default="hypersensitive")
     ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N > 1 on one GPU")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the sharded result with an unsharded one")
     args = ap.parse_args()
 
     import numpy as np
@@ -58,11 +61,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: pycollo_amd has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()   # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from pycollo_amd import problems
     from pycollo_amd.engine import NlpEngine
@@ -108,13 +116,28 @@ def main():
         def step():
             sh.evaluate_all_device(x, 1.0, lam, stream)
 
-        bulk_only = None
+        def bulk_only():   # this rank's tiles only
+            sh.engine.launch_bulk_only(x, lam, sh.c, sh.G, sh.H, stream)
+
+        if args.check:   # the complete, reassembled outputs of every rank equal the unsharded evaluation bit for bit
+            ref = NlpEngine(prob, device=local_rank, threads_per_block=sh.engine.info["threads_per_block"])
+            rc = torch.empty(ref.num_c, dtype=torch.float64, device=dev)
+            rG = torch.empty(ref.nnz_jac, dtype=torch.float64, device=dev)
+            rH = torch.empty(ref.nnz_hess, dtype=torch.float64, device=dev)
+            ref.evaluate_all_device(x, 1.0, lam, rc, rG, rH, stream)
+            c_, G_, H_ = sh.evaluate_all_device(x, 1.0, lam, stream)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(rc, c_) and torch.equal(rG, G_) and torch.equal(rH, H_))
+            print(f"[rank {rank}] sharded == unsharded: {ok}", file=sys.stderr, flush=True)
+            if not ok:
+                raise SystemExit("sharded evaluation differs from the unsharded one")
+            ref.close()
         alg_bytes = sh.local_algorithmic_bytes
         workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes sharded by "
                     f"section over {world} GPUs ({args.sections} sections = {args.sections * (args.order - 1) + 1} "
                     f"nodes per GPU)")
         extra = {"num_x": sh.num_x, "num_c": sh.num_c, "nnz_jac": sh.nnz_jac, "nnz_hess": sh.nnz_hess,
-                 "exchange": "all_reduce(partial sums) + all_gather(c, G, H shards)"}
+                 "exchange": "one all_gather_into_tensor per evaluation (CSR runs of c, G, H + per-tile partial sums)"}
 
     def sync():
         torch.cuda.synchronize()
@@ -156,8 +179,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
                 pmc = json.load(f)
-            key = f"{args.problem}_K{K_total}_n{args.order}_{eng.layout.phases[0].N}_nodes"
-            if key in pmc:
+            key = f"{args.problem}_K{K_total}_n{args.order}_{args.sections * (args.order - 1) + 1}_nodes"
+            if world == 1 and key in pmc:
                 traffic = pmc[key]["pc_bulk_p0"]["hbm_bytes_per_launch"]
         except OSError:
             pass

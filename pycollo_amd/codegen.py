@@ -180,16 +180,25 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append(_phase_struct(pm))
     parts.append(_point_struct(model.point))
     parts.append("}  // namespace gen\n")
+    parts.append("namespace gen {")
+    parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase, then the endpoint block")
+    parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a) {")
+    parts.append("    pc::tail_begin(a);")
+    for pm in model.phases:
+        parts.append(f"    pc::tail_phase<Phase{pm.index}>(a, {pm.index});")
+    parts.append("    pc::tail_point<Point>(a);")
+    parts.append("  }")
+    parts.append("};")
+    parts.append("}  // namespace gen\n")
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{pm.index}(PcPhaseArgs a) '
                      f'{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a); }}')
+    last = model.phases[-1].index
+    parts.append("// last phase with the tail folded in: the last workgroup to arrive finishes the evaluation")
+    parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{last}_f(PcPhaseArgs a, PcTailArgs t) '
+                 f'{{ pc::bulk<gen::Phase{last}, {int(orders[last])}, gen::Tail>(a, &t); }}')
     parts.append("")
-    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) {')
-    parts.append("  pc::tail_begin(a);")
-    for pm in model.phases:
-        parts.append(f"  pc::tail_phase<gen::Phase{pm.index}>(a, {pm.index});")
-    parts.append("  pc::tail_point<gen::Point>(a);")
-    parts.append("}")
+    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run(a); }')
     parts.append("")
     return "\n".join(parts)
 

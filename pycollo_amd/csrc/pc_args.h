@@ -35,6 +35,7 @@ struct PcPhaseArgs {
   const int64_t* hslotN;  // [NHZZ] slots of the node block at node N-1
   double* partials;       // [n_tiles][NRED] per-tile partial sums
   long long* dbg;         // diagnostic builds only: [n_tiles][16] s_memtime stamps (dbg_stage == 9)
+  unsigned* sync;         // fused tail: [(PC_SYNC_SHARDS + 1) * 16] arrival counters, all zero between launches
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
   int64_t c_off, c_path_off, c_int_off;
   double t_fixed[2];
@@ -55,7 +56,8 @@ struct PcPhaseArgs {
   int64_t hoff[PC_MAX_HOFF];  // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
 };
 
-#define PC_MAX_PHASES 16
+#define PC_MAX_PHASES 8
+#define PC_SYNC_SHARDS 64   // arrival counters of the fused tail, one 64-B line each, plus the top counter
 
 struct PcTailPhase {
   const double* partials;  // [n_tiles][NRED]

@@ -118,6 +118,7 @@ struct PhaseDev {
   DevBuf<long long> dbg;
   int uni_n = 0, spt = 0, lds_out = 0;
   hipFunction_t fn = nullptr;
+  hipFunction_t fn_fused = nullptr;  // last phase only: bulk kernel with the tail folded in
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
   int tile_begin = 0, tile_end = 0;  // launched tile range (whole phase unless sharded)
   double* partials_ext = nullptr;    // caller-owned partial-sum buffer (sharded exchange), else `partials`
@@ -154,6 +155,9 @@ struct pc_handle {
   std::vector<std::unique_ptr<PhaseDev>> pd;
   DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
+  DevBuf<unsigned> d_sync;   // arrival counters of the fused tail (zero between launches)
+  bool allow_fuse = false;   // PYCOLLO_AMD_FUSE=1 folds the tail into the last bulk launch (experimental:
+                             // measured no faster than two launches on MI355X)
   PinBuf<double> h_x, h_lam, h_c, h_G, h_H, h_fobj, h_grad, h_norms;
   std::vector<double> V_ocp, r_ocp, W_ocp;
   // cache for new_x == 0
@@ -166,62 +170,9 @@ struct pc_handle {
 
 namespace {
 
-void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
-                double* d_fobj, double* d_grad, int flags, hipStream_t st, double sigma, bool bulk = true,
-                bool tail = true) {
+void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double* d_lam, double* d_c, double* d_G,
+                    double* d_H, double* d_fobj, double* d_grad, int flags, double sigma) {
   auto& Q = h->Q;
-  for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
-    auto& P = Q.ph[ip];
-    auto& D = *h->pd[ip];
-    PcPhaseArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.x = d_x;
-    a.lam = d_lam;
-    a.c = d_c;
-    a.G = d_G;
-    a.H = d_H;
-    a.tile_k0 = D.tile_k0.p;
-    a.tile_n0 = D.tile_n0.p;
-    a.sec_s = D.sec_s.p;
-    a.sec_h = D.sec_h.p;
-    a.sec_E = D.sec_E.p;
-    a.qa = h->d_qa.p;
-    a.qw = h->d_qw.p;
-    if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
-    for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
-    for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
-    for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
-    a.uni_n = D.uni_n;
-    a.spt = D.spt;
-    a.lds_out = D.lds_out;
-    a.dbg_stage = h->dbg_stage;
-    a.hslot0 = D.hslot0.p;
-    a.hslotN = D.hslotN.p;
-    a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
-    a.dbg = D.dbg.p;
-    a.x_off = P.x_off;
-    a.s_off = Q.s_off;
-    a.c_off = P.c_off;
-    a.c_path_off = P.c_path_off;
-    a.c_int_off = P.c_int_off;
-    a.t_fixed[0] = P.t_fixed[0];
-    a.t_fixed[1] = P.t_fixed[1];
-    a.N = P.N;
-    a.K = P.K;
-    a.n_tiles = D.n_tiles;
-    a.flags = flags;
-    a.tile_begin = D.tile_begin;
-    a.qa_total = (int32_t)h->qa.size();
-    a.qw_total = (int32_t)h->qw.size();
-    std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
-    std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
-    size_t sz = sizeof(a);
-    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    if (D.tile_end > D.tile_begin)
-      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
-  }
-  if (!tail) return;
-  PcTailArgs t;
   std::memset(&t, 0, sizeof(t));
   t.x = d_x;
   t.lam = d_lam;
@@ -258,6 +209,85 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     tp.n_tiles = D.n_tiles;
     tp.N = P.N;
   }
+}
+
+void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
+                double* d_fobj, double* d_grad, int flags, hipStream_t st, double sigma, bool bulk = true,
+                bool tail = true) {
+  auto& Q = h->Q;
+  const size_t last = Q.ph.size() - 1;
+  // one launch per evaluation when the last phase runs whole: its last workgroup to arrive runs the tail
+  bool fuse = false;
+  if (bulk && tail && h->allow_fuse && (h->dbg_stage == 0 || h->dbg_stage == 9)) {
+    auto& D = *h->pd[last];
+    fuse = D.fn_fused && D.tile_begin == 0 && D.tile_end == D.n_tiles && D.n_tiles <= 8192;
+  }
+  struct Both {
+    PcPhaseArgs a;
+    PcTailArgs t;
+  };
+  for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
+    auto& P = Q.ph[ip];
+    auto& D = *h->pd[ip];
+    Both both;
+    PcPhaseArgs& a = both.a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = d_x;
+    a.lam = d_lam;
+    a.c = d_c;
+    a.G = d_G;
+    a.H = d_H;
+    a.tile_k0 = D.tile_k0.p;
+    a.tile_n0 = D.tile_n0.p;
+    a.sec_s = D.sec_s.p;
+    a.sec_h = D.sec_h.p;
+    a.sec_E = D.sec_E.p;
+    a.qa = h->d_qa.p;
+    a.qw = h->d_qw.p;
+    if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
+    for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
+    for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
+    for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
+    a.uni_n = D.uni_n;
+    a.spt = D.spt;
+    a.lds_out = D.lds_out;
+    a.dbg_stage = h->dbg_stage;
+    a.hslot0 = D.hslot0.p;
+    a.hslotN = D.hslotN.p;
+    a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
+    a.dbg = D.dbg.p;
+    a.sync = h->d_sync.p;
+    a.x_off = P.x_off;
+    a.s_off = Q.s_off;
+    a.c_off = P.c_off;
+    a.c_path_off = P.c_path_off;
+    a.c_int_off = P.c_int_off;
+    a.t_fixed[0] = P.t_fixed[0];
+    a.t_fixed[1] = P.t_fixed[1];
+    a.N = P.N;
+    a.K = P.K;
+    a.n_tiles = D.n_tiles;
+    a.flags = flags;
+    a.tile_begin = D.tile_begin;
+    a.qa_total = (int32_t)h->qa.size();
+    a.qw_total = (int32_t)h->qw.size();
+    std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
+    std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
+    if (D.tile_end <= D.tile_begin) continue;
+    if (fuse && ip == last) {
+      fill_tail_args(h, both.t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
+      size_t sz = sizeof(both);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      HIP_OK(hipModuleLaunchKernel(D.fn_fused, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
+    } else {
+      size_t sz = sizeof(a);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
+    }
+  }
+  if (!tail || fuse) return;
+  PcTailArgs t;
+  fill_tail_args(h, t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
   size_t sz = sizeof(t);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
@@ -340,7 +370,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
   std::unique_ptr<pc_handle> h;
   const int ok = guarded([&] {
     if (!d || !out) throw std::runtime_error("null descriptor or output pointer");
-    if (d->n_phases < 1 || d->n_phases > PC_MAX_PHASES) throw std::runtime_error("n_phases must be in [1, 16]");
+    if (d->n_phases < 1 || d->n_phases > PC_MAX_PHASES) throw std::runtime_error("n_phases must be in [1, 8]");
     h.reset(new pc_handle());
     auto& Q = h->Q;
     Q.n_s = d->n_s;
@@ -452,7 +482,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if ((int)P.goff.size() > PC_MAX_GOFF || (int)P.hoff.size() > PC_MAX_HOFF)
         throw std::runtime_error("too many variables/constraints per phase for the kernel argument block");
     }
-    h->n_launches = (int)Q.ph.size() + 1;
+    h->n_launches = (int)Q.ph.size() + 1;   // refined after the module is loaded (fused tail: one fewer)
     if (h->device < 0) return;  // structure-only handle
 
     // ---- device side ----------------------------------------------------------------------------
@@ -470,6 +500,10 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       auto& P = Q.ph[ip];
       auto& D = *h->pd[ip];
       HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
+      if (ip + 1 == Q.ph.size()) {
+        if (hipModuleGetFunction(&D.fn_fused, h->module, (P.bulk_kernel + "_f").c_str()) != hipSuccess)
+          D.fn_fused = nullptr;   // code object without the fused variant: two launches per evaluation
+      }
       D.tile_k0.upload(P.tile_k0);
       {
         std::vector<int32_t> tn(P.tile_k0.size());
@@ -485,6 +519,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
       if (h->dbg_stage == 9) D.dbg.alloc((size_t)16 * D.n_tiles);
     }
+    h->d_sync.upload(std::vector<unsigned>((PC_SYNC_SHARDS + 1) * 16, 0u));
+    if (const char* env = std::getenv("PYCOLLO_AMD_FUSE")) h->allow_fuse = std::atoi(env) != 0;
     h->d_point_x.upload(Q.point_x);
     h->d_tail_owned.upload(Q.tail_owned);
     h->d_pt_hslot.upload(Q.pt_hslot);
@@ -497,6 +533,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_fobj.alloc(1);
     h->h_grad.alloc(Q.num_x); h->h_norms.alloc(Q.num_c);
     HIP_OK(hipMemset(h->d_lam.p, 0, Q.num_c * sizeof(double)));
+    if (h->allow_fuse && h->pd.back()->fn_fused && h->pd.back()->n_tiles <= 8192) h->n_launches = (int)Q.ph.size();
   });
   if (!ok) return 0;
   *out = h.release();

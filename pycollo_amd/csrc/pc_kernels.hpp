@@ -226,6 +226,7 @@ struct BulkIn {
   const double* x; const double* lam; double* c; double* G; double* H;
   const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
   const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials; long long* dbg;
+  unsigned* sync;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
   int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage;
@@ -251,8 +252,24 @@ __device__ __forceinline__ void pin_array(const T (&a)[N]) {
 // UN > 0: the phase's mesh has UN nodes in every section and the kernel is compiled for exactly that
 // order (loops over section rows / nodes unroll, their LDS reads issue back to back, index arithmetic
 // divides by constants).  UN == 0: any mesh (orders may differ section by section).
-template <class M, int UN>
-__device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
+// Agent-scope relaxed store: `global_store ... sc1` (write-through).  Used for the few words another
+// workgroup of the same launch reads (fused tail): per-tile partial sums and the Hessian entries of the
+// edge nodes 0 / N-1 that the endpoint block accumulates into.
+__device__ __forceinline__ void store_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// TAIL = void: the per-phase bulk kernel; a separate `pc_tail` launch finishes the evaluation.
+// TAIL = generated struct with `static void run(const PcTailArgs&)`: the last workgroup to finish runs the
+// tail inside this launch (one launch per evaluation).  Protocol (cdna_hip_programming.md G16, fan-in
+// row): payload stored sc1 -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane adds to an
+// arrival counter (two levels: PC_SYNC_SHARDS shards, then a top counter, so that tens of thousands of
+// workgroups do not serialise on one word); the workgroup whose add completes the count issues ONE
+// agent-scope acquire and then reads with vector loads.  Counters reset themselves for the next launch.
+template <class M, int UN, class TAIL = void>
+__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr) {
+  constexpr bool FUSED = !std::is_void<TAIL>::value;
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
@@ -260,6 +277,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
   A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
   A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; A.sec_h = KA.sec_h; A.sec_E = KA.sec_E;
   A.qa = KA.qa; A.qw = KA.qw; A.hslot0 = KA.hslot0; A.hslotN = KA.hslotN; A.partials = KA.partials; A.dbg = KA.dbg;
+  A.sync = KA.sync;
   A.x_off = KA.x_off; A.s_off = KA.s_off; A.c_off = KA.c_off; A.c_path_off = KA.c_path_off; A.c_int_off = KA.c_int_off;
   A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
   A.N = KA.N; A.K = KA.K; A.flags = KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
@@ -269,7 +287,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
   PC_PIN(A.x); PC_PIN(A.lam); PC_PIN(A.c); PC_PIN(A.G); PC_PIN(A.H); PC_PIN(A.tile_k0); PC_PIN(A.tile_n0);
   PC_PIN(A.sec_s); PC_PIN(A.sec_h); PC_PIN(A.sec_E); PC_PIN(A.qa); PC_PIN(A.qw); PC_PIN(A.hslot0); PC_PIN(A.hslotN);
-  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
+  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
   PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
   PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
   PC_PIN(A.dbg_stage);
@@ -596,7 +614,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
           static_for<0, NH>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr (M::hr(e) == rv)
-              A.H[(edge0 ? A.hslot0 : A.hslotN)[St::hzz_index(e)]] = vals[St::hpos(e)];
+              {
+                double* dstp = A.H + (edge0 ? A.hslot0 : A.hslotN)[St::hzz_index(e)];
+                if constexpr (FUSED) store_agent(dstp, vals[St::hpos(e)]); else *dstp = vals[St::hpos(e)];
+              }
           });
         }
         if constexpr (MB == 1) {
@@ -617,7 +638,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
         constexpr int e = decltype(e_)::value;
         constexpr int rv = M::hr(e), cv = M::hc(e);
         if constexpr (rv >= NZ && cv < NZ) {
-          A.H[A.hoff[St::HO_S + (rv - NZ) * NZ + cv] + node] = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
+          {
+            double* dstp = A.H + A.hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
+            const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
+            if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
+          }
         } else if constexpr (rv >= NZ) {
           constexpr int l = rv - NZ, l2 = cv - NZ;
           red[St::R_SS + l * (l + 1) / 2 + l2] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
@@ -636,7 +661,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
             if constexpr (cvar < NZ) {
               static_for<0, NT>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
-                A.H[A.hoff[St::HO_T + j * NZ + cvar] + node] = dst[j] * sc[St::O_VZ + cvar] * acc;
+                double* dstp = A.H + A.hoff[St::HO_T + j * NZ + cvar] + node;
+                const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
+                if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
               });
             } else {
               red[St::R_TS + cvar - NZ] = acc;
@@ -647,6 +674,53 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
     }
   }
 
+  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile) and, in the fused build, the arrival:
+  //      everything the tail consumes (partials, edge Hessian entries) is out before the bulky c~/G~ runs,
+  //      so the store drain below waits for a handful of stores only
+  bool is_last = false;
+  if constexpr (NRED > 0) {
+    const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
+    static_for<0, NRED>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      const double s = wave_sum(red[r]);
+      if (lane == 0) s_red[r * 16 + wave] = s;
+    });
+    lds_barrier();
+    if (tid < NRED) {
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
+      if constexpr (FUSED) store_agent(A.partials + (int64_t)tile * NRED + tid, s);
+      else A.partials[(int64_t)tile * NRED + tid] = s;
+    }
+  }
+  if constexpr (FUSED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (payload is sc1)
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+      const unsigned nblk = gridDim.x;
+      const unsigned nsh = nblk < PC_SYNC_SHARDS ? nblk : PC_SYNC_SHARDS;
+      const unsigned sh = blockIdx.x % nsh;
+      const unsigned members = nblk / nsh + (sh < nblk % nsh ? 1u : 0u);
+      unsigned* cnt = A.sync + 16 * sh;
+      unsigned* top = A.sync + 16 * PC_SYNC_SHARDS;
+      int last = 0;
+      if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1) {
+          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = 1;
+        }
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    is_last = s_last != 0;
+    STAMP(9);
+    if (is_last) {   // ONE acquire; its latency overlaps this workgroup's own c~/G~ work below
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
   STAMP(5);
   if (A.dbg_stage == 4) return;
   // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
@@ -743,22 +817,19 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA) {
 
   STAMP(7);
   if (A.dbg_stage == 6) return;
-  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile) ------------------------------
-  if constexpr (NRED > 0) {
-    const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
-    static_for<0, NRED>([&](auto r_) {
-      constexpr int r = decltype(r_)::value;
-      const double s = wave_sum(red[r]);
-      if (lane == 0) s_red[r * 16 + wave] = s;
-    });
-    lds_barrier();
-    if (tid < NRED) {
-      double s = 0.0;
-      for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
-      A.partials[(int64_t)tile * NRED + tid] = s;
+  if constexpr (FUSED) {
+    if (is_last) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
   }
   STAMP(8);
+  if constexpr (FUSED) {
+    if (is_last) {
+      TAIL::run(*TA);
+      STAMP(10);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -779,7 +850,7 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
     __shared__ double s_part[NRED * 4];
     __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = blockDim.x;  // TB == 256: 4 waves
+    const int tid = threadIdx.x, TB = blockDim.x;  // 1 to 4 waves (64 .. 256 threads)
     double acc[NRED];
     static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
     for (int b = tid; b < P.n_tiles; b += TB)
@@ -790,7 +861,12 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
       if ((tid & 63) == 0) s_part[r * 4 + (tid >> 6)] = w;
     });
     __syncthreads();
-    if (tid < NRED) s_sum[tid] = ((s_part[tid * 4] + s_part[tid * 4 + 1]) + s_part[tid * 4 + 2]) + s_part[tid * 4 + 3];
+    if (tid < NRED) {
+      const int nw = (TB + 63) >> 6;
+      double tot = s_part[tid * 4];
+      for (int w = 1; w < nw; ++w) tot += s_part[tid * 4 + w];
+      s_sum[tid] = tot;
+    }
     __syncthreads();
     if (tid == 0) {
       const double* sc = P.scal;

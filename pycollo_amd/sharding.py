@@ -138,7 +138,13 @@ class SegmentExchange:
         n = self.idx_me.numel()
         if n:
             torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU cannot form an RCCL group): stage through the host
+            recv = torch.empty(self.recv.shape, dtype=self.recv.dtype)
+            dist.all_gather_into_tensor(recv, self.send.cpu(), group=self.group)
+            self.recv.copy_(recv)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         if self.unpack_dst.numel():
             buf.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
         return buf
