@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--problem", default="hypersensitive")
     ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="use the any-mesh kernels (no order specialisation)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N > 1 on one GPU")
     ap.add_argument("--check", action="store_true", help="N > 1: compare the sharded result with an unsharded one")
     args = ap.parse_args()
@@ -85,7 +86,7 @@ def main():
     assert stream != 0
 
     if world == 1:
-        eng = NlpEngine(prob, device=local_rank, threads_per_block=args.tpb)
+        eng = NlpEngine(prob, device=local_rank, threads_per_block=args.tpb, specialise=not args.generic)
         rng = np.random.default_rng(1234)
         x = torch.from_numpy(rng.uniform(-0.45, 0.45, eng.num_x)).to(dev)
         lam = torch.from_numpy(np.random.default_rng(1235).normal(size=eng.num_c)).to(dev)

@@ -152,6 +152,11 @@ int pc_synchronize(pc_handle* h);
  * (pycollo/scaling.py:392-395) without densifying G; evaluates G at x with the current scaling */
 int pc_row_norms_jac(pc_handle* h, const double* x, double* norms);
 
+/* replaces: interpolate_to_new_mesh (pycollo/iteration.py:96-137, scipy interp1d linear + extrapolate): carries
+ * the rows of vals_prev[n_vars][n_prev] from the mesh tau_prev to tau_new.  Host pointers in and out. */
+int pc_interp_linear(int device, const double* tau_prev, int n_prev, const double* vals_prev, int n_vars,
+                     const double* tau_new, int n_new, double* out);
+
 /* timing of the last n pc_eval_all_device launches is measured by the caller with HIP events on the
  * stream it passed; this returns the stream the handle owns (hipStream_t) */
 void* pc_stream(pc_handle* h);

@@ -137,6 +137,30 @@ __global__ void row_norms_kernel(const int64_t* __restrict__ indptr, const doubl
   if (lane == 0) out[wave] = sqrt(acc);
 }
 
+// generic kernel: piecewise-linear interpolation of every row of vals_prev[n_vars][n_prev] from the
+// abscissae tau_prev onto tau_new, extrapolating with the end segments -- the arithmetic of
+// scipy.interpolate.interp1d(kind="linear", fill_value="extrapolate") that the reference uses to carry a
+// guess / solution to the next mesh (pycollo/iteration.py:96-137): slope * (x - x_lo) + y_lo.
+__global__ void interp_linear_kernel(const double* __restrict__ tau_prev, int n_prev, const double* __restrict__ vals_prev,
+                                     int n_vars, const double* __restrict__ tau_new, int n_new, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const double x = tau_new[i];
+  // searchsorted(tau_prev, x, side="left") clipped to [1, n_prev-1]
+  int lo = 0, hi = n_prev;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tau_prev[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int idx = lo < 1 ? 1 : (lo > n_prev - 1 ? n_prev - 1 : lo);
+  const double x_lo = tau_prev[idx - 1], x_hi = tau_prev[idx];
+  for (int v = 0; v < n_vars; ++v) {
+    const double y_lo = vals_prev[(size_t)v * n_prev + idx - 1], y_hi = vals_prev[(size_t)v * n_prev + idx];
+    const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+    out[(size_t)v * n_new + i] = slope * (x - x_lo) + y_lo;
+  }
+}
+
 }  // namespace
 
 struct pc_handle {
@@ -814,6 +838,26 @@ int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles) {
     if (!D.dbg.p) throw std::runtime_error("no stamps: create the handle with PYCOLLO_AMD_DBG_STAGE=9");
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out, D.dbg.p, sizeof(long long) * 16 * std::min(n_tiles, D.n_tiles), hipMemcpyDeviceToHost));
+  });
+}
+
+int pc_interp_linear(int device, const double* tau_prev, int n_prev, const double* vals_prev, int n_vars,
+                     const double* tau_new, int n_new, double* out) {
+  return guarded([&] {
+    if (n_prev < 2 || n_new < 1 || n_vars < 0) throw std::runtime_error("interpolation needs at least two abscissae");
+    int ndev = 0;
+    if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device)
+      throw std::runtime_error("requested HIP device is not available (no GPU visible?); this library has no CPU fallback");
+    HIP_OK(hipSetDevice(device));
+    DevBuf<double> d_tp, d_vp, d_tn, d_out;
+    d_tp.upload(std::vector<double>(tau_prev, tau_prev + n_prev));
+    d_vp.upload(std::vector<double>(vals_prev, vals_prev + (size_t)n_vars * n_prev));
+    d_tn.upload(std::vector<double>(tau_new, tau_new + n_new));
+    d_out.alloc((size_t)std::max(1, n_vars) * n_new);
+    hipLaunchKernelGGL(interp_linear_kernel, dim3((n_new + 255) / 256), dim3(256), 0, 0, d_tp.p, n_prev, d_vp.p, n_vars,
+                       d_tn.p, n_new, d_out.p);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_vars * n_new, hipMemcpyDeviceToHost));
   });
 }
 

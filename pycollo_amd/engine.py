@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
     lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
+    lib.pc_interp_linear.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     lib.pc_stream.argtypes = [vp]
     lib.pc_stream.restype = vp
     _lib = lib
@@ -118,6 +119,23 @@ def _i32(a):
 
 def _ptr(a, typ):
     return a.ctypes.data_as(typ) if a.size else C.cast(None, typ)
+
+
+def interp_linear(tau_prev, vals_prev, tau_new, device: int = 0) -> np.ndarray:
+    """Rows of ``vals_prev`` carried from ``tau_prev`` to ``tau_new`` on the GPU (pycollo/iteration.py:96-137)."""
+    lib = load_library()
+    tp = np.ascontiguousarray(tau_prev, dtype=np.float64)
+    vp_ = np.ascontiguousarray(np.atleast_2d(vals_prev), dtype=np.float64)
+    tn = np.ascontiguousarray(tau_new, dtype=np.float64)
+    if vp_.shape[1] != tp.shape[0]:
+        raise ValueError("vals_prev must have one column per previous abscissa")
+    out = np.empty((vp_.shape[0], tn.shape[0]))
+    if vp_.shape[0] == 0:
+        return out
+    if not lib.pc_interp_linear(int(device), tp.ctypes.data, tp.shape[0], vp_.ctypes.data, vp_.shape[0], tn.ctypes.data,
+                                tn.shape[0], out.ctypes.data):
+        raise RuntimeError(lib.pc_last_error().decode())
+    return out
 
 
 class NlpEngine:

@@ -1,0 +1,136 @@
+"""One mesh iteration: everything between a problem description and a ready-to-solve NLP.
+
+SURVEY.md section 8f row N1 -- the direct caller of the hot path.  Restates ``Iteration.initialise``
+(pycollo/iteration.py:69-79): interpolate the guess to the mesh (:86-194), lay out variables and
+constraints (:196-342, done by ``NlpLayout``), scale the guess (:360-373, pycollo/scaling.py:172-174),
+generate the NLP callbacks + objective / constraint scaling (:375-394, scaling.py:271-281) and the scaled
+bounds (:396-453).  The O(N) pieces run on the GPU: guess interpolation (``pc_interp_linear``), the
+Jacobian row norms behind the constraint scaling (``pc_row_norms_jac``); the reference does the first with
+one scipy ``interp1d`` per variable and the second on a dense ``num_c x num_x`` array (scaling.py:394).
+
+``solve_with_scipy`` drives the callbacks with ``scipy.optimize.minimize(method="trust-constr")`` -- a
+stand-in for IPOPT (not installed here) that lets the reference's converged-objective known
+answers act as end-to-end checks on small meshes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import NlpEngine, interp_linear
+from .mesh import build_phase_mesh
+from .model import compile_model
+from .quadrature import QuadratureTables
+from .scaling import constraint_scaling, objective_scaling
+
+
+class MeshIteration:
+    def __init__(self, problem, *, device: int = 0, meshes=None, prev=None, threads_per_block: int = 0):
+        """``prev`` = (tau per phase, y per phase, u per phase, q per phase, t per phase, s) in *unscaled*
+        variables -- the previous iteration's solution; default: the problem's user guess."""
+        self.problem = problem
+        self.model = compile_model(problem)
+        self.quad = QuadratureTables(self.model.quadrature_method)
+        self.meshes = meshes or [build_phase_mesh(self.quad, *ph.mesh.resolved()) for ph in problem.phases]
+        self.device = device
+        self.engine = NlpEngine(problem, self.meshes, device=device, threads_per_block=threads_per_block)
+        self.layout = self.engine.layout
+        self.guess_x = self._interpolate_guess(prev if prev is not None else self._user_guess())
+        V, r = self.layout.base_variable_scaling()
+        self.V, self.r = self.layout.expand_x(V), self.layout.expand_x(r)
+        self.guess_x_tilde = (self.guess_x - self.r) / self.V                    # scaling.py:172-174
+        # first-iteration scaling: w = 1, W from the Jacobian row norms at the guess (scaling.py:271-275)
+        self.w = 1.0
+        self.W_ocp = constraint_scaling(self.engine, self.guess_x_tilde)
+        self.engine.set_scaling(V, r, self.W_ocp, self.w)
+        self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u = self._bounds()
+
+    # ---- guess ------------------------------------------------------------------------------------
+    def _user_guess(self):
+        from . import problem as pb
+        taus, ys, us, qs, ts = [], [], [], [], []
+        for ph, pm in zip(self.problem.phases, self.model.phases):
+            g = ph.guess
+            if g.time is None:
+                raise ValueError(f"phase {ph.name}: a guess is required")
+            time = np.asarray(g.time, dtype=np.float64)
+            t0, tF = time[0], time[-1]
+            tau = (time - 0.5 * (t0 + tF)) / (0.5 * (tF - t0))                   # guess.py:165-170
+            y_b, u_b, q_b = pb.phase_variable_bounds(ph)
+            t_b = pb.phase_time_bounds(ph)
+            yk, uk, qk, tk = pb.needed(y_b), pb.needed(u_b), pb.needed(q_b), pb.needed(list(t_b))
+            y = np.asarray(g.state_variables, dtype=np.float64).reshape(len(ph._y), -1)[yk]
+            u = np.asarray(g.control_variables if g.control_variables is not None else np.empty((0, len(time))),
+                           dtype=np.float64).reshape(len(ph._u), -1)[uk]
+            q = np.asarray(g.integral_variables if g.integral_variables is not None else [], dtype=np.float64).reshape(-1)[qk]
+            taus.append(tau); ys.append(y); us.append(u); qs.append(q)
+            ts.append(np.array([t0, tF])[tk])
+        pg = self.problem.guess.parameter_variables
+        s_b = pb._bounds_for(list(self.problem.parameter_variables), self.problem.bounds.parameter_variables, "parameter")
+        s = np.asarray(pg if pg is not None else [], dtype=np.float64).reshape(-1)[pb.needed(s_b)] if s_b else np.zeros(0)
+        return taus, ys, us, qs, ts, s
+
+    def _interpolate_guess(self, prev):
+        taus, ys, us, qs, ts, s = prev
+        parts = []
+        for tau_prev, y, u, q, t, mesh in zip(taus, ys, us, qs, ts, self.meshes):
+            zu = np.vstack([y, u]) if (len(y) + len(u)) else np.empty((0, len(tau_prev)))
+            parts.append(interp_linear(tau_prev, zu, mesh.tau, self.device).reshape(-1))
+            parts.append(np.asarray(q, dtype=float).reshape(-1))
+            parts.append(np.asarray(t, dtype=float).reshape(-1))
+        parts.append(np.asarray(s, dtype=float).reshape(-1))
+        x = np.concatenate(parts)
+        if x.shape[0] != self.layout.num_x:
+            raise ValueError("guess does not match the variable layout")
+        return x
+
+    # ---- bounds (iteration.py:408-453) -----------------------------------------------------------------
+    def _bounds(self):
+        xb = []
+        cb = []
+        for pm, pl in zip(self.model.phases, self.layout.phases):
+            N = pl.N
+            yb = pm.x_bounds[:pm.n_y]
+            for b, b0, bF in zip(yb, pm.y_t0_bounds, pm.y_tF_bounds):
+                xb.extend([b0] + [b] * (N - 2) + [bF])
+            for b in pm.x_bounds[pm.n_y:pm.n_z]:
+                xb.extend([b] * N)
+            xb.extend(pm.x_bounds[pm.n_z:])
+            cb.extend([(0.0, 0.0)] * (pm.n_y * (N - 1)))
+            for b in pm.p_bounds:
+                cb.extend([b] * N)
+            cb.extend([(0.0, 0.0)] * pm.n_q)
+        xb.extend(self.model.s_bounds)
+        cb.extend(self.model.point.b_bounds)
+        xb = np.asarray(xb, dtype=np.float64).reshape(-1, 2)
+        cb = np.asarray(cb, dtype=np.float64).reshape(-1, 2)
+        W = self.layout.expand_c(self.W_ocp)
+        return ((xb[:, 0] - self.r) / self.V, (xb[:, 1] - self.r) / self.V, W * cb[:, 0], W * cb[:, 1])
+
+    # ---- solve -------------------------------------------------------------------------------------
+    def solve_with_scipy(self, maxiter: int = 500, tol: float = 1e-9, verbose: int = 0):
+        """Solve the scaled NLP with scipy's trust-region interior point method (stand-in for IPOPT)."""
+        import scipy.sparse as sp
+        from scipy.optimize import Bounds, NonlinearConstraint, minimize
+        e = self.engine
+        gr, gc = e.evaluate_G_structure()
+        hr, hc = e.evaluate_H_structure()
+        n, m = e.num_x, e.num_c
+        lo = hr != hc
+
+        def sym(vals):
+            H = sp.coo_matrix((vals, (hr, hc)), shape=(n, n))
+            return (H + sp.coo_matrix((vals[lo], (hc[lo], hr[lo])), shape=(n, n))).tocsr()
+
+        zero_lam = np.zeros(m)
+        con = NonlinearConstraint(lambda x: e.evaluate_c(x), self.c_bnd_l, self.c_bnd_u,
+                                  jac=lambda x: sp.csr_matrix((e.evaluate_G_nonzeros(x), (gr, gc)), shape=(m, n)),
+                                  hess=lambda x, v: sym(e.evaluate_H_nonzeros(x, 0.0, v)))
+        res = minimize(e.evaluate_J, self.guess_x_tilde, jac=e.evaluate_g,
+                       hess=lambda x: sym(e.evaluate_H_nonzeros(x, 1.0, zero_lam)),
+                       method="trust-constr", constraints=[con],
+                       bounds=Bounds(self.x_bnd_l, self.x_bnd_u, keep_feasible=False),
+                       options={"maxiter": maxiter, "gtol": tol, "xtol": 1e-12, "verbose": verbose})
+        self.result = res
+        self.x_tilde = res.x
+        self.objective = res.fun / self.w                                       # scaling.py:186-189
+        return res

@@ -69,6 +69,21 @@ class PhaseBounds:
         self.final_state_constraints = None
 
 
+class PhaseGuess:
+    """User guess of one phase (pycollo/guess.py:80-107): values at the time points ``time``."""
+
+    def __init__(self):
+        self.time = None
+        self.state_variables = None
+        self.control_variables = None
+        self.integral_variables = None
+
+
+class EndpointGuess:
+    def __init__(self):
+        self.parameter_variables = None
+
+
 class PhaseMeshSpec:
     """User mesh description (pycollo/mesh.py:10-107): K, section fractions, nodes per section."""
 
@@ -107,6 +122,7 @@ class Phase:
         self._q_fnc: list[sym.Expr] = []
         self.auxiliary_data: dict = {}
         self.bounds = PhaseBounds()
+        self.guess = PhaseGuess()
         self.mesh = PhaseMeshSpec()
         self.initial_state_variables: tuple = ()
         self.final_state_variables: tuple = ()
@@ -170,6 +186,7 @@ class ProblemSpec:
         self.endpoint_constraints: list[sym.Expr] = []
         self.auxiliary_data: dict = {}
         self.bounds = EndpointBounds()
+        self.guess = EndpointGuess()
         self.scaling_method: str | None = "bounds"
         self.quadrature_method: str = "lobatto"
 

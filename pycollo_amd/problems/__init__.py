@@ -34,6 +34,9 @@ def brachistochrone(K: int = 10, order: int = 4) -> ProblemSpec:
     ph.bounds.control_variables = [[-np.pi / 2, np.pi / 2]]
     ph.bounds.initial_state_constraints = {x: 0, y: 0, v: 0}
     ph.bounds.final_state_constraints = {x: 2, y: 2}
+    ph.guess.time = np.array([0.0, 10.0])
+    ph.guess.state_variables = np.array([[0.0, 2.0], [0.0, 2.0], [0.0, 0.0]])
+    ph.guess.control_variables = np.array([[0.0, np.pi / 2]])
     _mesh(ph, K, order)
     return prob
 
@@ -61,6 +64,10 @@ def hypersensitive(K: int = 10, order: int = 4, *, test_fixture_bounds: bool = F
         ph.bounds.integral_variables = [[0, 100000]]
     ph.bounds.initial_state_constraints = [[1.0, 1.0]]
     ph.bounds.final_state_constraints = [[1.5, 1.5]]
+    ph.guess.time = np.array([0.0, 10000.0])
+    ph.guess.state_variables = np.array([[1.0, 1.5]])
+    ph.guess.control_variables = np.array([[0.0, 0.0]])
+    ph.guess.integral_variables = np.array([4.0])
     _mesh(ph, K, order)
     return prob
 
@@ -82,6 +89,10 @@ def cart_pole(K: int = 10, order: int = 4) -> ProblemSpec:
     ph.bounds.integral_variables = [[0, 100]]
     ph.bounds.initial_state_constraints = {q1: 0, q2: 0, q1d: 0, q2d: 0}
     ph.bounds.final_state_constraints = {q1: 1.0, q2: np.pi, q1d: 0, q2d: 0}
+    ph.guess.time = np.array([0.0, 2.0])
+    ph.guess.state_variables = np.array([[0.0, 1.0], [0.0, np.pi], [0.0, 0.0], [0.0, 0.0]])
+    ph.guess.control_variables = np.array([[0.0, 0.0]])
+    ph.guess.integral_variables = np.array([0.0])
     s2, c2 = sym.sin(q2), sym.cos(q2)
     prob.objective_function = ph.integral_variables[0]
     prob.auxiliary_data = {
@@ -134,6 +145,10 @@ def shuttle(K: int = 10, order: int = 4) -> ProblemSpec:
     ph.bounds.control_variables = {alpha: [-np.pi / 2, np.pi / 2], beta: [-np.pi / 2, deg]}
     ph.bounds.initial_state_constraints = {h: 79248, phi: 0, theta: 0, nu: 7802.88, gamma: -1 * deg, psi: 90 * deg}
     ph.bounds.final_state_constraints = {h: [24384, 24384], nu: [762, 762], gamma: [-5 * deg, -5 * deg]}
+    ph.guess.time = np.array([0.0, 1000.0])
+    ph.guess.state_variables = np.array([[79248, 24384], [0, 10 * deg], [0, 10 * deg], [7802.88, 762],
+                                         [-1 * deg, -5 * deg], [90 * deg, -90 * deg]], dtype=float)
+    ph.guess.control_variables = np.array([[0.0, 0.0], [0.0, 0.0]])
     _mesh(ph, K, order)
     return prob
 
@@ -265,6 +280,11 @@ def double_pendulum(K: int = 10, order: int = 4) -> ProblemSpec:
     ph.bounds.initial_state_constraints = [[-0.5 * np.pi] * 2, [-0.5 * np.pi] * 2, [0, 0], [0, 0]]
     ph.bounds.final_state_constraints = [[0.5 * np.pi] * 2, [0.5 * np.pi] * 2, [0, 0], [0, 0]]
     prob.bounds.parameter_variables = [[0.5, 1.5], [0.5, 1.5]]
+    ph.guess.time = np.array([0.0, 2.0])
+    ph.guess.state_variables = np.array([[-0.5 * np.pi, 0.5 * np.pi], [-0.5 * np.pi, 0.5 * np.pi], [0, 0], [0, 0]], dtype=float)
+    ph.guess.control_variables = np.array([[0.0, 0.0], [0.0, 0.0]])
+    ph.guess.integral_variables = np.array([100.0])
+    prob.guess.parameter_variables = np.array([1.0, 1.0])
     _mesh(ph, K, order)
     return prob
 
