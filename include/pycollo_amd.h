@@ -157,6 +157,15 @@ int pc_row_norms_jac(pc_handle* h, const double* x, double* norms);
 int pc_interp_linear(int device, const double* tau_prev, int n_prev, const double* vals_prev, int n_vars,
                      const double* tau_new, int n_new, double* out);
 
+/* replaces: PattersonRaoMeshRefinement.mesh_error / phase_mesh_error (pycollo/mesh_refinement.py:63-240) with the
+ * section polynomial fits of pycollo/solution/solution_abc.py:60-107 folded into per-order tables:
+ * for every order n in `orders`, packed back to back, tabB / tabE are (n-1) x n (integral / value of the Lagrange
+ * basis on the n section nodes at the n-1 interior nodes of the order-(n+1) rule) and tabA is the n x (n+1)
+ * integration matrix of order n+1.  Writes the section maxima of the relative error, max_rel[K], and of the
+ * absolute error per state, max_abs[K][n_y] (may be NULL).  x is the scaled solution (host pointer). */
+int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const int32_t* orders, const double* tabB,
+                  const double* tabE, const double* tabA, double* max_rel, double* max_abs);
+
 /* timing of the last n pc_eval_all_device launches is measured by the caller with HIP events on the
  * stream it passed; this returns the stream the handle owns (hipStream_t) */
 void* pc_stream(pc_handle* h);

@@ -130,7 +130,12 @@ def _phase_struct(pm: PhaseModel) -> str:
              "      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ Hv) {",
              "    (void)v; (void)mult; (void)F; (void)Jv; (void)Hv;"]
     lines += body
-    lines += ["  }", "};", ""]
+    lines += ["  }"]
+    # state equations only (ph mesh-error estimate, mesh_refinement.py:199-201)
+    fbody = [f"    constexpr double {k} = {float(val)!r};" for k, val in pm.consts]
+    fbody += _emit_block(v_in, [(f"F[{i}]", e) for i, e in enumerate(pm.f)], "w")
+    lines += ["  __device__ static __forceinline__ void eval_f(const double* __restrict__ v, double* __restrict__ F) {",
+              "    (void)v; (void)F;"] + fbody + ["  }", "};", ""]
     assert nfn >= 0 and nv >= 0
     return "\n".join(lines)
 
@@ -198,6 +203,9 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{last}_f(PcPhaseArgs a, PcTailArgs t) '
                  f'{{ pc::bulk<gen::Phase{last}, {int(orders[last])}, gen::Tail>(a, &t); }}')
     parts.append("")
+    for pm in model.phases:
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
+                     f'{{ pc::mesh_error<gen::Phase{pm.index}>(a); }}')
     parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run(a); }')
     parts.append("")
     return "\n".join(parts)

@@ -90,4 +90,24 @@ struct PcTailArgs {
   PcTailPhase ph[PC_MAX_PHASES];
 };
 
+// Arguments of the ph mesh-error kernel (pycollo/mesh_refinement.py:63-240).
+struct PcRefineArgs {
+  const double* x;          // [num_x] scaled solution
+  const int32_t* tile_k0;   // [n_tiles+1] first section of every tile (sum of n_k+1 lanes <= blockDim)
+  const int32_t* lane0;     // [K] first lane of every section inside its tile
+  const int32_t* sec_s;     // [K+1] first solution node of every section
+  const double* sec_h;      // [K]
+  const double* tabB;       // per order n: (n-1) x n integration of the solution-node Lagrange basis up to ph node j
+  const double* tabE;       // per order n: (n-1) x n evaluation of that basis at the interior ph nodes
+  const double* tabA;       // per order n: n x (n+1) integration matrix of order n+1 (quadrature A(n+1))
+  double* max_rel;          // [K] section maximum of the relative error
+  double* max_abs;          // [K][NY] section maximum of the absolute error per state
+  int64_t x_off, s_off;
+  double t_fixed[2];
+  int32_t N, K, tab_total_BE, tab_total_A;
+  int32_t offBE[PC_MAX_ORDER + 1];
+  int32_t offA[PC_MAX_ORDER + 1];
+  double scal[PC_MAX_SCAL];
+};
+
 #endif  // PC_ARGS_H

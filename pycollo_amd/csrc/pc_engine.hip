@@ -861,6 +861,86 @@ int pc_interp_linear(int device, const double* tau_prev, int n_prev, const doubl
   });
 }
 
+int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const int32_t* orders, const double* tabB,
+                  const double* tabE, const double* tabA, double* max_rel, double* max_abs) {
+  return guarded([&] {
+    require_device(h);
+    if (phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
+    auto& Q = h->Q;
+    auto& P = Q.ph[phase];
+    auto& D = *h->pd[phase];
+    hipFunction_t fn = nullptr;
+    const std::string name = "pc_mesh_err_p" + std::to_string(phase);
+    HIP_OK(hipModuleGetFunction(&fn, h->module, name.c_str()));
+    PcRefineArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i <= PC_MAX_ORDER; ++i) a.offBE[i] = a.offA[i] = -1;
+    size_t oBE = 0, oA = 0;
+    for (int i = 0; i < n_orders; ++i) {
+      const int n = orders[i];
+      if (n < 2 || n >= PC_MAX_ORDER) throw std::runtime_error("mesh-error tables: order outside [2, 19]");
+      a.offBE[n] = (int32_t)oBE;
+      a.offA[n] = (int32_t)oA;
+      oBE += (size_t)(n - 1) * n;
+      oA += (size_t)n * (n + 1);
+    }
+    for (int k = 0; k < P.K; ++k)
+      if (a.offBE[P.n_k[k]] < 0) throw std::runtime_error("mesh-error tables: an order in use has no table");
+    // tiles: every section occupies n_k + 1 lanes
+    const int TB = 256;
+    std::vector<int32_t> tile_k0{0}, lane0(P.K);
+    int lanes = 0;
+    for (int k = 0; k < P.K; ++k) {
+      const int need = P.n_k[k] + 1;
+      if (lanes + need > TB) {
+        tile_k0.push_back(k);
+        lanes = 0;
+      }
+      lane0[k] = lanes;
+      lanes += need;
+    }
+    tile_k0.push_back(P.K);
+    DevBuf<int32_t> d_tile, d_lane;
+    DevBuf<double> d_B, d_E, d_A, d_rel, d_abs;
+    d_tile.upload(tile_k0);
+    d_lane.upload(lane0);
+    d_B.upload(std::vector<double>(tabB, tabB + oBE));
+    d_E.upload(std::vector<double>(tabE, tabE + oBE));
+    d_A.upload(std::vector<double>(tabA, tabA + oA));
+    d_rel.alloc(P.K);
+    d_abs.alloc((size_t)P.K * std::max(1, P.n_y));
+    copy_x_in(h, x);
+    a.x = h->d_x.p;
+    a.tile_k0 = d_tile.p;
+    a.lane0 = d_lane.p;
+    a.sec_s = D.sec_s.p;
+    a.sec_h = D.sec_h.p;
+    a.tabB = d_B.p;
+    a.tabE = d_E.p;
+    a.tabA = d_A.p;
+    a.max_rel = d_rel.p;
+    a.max_abs = d_abs.p;
+    a.x_off = P.x_off;
+    a.s_off = Q.s_off;
+    a.t_fixed[0] = P.t_fixed[0];
+    a.t_fixed[1] = P.t_fixed[1];
+    a.N = P.N;
+    a.K = P.K;
+    a.tab_total_BE = (int32_t)oBE;
+    a.tab_total_A = (int32_t)oA;
+    for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
+    const int NU = P.n_u, NY = P.n_y;
+    const size_t lds = 8 * (2 * oBE + oA + (size_t)TB * (5 * NY + std::max(1, NU) + 1)) + 4 * (size_t)TB;
+    if ((int)lds > h->lds_limit) throw std::runtime_error("mesh-error kernel: tables do not fit in LDS");
+    size_t sz = sizeof(a);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIP_OK(hipModuleLaunchKernel(fn, (int)tile_k0.size() - 1, 1, 1, TB, 1, 1, (unsigned)lds, h->stream, nullptr, cfg));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipMemcpy(max_rel, d_rel.p, sizeof(double) * P.K, hipMemcpyDeviceToHost));
+    if (max_abs && NY > 0) HIP_OK(hipMemcpy(max_abs, d_abs.p, sizeof(double) * (size_t)P.K * NY, hipMemcpyDeviceToHost));
+  });
+}
+
 int pc_synchronize(pc_handle* h) {
   return guarded([&] {
     require_device(h);

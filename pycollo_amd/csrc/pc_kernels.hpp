@@ -967,4 +967,142 @@ __device__ __forceinline__ void tail_point(const PcTailArgs& A) {
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// ph mesh-error estimate (pycollo/mesh_refinement.py:63-240 + solution/solution_abc.py:60-107)
+// One workgroup per run of sections; section k owns n_k + 1 consecutive lanes = its nodes on the "ph mesh"
+// (one node more per section).  Lane j < n_k also evaluates solution node j of the section.
+//   1. f at the solution nodes                      (casadi_solution.py:71)
+//   2. states / controls at the interior ph nodes from the section's interpolants, as two small
+//      table contractions:  y_ph = y_start + stretch h_k B f,   u_ph = E u   (solution_abc.py:70-100)
+//   3. f at the ph nodes, Y_ph = y_start + stretch h_k A_(n+1) f_ph          (mesh_refinement.py:199-210)
+//   4. |Y_ph - y_ph| relative to 1 + (1 + max|y_ph|) per state, section maximum (mesh_refinement.py:211-233)
+// ---------------------------------------------------------------------------------------------
+template <class M>
+__device__ __forceinline__ void mesh_error(const PcRefineArgs& A) {
+  using St = S<M>;
+  constexpr int NY = St::NY, NU = St::NU, NZ = St::NZ, NS = St::NS, NQ = St::NQ;
+  extern __shared__ double smem[];
+  const int tid = threadIdx.x, TB = blockDim.x;
+  double* s_B = smem;
+  double* s_E = s_B + A.tab_total_BE;
+  double* s_A = s_E + A.tab_total_BE;
+  double* s_fs = s_A + A.tab_total_A;          // [NY][TB] f at solution nodes
+  double* s_ys = s_fs + NY * TB;               // [NY][TB] y at solution nodes
+  double* s_us = s_ys + NY * TB;               // [NU][TB]
+  double* s_yp = s_us + (NU > 0 ? NU : 1) * TB;  // [NY][TB] y on the ph mesh
+  double* s_fp = s_yp + NY * TB;               // [NY][TB] f on the ph mesh
+  double* s_re = s_fp + NY * TB;               // [TB] row maxima of the relative error
+  double* s_ae = s_re + TB;                    // [NY][TB] absolute errors
+  int* s_sec = reinterpret_cast<int*>(s_ae + NY * TB);   // [TB] section of every lane
+  const int k0 = A.tile_k0[blockIdx.x], k1 = A.tile_k0[blockIdx.x + 1];
+  for (int i = tid; i < A.tab_total_BE; i += TB) {
+    s_B[i] = A.tabB[i];
+    s_E[i] = A.tabE[i];
+  }
+  for (int i = tid; i < A.tab_total_A; i += TB) s_A[i] = A.tabA[i];
+  s_sec[tid] = -1;
+  __syncthreads();
+  for (int k = k0 + tid; k < k1; k += TB) {
+    const int n = A.sec_s[k + 1] - A.sec_s[k] + 1, l0 = A.lane0[k];
+    for (int j = 0; j <= n; ++j) s_sec[l0 + j] = k;
+  }
+  __syncthreads();
+  const int k = s_sec[tid];
+  const bool active = k >= 0;
+  const double* sc = A.scal;
+  double t0 = A.t_fixed[0], tF = A.t_fixed[1];
+  {
+    const int64_t t_off = A.x_off + (int64_t)NZ * A.N + NQ;
+    int j = 0;
+    if constexpr (M::T0_FREE) { t0 = sc[St::O_VT + j] * A.x[t_off + j] + sc[St::O_RT + j]; ++j; }
+    if constexpr (M::TF_FREE) { tF = sc[St::O_VT + j] * A.x[t_off + j] + sc[St::O_RT + j]; }
+  }
+  const double stretch = 0.5 * (tF - t0);
+  int n = 2, j = 0, l0 = 0, sk = 0;
+  double h = 0.0;
+  double v[St::NV > 0 ? St::NV : 1], F[NY > 0 ? NY : 1];
+  if (active) {
+    sk = A.sec_s[k];
+    n = A.sec_s[k + 1] - sk + 1;
+    l0 = A.lane0[k];
+    j = tid - l0;
+    h = A.sec_h[k];
+    static_for<0, NS>([&](auto l_) {
+      constexpr int l = decltype(l_)::value;
+      v[NZ + l] = sc[St::O_VS + l] * A.x[A.s_off + l] + sc[St::O_RS + l];
+    });
+    if (j < n) {   // this lane doubles as solution node j of its section
+      static_for<0, NZ>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        v[b] = sc[St::O_VZ + b] * A.x[A.x_off + (int64_t)b * A.N + sk + j] + sc[St::O_RZ + b];
+      });
+      M::eval_f(v, F);
+      static_for<0, NY>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        s_fs[a * TB + tid] = F[a];
+        s_ys[a * TB + tid] = v[a];
+      });
+      static_for<0, NU>([&](auto b_) { s_us[decltype(b_)::value * TB + tid] = v[NY + decltype(b_)::value]; });
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const double* Bt = s_B + A.offBE[n];
+    const double* Et = s_E + A.offBE[n];
+    if (j == 0 || j == n) {   // section boundaries keep the solution's values (mesh_refinement.py:164-166,176-178)
+      const int src = l0 + (j == 0 ? 0 : n - 1);
+      static_for<0, NY>([&](auto a_) { v[decltype(a_)::value] = s_ys[decltype(a_)::value * TB + src]; });
+      static_for<0, NU>([&](auto b_) { v[NY + decltype(b_)::value] = s_us[decltype(b_)::value * TB + src]; });
+    } else {
+      static_for<0, NY>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += Bt[(j - 1) * n + i] * s_fs[a * TB + l0 + i];
+        v[a] = s_ys[a * TB + l0] + stretch * (h * acc);
+      });
+      static_for<0, NU>([&](auto b_) {
+        constexpr int b = decltype(b_)::value;
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += Et[(j - 1) * n + i] * s_us[b * TB + l0 + i];
+        v[NY + b] = acc;
+      });
+    }
+    M::eval_f(v, F);
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      s_yp[a * TB + tid] = v[a];
+      s_fp[a * TB + tid] = F[a];
+    });
+  }
+  __syncthreads();
+  double rel = 0.0;
+  if (active && j >= 1) {
+    const double* At = s_A + A.offA[n] + (j - 1) * (n + 1);
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      double acc = 0.0;
+      for (int i = 0; i <= n; ++i) acc += At[i] * s_fp[a * TB + l0 + i];
+      const double Yph = s_yp[a * TB + l0] + stretch * (h * acc);
+      const double err = fabs(Yph - s_yp[a * TB + tid]);
+      double mx = 0.0;
+      for (int i = 1; i <= n; ++i) mx = fmax(mx, fabs(s_yp[a * TB + l0 + i]));
+      rel = fmax(rel, err / (1.0 + (mx + 1.0)));
+      s_ae[a * TB + tid] = err;
+    });
+    s_re[tid] = rel;
+  }
+  __syncthreads();
+  if (active && j == 0) {
+    double m = 0.0;
+    for (int i = 1; i <= n; ++i) m = fmax(m, s_re[l0 + i]);
+    A.max_rel[k] = m;
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      double ma = 0.0;
+      for (int i = 1; i <= n; ++i) ma = fmax(ma, s_ae[a * TB + l0 + i]);
+      A.max_abs[(int64_t)k * NY + a] = ma;
+    });
+  }
+}
+
 }  // namespace pc

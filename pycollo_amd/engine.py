@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_interp_linear.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    lib.pc_mesh_error.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.pc_stream.argtypes = [vp]
     lib.pc_stream.restype = vp
     _lib = lib
@@ -387,6 +388,17 @@ class NlpEngine:
     def set_partials_buffer(self, phase: int, d_partials):
         ptr = d_partials.data_ptr() if hasattr(d_partials, "data_ptr") else d_partials
         self._check(self._lib.pc_set_partials_buffer(self._h, phase, ptr))
+
+    def mesh_error(self, phase: int, x, orders, tabB, tabE, tabA):
+        """Section maxima of the ph relative / absolute mesh error of one phase (mesh_refinement.py:198-233)."""
+        x = self._x(x)
+        K, n_y = self.meshes[phase].K, self.model.phases[phase].n_y
+        od = _i32(orders)
+        B, E, A = (np.ascontiguousarray(t, dtype=np.float64) for t in (tabB, tabE, tabA))
+        rel, ab = np.empty(K), np.empty((K, max(n_y, 1)))
+        self._check(self._lib.pc_mesh_error(self._h, phase, x.ctypes.data, len(od), od.ctypes.data, B.ctypes.data,
+                                            E.ctypes.data, A.ctypes.data, rel.ctypes.data, ab.ctypes.data))
+        return rel, ab[:, :n_y]
 
     def synchronize(self):
         self._check(self._lib.pc_synchronize(self._h))
