@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--problem", default="hypersensitive")
     ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ragged", action="store_true", help="ph-refined style mesh: random section sizes, orders 4..8")
     ap.add_argument("--generic", action="store_true", help="use the any-mesh kernels (no order specialisation)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N > 1 on one GPU")
     ap.add_argument("--check", action="store_true", help="N > 1: compare the sharded result with an unsharded one")
@@ -78,6 +79,11 @@ def main():
 
     K_total = args.sections * world
     prob = problems.REGISTRY[args.problem](K=K_total, order=args.order)
+    if args.ragged:
+        rr = np.random.default_rng(7)
+        for ph in prob.phases:
+            ph.mesh.mesh_section_sizes = rr.uniform(0.5, 1.5, K_total)
+            ph.mesh.number_mesh_section_nodes = rr.integers(4, 9, K_total)
     # a dedicated (non-default) stream: the library treats a NULL stream as "use the handle's own stream",
     # and torch events only see the stream they are recorded on
     tstream = torch.cuda.Stream(device=dev)

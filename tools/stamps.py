@@ -9,7 +9,13 @@ name = sys.argv[1] if len(sys.argv) > 1 else "hypersensitive"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 tpb = int(sys.argv[4]) if len(sys.argv) > 4 else 64
-eng = NlpEngine(problems.REGISTRY[name](K=K, order=order), device=0, threads_per_block=tpb)
+prob = problems.REGISTRY[name](K=K, order=order)
+if os.environ.get("RAGGED"):
+    rr = np.random.default_rng(7)
+    for ph in prob.phases:
+        ph.mesh.mesh_section_sizes = rr.uniform(0.5, 1.5, K)
+        ph.mesh.number_mesh_section_nodes = rr.integers(4, 9, K)
+eng = NlpEngine(prob, device=0, threads_per_block=tpb, specialise=not os.environ.get("GENERIC"))
 dev = torch.device("cuda", 0)
 x = torch.rand(eng.num_x, dtype=torch.float64, device=dev) - 0.5
 lam = torch.randn(eng.num_c, dtype=torch.float64, device=dev)
