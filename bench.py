@@ -111,7 +111,7 @@ def main():
         workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes "
                     f"= {eng.layout.phases[0].N} collocation nodes")
         extra = {"num_x": eng.num_x, "num_c": eng.num_c, "nnz_jac": eng.nnz_jac, "nnz_hess": eng.nnz_hess,
-                 "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"],
+                 "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"], "waves_per_tile": info["waves_per_tile"],
                  "launches_per_eval": info["n_launches"]}
     else:
         from pycollo_amd.sharding import ShardedNlp

@@ -84,8 +84,9 @@ typedef struct {
   int32_t n, m;
   int64_t nnz_jac, nnz_hess;
   int64_t algorithmic_bytes;       /* 8*(n+m) read + 8*(m+nnz_jac+nnz_hess) written per eval_all */
-  int32_t n_tiles_total, threads_per_block;
+  int32_t n_tiles_total, threads_per_block;   /* threads_per_block = nodes per tile (plus the shared end node) */
   int32_t lds_bytes_max, n_launches; /* kernels per eval_all */
+  int32_t waves_per_tile, reserved;  /* largest replica count of a phase (1, 2 or 4): workgroup = tile x this */
 } pc_info;
 
 const char* pc_last_error(void);

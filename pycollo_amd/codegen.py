@@ -195,8 +195,9 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("  }")
     parts.append("};")
     parts.append("}  // namespace gen\n")
+    occ = _occupancy_attr()
     for pm in model.phases:
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{pm.index}(PcPhaseArgs a) '
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(PcPhaseArgs a) '
                      f'{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a); }}')
     last = model.phases[-1].index
     parts.append("// last phase with the tail folded in: the last workgroup to arrive finishes the evaluation")
@@ -209,6 +210,20 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run(a); }')
     parts.append("")
     return "\n".join(parts)
+
+
+def _waves_per_eu() -> int:
+    """Experiment knob: PYCOLLO_AMD_WAVES_PER_EU=3|4 asks the compiler to fit the bulk kernels into the VGPR budget
+    of that many waves per SIMD (168 / 128 registers), spilling if it must.  0 (default) = no constraint."""
+    try:
+        return int(os.environ.get("PYCOLLO_AMD_WAVES_PER_EU", "0"))
+    except ValueError:
+        return 0
+
+
+def _occupancy_attr() -> str:
+    w = _waves_per_eu()
+    return f"__attribute__((amdgpu_waves_per_eu({w},{w}))) " if w > 0 else ""
 
 
 def _kernels_stamp() -> str:
@@ -235,7 +250,8 @@ def _orders_tag(model: Model, orders) -> str:
 
 
 def code_object_path(model: Model, orders=None) -> str:
-    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}.hsaco")
+    occ = f"_w{_waves_per_eu()}" if _waves_per_eu() > 0 else ""
+    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
 
 
 def build_code_object(model: Model, orders=None, force: bool = False, verbose: bool = False) -> str:

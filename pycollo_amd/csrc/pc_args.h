@@ -46,7 +46,7 @@ struct PcPhaseArgs {
   int32_t spt;            // sections per tile when uniform
   int32_t lds_out;        // doubles of the output staging buffer
   int32_t dbg_stage;      // 0 = normal; k > 0: diagnostic build of the timeline, return after stage k
-  int32_t pad1;
+  int32_t wpt;            // waves (replicas) per tile: 1, 2 or 4; > 1 only with 64-node tiles
   int32_t qa_off[PC_MAX_ORDER + 1];
   int32_t qw_off[PC_MAX_ORDER + 1];
   // packed scaling doubles: Vz[NZ] rz[NZ] Vq[NQ] rq[NQ] Vt[2] rt[2] Vs[NS] rs[NS] Wd[NY] Wp[NP] Wi[NQ]

@@ -30,19 +30,19 @@ void set_err(const std::string& s) { g_err = s; }
 // LDS plan must match pc_kernels.hpp::lds_plan (kept in one place there; mirrored here because this
 // TU does not include device templates).
 int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
-  int o = lds_out;
+  int o = 0;
   o += qa_total;
   o += qw_total;
   o += PC_MAX_ORDER + 1;
+  o += PC_MAX_SCAL + PC_MAX_GOFF + PC_MAX_HOFF;
   o += TB + 2;
   o += TB + 2;
   o += (TB + 4) / 2 + 1;
   o += (TB + 1) / 2 + 1;
-  o += NY * TB;
-  o += NY * TB;
   o += NFS * TB;
-  o += NY * (TB + PC_MAX_ORDER);
   o += (NRED > 0 ? NRED : 1) * 16;
+  const int node_arrays = 2 * NY * TB + NY * (TB + PC_MAX_ORDER);
+  o += std::max(node_arrays, lds_out);   // the staging buffer overlays f / y / lambda
   return o;
 }
 
@@ -117,6 +117,7 @@ struct PhaseDev {
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
   DevBuf<long long> dbg;
   int uni_n = 0, spt = 0, lds_out = 0;
+  int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
   hipFunction_t fn = nullptr;
   hipFunction_t fn_fused = nullptr;  // last phase only: bulk kernel with the tail folded in
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
@@ -275,6 +276,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     a.uni_n = D.uni_n;
     a.spt = D.spt;
     a.lds_out = D.lds_out;
+    a.wpt = (fuse && ip == last) ? 1 : D.wpt;
     a.dbg_stage = h->dbg_stage;
     a.hslot0 = D.hslot0.p;
     a.hslotN = D.hslotN.p;
@@ -306,7 +308,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     } else {
       size_t sz = sizeof(a);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
+      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB * D.wpt, 1, 1, D.lds_bytes, st, nullptr, cfg));
     }
   }
   if (!tail || fuse) return;
@@ -478,6 +480,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->V_ocp.assign(Q.num_ocp_x, 1.0);
     h->r_ocp.assign(Q.num_ocp_x, 0.0);
     h->W_ocp.assign(Q.num_ocp_c, 1.0);
+    bool fuse_env = false;
+    if (const char* env = std::getenv("PYCOLLO_AMD_FUSE")) fuse_env = std::atoi(env) != 0;
     h->pd.resize(Q.ph.size());
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       h->pd[ip].reset(new PhaseDev());
@@ -498,7 +502,22 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, Q.n_s, TB);
-      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred, D.lds_out);
+      // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
+      // SIMDs each hold a wave instead of a quarter of them holding one long-running wave.  Past one wave per
+      // SIMD the replicas only add redundant node evaluations and LDS (measured: shuttle, 953 tiles, 31 us at
+      // W = 1 against 36-39 us at W = 2, 4), hence the cap.
+      D.wpt = 1;
+      if (TB == 64 && !fuse_env) {
+        while (D.wpt < 4 && D.wpt * 2 <= P.n_y && (int64_t)D.n_tiles * D.wpt * 2 <= 1280) D.wpt *= 2;
+        if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
+          const int v = std::atoi(env);
+          if (v == 1 || v == 2 || v == 4) D.wpt = v;
+        }
+        while (D.wpt > 1 && 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred,
+                                            D.lds_out * D.wpt) > h->lds_limit)
+          D.wpt /= 2;
+      }
+      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred, D.lds_out * D.wpt);
       h->lds_max = std::max(h->lds_max, D.lds_bytes);
       if (D.lds_bytes > h->lds_limit)
         throw std::runtime_error("tile needs more dynamic LDS than a workgroup may request; use a smaller "
@@ -591,6 +610,9 @@ int pc_get_info(const pc_handle* h, pc_info* info) {
     info->threads_per_block = h->TB;
     info->lds_bytes_max = h->lds_max;
     info->n_launches = h->n_launches;
+    info->waves_per_tile = 1;
+    for (auto& D : h->pd) info->waves_per_tile = std::max(info->waves_per_tile, (int32_t)D->wpt);
+    info->reserved = 0;
   });
 }
 

@@ -145,7 +145,7 @@ struct S {
 
 // LDS carve-up, shared by host (size query) and device.  All offsets in doubles.
 struct LdsPlan {
-  int qa, qw, off, h, E, s, kr, f, yu, fs, lam, red, out, total;
+  int qa, qw, off, tab, h, E, s, kr, f, yu, fs, lam, red, out, total;
 };
 __host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
   LdsPlan p;
@@ -153,16 +153,23 @@ __host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, 
   p.qa = o; o += qa_total;
   p.qw = o; o += qw_total;
   p.off = o; o += PC_MAX_ORDER + 1;     // int32 x 2 x (PC_MAX_ORDER+1): table offsets by order
+  p.tab = o; o += PC_MAX_SCAL + PC_MAX_GOFF + PC_MAX_HOFF;   // scal | goff | hoff when they do not fit in SGPRs
   p.h = o; o += TB + 2;
   p.E = o; o += TB + 2;                 // int64 entries
   p.s = o; o += (TB + 4) / 2 + 1;       // int32 entries, (TB+3) of them
   p.kr = o; o += (TB + 1) / 2 + 1;      // int32 entries
-  p.f = o; o += NY * TB;
-  p.yu = o; o += NY * TB;
   p.fs = o; o += NFS * TB;
-  p.lam = o; o += NY * (TB + PC_MAX_ORDER);
   p.red = o; o += (NRED > 0 ? NRED : 1) * 16;
-  p.out = o; o += lds_out;              // output staging: CSR runs are written to HBM fully coalesced
+  // f, y and the staged multipliers are dead once the defect values are formed; the output staging buffer
+  // (CSR runs are written to HBM fully coalesced) is laid over them -- LDS per tile is what bounds occupancy
+  p.f = o;
+  p.yu = p.f + NY * TB;
+  p.lam = p.yu + NY * TB;
+  p.out = o;
+  {
+    const int node_arrays = 2 * NY * TB + NY * (TB + PC_MAX_ORDER);
+    o += node_arrays > lds_out ? node_arrays : lds_out;
+  }
   p.total = o;
   return p;
 }
@@ -201,18 +208,32 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Cooperative, fully coalesced copy of a staged CSR run from LDS to HBM (512 B per wave instruction).
+// Cooperative, fully coalesced copy of a staged CSR run from LDS to HBM: 16 B per lane and instruction (1 KiB per
+// wave instruction).  A run starts wherever the CSR layout puts it (8-byte granularity), so lane 0 peels one
+// element when that makes the destination 16-byte aligned; the LDS side is then read as two 8-byte halves.
+typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef double pc_d2_a16 __attribute__((ext_vector_type(2), aligned(16)));
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
                                           int TB) {
+  if (len <= 0) return;
+  const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
+  if (head && tid == 0) dst[0] = src[0];
+  dst += head;
+  src += head;
+  len -= head;
+  const int pairs = len >> 1;
   int e = tid;
-  for (; e + 3 * TB < len; e += 4 * TB) {   // four LDS reads in flight before the first store issues
-    const double a0 = src[e], a1 = src[e + TB], a2 = src[e + 2 * TB], a3 = src[e + 3 * TB];
-    dst[e] = a0;
-    dst[e + TB] = a1;
-    dst[e + 2 * TB] = a2;
-    dst[e + 3 * TB] = a3;
+  for (; e + TB < pairs; e += 2 * TB) {   // two LDS reads in flight before the first store issues
+    const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
+    const pc_d2_a8 a1 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + TB));
+    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
+    *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + TB)) = a1;
   }
-  for (; e < len; e += TB) dst[e] = src[e];
+  for (; e < pairs; e += TB) {
+    const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
+    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
+  }
+  if ((len & 1) && tid == TB - 1) dst[len - 1] = src[len - 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,13 +250,16 @@ struct BulkIn {
   unsigned* sync;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
-  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage;
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
 };
 
 #define PC_PIN(v) asm volatile("" ::"s"(v))
+#ifndef PC_PIN_BUDGET
+#define PC_PIN_BUDGET 40   // SGPRs the per-variable constants may take
+#endif
 template <class T>
 __device__ __forceinline__ void pin_one(T v) {
   asm volatile("" ::"s"(v));
@@ -282,6 +306,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
   A.N = KA.N; A.K = KA.K; A.flags = KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
   A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
+  A.wpt = KA.wpt;
   static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
   static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
@@ -290,14 +315,29 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
   PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
   PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
-  PC_PIN(A.dbg_stage);
-  pin_array<St::NSCAL>(A.scal);
-  pin_array<NFN>(A.goff);
-  pin_array<3 * NZ + NS * NZ>(A.hoff);
+  PC_PIN(A.dbg_stage); PC_PIN(A.wpt);
+  // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
+  // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
+  // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
+  // copy instead (uniform-address ds_read, staged with the quadrature tables).
+  constexpr int NHO = 3 * NZ + NS * NZ;
+  constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= PC_PIN_BUDGET;
+  if constexpr (PINNED) {
+    pin_array<St::NSCAL>(A.scal);
+    pin_array<NFN>(A.goff);
+    pin_array<NHO>(A.hoff);
+  }
 
   extern __shared__ double smem[];
+  // W replicas ("waves per tile") share one tile of TN nodes: every replica evaluates all TN nodes (the node
+  // functions are cheap next to a SIMD that would otherwise idle) and produces a disjoint subset of the output
+  // runs -- states, Hessian row blocks, path rows are dealt round-robin.  W > 1 only with TN = 64 (a replica is
+  // exactly one wave, so its private staging region needs no workgroup barrier).
   const int tid = threadIdx.x, TB = blockDim.x;
-  const LdsPlan lp = lds_plan(TB, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out);
+  const int W = A.wpt;                                        // 1, 2 or 4
+  const int TN = W > 1 ? 64 : TB;
+  const int w = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // wave-uniform: branches on it are scalar
+  const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
   int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off
@@ -310,7 +350,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   double* s_fs = smem + lp.fs;
   double* s_lam = smem + lp.lam;
   double* s_red = smem + lp.red;
-  double* s_out = smem + lp.out;
+  double* s_out = smem + lp.out + w * A.lds_out;   // this replica's staging region
+  auto mine = [&](int item) -> bool { return (item & (W - 1)) == w; };
+  auto stage_sync = [&]() {
+    if (W == 1) lds_barrier();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: LDS ops of a wave complete in order
+  };
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
   const int N = A.N;
@@ -350,8 +395,21 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   const int T = n1 - n0;                 // defect rows per state in this tile; nodes n0 .. n0+T
 
   // ---- per-node loads are issued before any staging so that their latency overlaps it -------------
-  const double* sc = A.scal;   // kernarg-resident: scalar loads, no global round trip
-  const int t = tid;
+  // kernarg-resident (scalar registers) or the LDS copy, see PINNED above
+  double* s_tab = smem + lp.tab;
+  const double* sc;
+  const int64_t* goff;
+  const int64_t* hoff;
+  if constexpr (PINNED) {
+    sc = A.scal;
+    goff = A.goff;
+    hoff = A.hoff;
+  } else {
+    sc = s_tab;
+    goff = reinterpret_cast<const int64_t*>(s_tab + St::NSCAL);
+    hoff = goff + NFN;
+  }
+  const int t = tid - w * TN;
   const bool active = t <= T;
   const int node = n0 + t;
   const bool owns = active && (t < T || last_tile);
@@ -406,14 +464,20 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if (tid < A.qa_total) s_qa[tid] = r_qa;
   if (tid < A.qw_total) s_qw[tid] = r_qw;
   if (tid < nsec) s_h[tid] = r_h;
+  if constexpr (!PINNED) {   // the kernarg segment is ordinary memory: lane-indexed loads of the three tables
+    for (int i = tid; i < St::NSCAL; i += TB) s_tab[i] = KA.scal[i];
+    int64_t* s_go = reinterpret_cast<int64_t*>(s_tab + St::NSCAL);
+    for (int i = tid; i < NFN; i += TB) s_go[i] = KA.goff[i];
+    for (int i = tid; i < NHO; i += TB) s_go[NFN + i] = KA.hoff[i];
+  }
   for (int i = tid + TB; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
   for (int i = tid + TB; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
   for (int i = tid + TB; i < nsec; i += TB) s_h[i] = A.sec_h[kp + i];
   if (wantH) {
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
-      if (tid < lam_cnt) s_lam[a * (TB + PC_MAX_ORDER) + tid] = r_lam[2 * a];
-      if (tid + TB < lam_cnt) s_lam[a * (TB + PC_MAX_ORDER) + tid + TB] = r_lam[2 * a + 1];
+      if (tid < lam_cnt) s_lam[a * (TN + PC_MAX_ORDER) + tid] = r_lam[2 * a];
+      if (tid + TB < lam_cnt) s_lam[a * (TN + PC_MAX_ORDER) + tid + TB] = r_lam[2 * a + 1];
     });
   }
   if (!uni) {
@@ -493,7 +557,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if (owns && wantH) {
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
-      const double* la = s_lam + a * (TB + PC_MAX_ORDER);
+      const double* la = s_lam + a * (TN + PC_MAX_ORDER);
       double acc = 0.0;
       if (ls_r >= 0) {
         const double* At = s_qa + s_off[n_r];
@@ -534,17 +598,40 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     M::eval(v, mult, F, Jv, Hv);
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
-      s_f[a * TB + t] = F[a];
-      s_yu[a * TB + t] = v[a];
+      s_f[a * TN + t] = F[a];
+      s_yu[a * TN + t] = v[a];
       static_for<0, NS>([&](auto l_) {
         constexpr int l = decltype(l_)::value;
-        if constexpr (St::dep(a, NZ + l)) s_fs[St::fs_slot(a, l) * TB + t] = Jv[St::jidx(a, NZ + l)];
+        if constexpr (St::dep(a, NZ + l)) s_fs[St::fs_slot(a, l) * TN + t] = Jv[St::jidx(a, NZ + l)];
       });
     });
   }
   __syncthreads();
   STAMP(3);
   if (A.dbg_stage == 3) { if (active && F[0] == 1.2345e300) A.c[0] = F[0]; return; }
+
+  // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
+  double accf[NY > 0 ? NY : 1];
+  const bool rowthr = active && t >= 1;
+  if (rowthr && (wantC || wantG)) {
+    const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
+    const double h = S_h(ls_r);
+    const double* Arow = s_qa + s_off[n] + (j - 1) * n;
+    static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      accf[a] = 0.0;
+      if (!mine(a)) return;
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TN + sk + i];
+      accf[a] = h * acc;
+      if (wantC)
+        A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TN + sk] - v[a]) + stretch * accf[a]);
+    });
+  }
+  lds_barrier();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
+  STAMP(4);
+  if (A.dbg_stage == 4) return;
 
   // number of nodes this tile owns, and the first one (for the staged per-node runs)
   const int n_own = T + (last_tile ? 1 : 0);
@@ -555,8 +642,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     constexpr int r = NY + m;
     constexpr int R = St::nzdep(r) + St::nsdep(r);
     const double Wp = sc[St::O_WP + m];
-    if (owns && wantC) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
-    if (wantG && R > 0) {
+    if (owns && wantC && mine(m)) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
+    if (wantG && R > 0 && mine(m)) {
       if (owns) {
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
@@ -568,9 +655,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
             s_out[t * R + St::nzdep(r) + St::srank(r, l)] = Wp * sc[St::O_VS + l] * Jv[St::jidx(r, NZ + l)];
         });
       }
-      lds_barrier();
-      flush_run(A.G + A.goff[St::GO_P + m] + (int64_t)n0 * R, s_out, n_own * R, tid, TB);
-      lds_barrier();
+      stage_sync();
+      flush_run(A.G + goff[St::GO_P + m] + (int64_t)n0 * R, s_out, n_own * R, t, TN);
+      stage_sync();
     }
   });
 
@@ -584,18 +671,18 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         constexpr int l = decltype(l_)::value;
         if constexpr (St::dep(r, NZ + l)) red[St::R_QS + m * NS + l] = w_node * Jv[St::jidx(r, NZ + l)];
       });
-      if (wantG) {
+      if (wantG && mine(m)) {
         const double k = -sc[St::O_WI + m] * stretch * w_node;
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
           if constexpr (St::dep(r, b))
-            A.G[A.goff[St::GO_Q + m] + (int64_t)St::zrank(r, b) * N + node] = k * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
+            A.G[goff[St::GO_Q + m] + (int64_t)St::zrank(r, b) * N + node] = k * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
         });
       }
     });
   }
 
-  STAMP(4);
+  STAMP(5);
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
   if (wantH) {
     const bool edge0 = (node == 0), edgeN = (node == N - 1);
@@ -603,7 +690,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     static_for<0, NZ>([&](auto rv_) {
       constexpr int rv = decltype(rv_)::value;
       constexpr int MB = St::hrow_count(rv);
-      if constexpr (MB > 0) {
+      if constexpr (MB > 0) if (mine(rv + 1)) {   // shifted by one: states are dealt from replica 0
         double vals[MB];
         static_for<0, NH>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
@@ -621,15 +708,15 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           });
         }
         if constexpr (MB == 1) {
-          if (owns && !edge0 && !edgeN) A.H[A.hoff[St::HO_Z + rv] + (int64_t)node] = vals[0];
+          if (owns && !edge0 && !edgeN) A.H[hoff[St::HO_Z + rv] + (int64_t)node] = vals[0];
         } else {
           if (owns) static_for<0, MB>([&](auto q_) { s_out[t * MB + decltype(q_)::value] = vals[decltype(q_)::value]; });
-          lds_barrier();
+          stage_sync();
           // interior nodes of the tile: [lo, hi)
           const int lo = (n0 == 0) ? 1 : 0, hi = (last_tile ? n_own - 1 : n_own);
           if (hi > lo)
-            flush_run(A.H + A.hoff[St::HO_Z + rv] + (int64_t)(n0 + lo) * MB, s_out + lo * MB, (hi - lo) * MB, tid, TB);
-          lds_barrier();
+            flush_run(A.H + hoff[St::HO_Z + rv] + (int64_t)(n0 + lo) * MB, s_out + lo * MB, (hi - lo) * MB, t, TN);
+          stage_sync();
         }
       }
     });
@@ -638,8 +725,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         constexpr int e = decltype(e_)::value;
         constexpr int rv = M::hr(e), cv = M::hc(e);
         if constexpr (rv >= NZ && cv < NZ) {
-          {
-            double* dstp = A.H + A.hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
+          if (mine(cv)) {
+            double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
             const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
             if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
           }
@@ -659,9 +746,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
               if constexpr (!(r >= NY && r < NY + NP) && St::dep(r, cvar)) acc += mu[r] * Jv[St::jidx(r, cvar)];
             });
             if constexpr (cvar < NZ) {
-              static_for<0, NT>([&](auto j_) {
+              if (mine(cvar)) static_for<0, NT>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
-                double* dstp = A.H + A.hoff[St::HO_T + j * NZ + cvar] + node;
+                double* dstp = A.H + hoff[St::HO_T + j * NZ + cvar] + node;
                 const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
                 if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
               });
@@ -679,6 +766,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   //      so the store drain below waits for a handful of stores only
   bool is_last = false;
   if constexpr (NRED > 0) {
+    if (w != 0) static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });   // replicas hold copies
     const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
     static_for<0, NRED>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
@@ -721,26 +809,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
   }
-  STAMP(5);
-  if (A.dbg_stage == 4) return;
-  // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
-  double accf[NY > 0 ? NY : 1];
-  const bool rowthr = active && t >= 1;
-  if (rowthr && (wantC || wantG)) {
-    const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
-    const double h = S_h(ls_r);
-    const double* Arow = s_qa + s_off[n] + (j - 1) * n;
-    static_for<0, NY>([&](auto a_) {
-      constexpr int a = decltype(a_)::value;
-      double acc = 0.0;
-#pragma unroll
-      for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TB + sk + i];
-      accf[a] = h * acc;
-      if (wantC)
-        A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TB + sk] - v[a]) + stretch * accf[a]);
-    });
-  }
-
   STAMP(6);
   if (A.dbg_stage == 5) return;
   // ---- Jacobian of the defect rows (compiled.py:305-334), one state at a time:
@@ -751,6 +819,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     const long long E0 = S_E(lsA), E1 = S_E(nsec);
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
+      if (!mine(a)) return;
       constexpr int Da = St::D(a), Ca = St::C(a);
       const double Wd = sc[St::O_WD + a];
       // local offset of row (section ls, row j) inside the run: rows before it in the tile
@@ -760,27 +829,35 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         return Da * eloc + Ca * (S_s(ls) - n0) + (j - 1) * (Da * n + Ca);
       };
       if (active) {
+        // row a of dF/dz with every factor that does not depend on the CSR row folded in once:
+        // W_a * stretch * (df_a/dz_b * V_b); an entry is then one multiply by h_k A[j][pos]
+        double js[Da > 0 ? Da : 1];
+        const double WS = Wd * stretch, WV = Wd * sc[St::O_VZ + a];
+        static_for<0, NZ>([&](auto b_) {
+          constexpr int b = decltype(b_)::value;
+          if constexpr (St::dep(a, b)) js[St::ndep_before(a, b)] = WS * (Jv[St::jidx(a, b)] * sc[St::O_VZ + b]);
+        });
         auto write_cols = [&](int ls, int pos, int n) {
           const double h = S_h(ls);
           const double* At = s_qa + s_off[n];
 #pragma unroll
           for (int j = 1; j < n; ++j) {
-            const double coef = stretch * h * At[(j - 1) * n + pos];
+            const double coef = h * At[(j - 1) * n + pos];
             const int rs = row_off(ls, j, n);
             static_for<0, NZ>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
               if constexpr (St::dep(a, b)) {
                 constexpr int before = St::ndep_before(a, b);
                 constexpr int extra = (St::own_sparse(a) && a < b) ? 2 : 0;
-                double val = coef * Jv[St::jidx(a, b)] * sc[St::O_VZ + b];
-                if constexpr (a == b) val += sc[St::O_VZ + a] * ((pos == 0 ? 1.0 : 0.0) - (pos == j ? 1.0 : 0.0));
-                s_out[rs + before * n + extra + pos] = Wd * val;
+                double val = coef * js[before];
+                if constexpr (a == b) val += WV * ((pos == 0 ? 1.0 : 0.0) - (pos == j ? 1.0 : 0.0));
+                s_out[rs + before * n + extra + pos] = val;
               }
             });
             if constexpr (St::own_sparse(a)) {
               const int o = rs + St::ndep_before(a, a) * n;
-              if (pos == 0) s_out[o] = Wd * sc[St::O_VZ + a];
-              if (pos == j) s_out[o + 1] = -(Wd * sc[St::O_VZ + a]);
+              if (pos == 0) s_out[o] = WV;
+              if (pos == j) s_out[o + 1] = -WV;
             }
           }
         };
@@ -800,18 +877,18 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
                 const double* Arow = s_qa + s_off[n] + (j - 1) * n;
                 double as = 0.0;
 #pragma unroll
-                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[St::fs_slot(a, l) * TB + sk + i];
+                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[St::fs_slot(a, l) * TN + sk + i];
                 s_out[rs + NT + St::srank(a, l)] = Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
               }
             });
           }
         }
       }
-      lds_barrier();
+      stage_sync();
       const int len = (int)((long long)Da * (E1 - E0)) + Ca * T;
-      const int64_t g0 = A.goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
-      flush_run(A.G + g0, s_out, len, tid, TB);
-      lds_barrier();
+      const int64_t g0 = goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
+      flush_run(A.G + g0, s_out, len, t, TN);
+      stage_sync();
     });
   }
 

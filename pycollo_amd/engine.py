@@ -60,7 +60,8 @@ class _ProblemDesc(C.Structure):
 class _Info(C.Structure):
     _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("nnz_jac", C.c_int64), ("nnz_hess", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("n_tiles_total", C.c_int32), ("threads_per_block", C.c_int32),
-                ("lds_bytes_max", C.c_int32), ("n_launches", C.c_int32)]
+                ("lds_bytes_max", C.c_int32), ("n_launches", C.c_int32), ("waves_per_tile", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 _lib = None

@@ -69,6 +69,28 @@ def test_parity_with_oracle(built, tab, name, kw, tpb):
     eng.close()
 
 
+@pytest.mark.parametrize("name,kw", [("shuttle", dict(K=60, order=5)), ("delta_iii", dict(K=9, order=4)),
+                                     ("two_phase_transfer", {})])
+def test_waves_per_tile_replicas(built, tab, monkeypatch, name, kw):
+    """64-node tiles shared by 1, 2 or 4 waves (pc::bulk, `wpt`): every split writes the same bits, and the
+    automatic choice is one of them."""
+    prob = problems.REGISTRY[name](**kw)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+    outs = {}
+    for wpt in (1, 2, 4):
+        monkeypatch.setenv("PYCOLLO_AMD_WPT", str(wpt))
+        eng = _engine(prob, threads_per_block=64)
+        assert eng.info["waves_per_tile"] == wpt
+        if wpt == 1:
+            ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+        x, lam = _check_all(eng, ora, seed=3, xlo=lo, xhi=hi)
+        outs[wpt] = eng.evaluate_all(x, 0.6, lam)
+        eng.close()
+    for wpt in (2, 4):
+        for a, b in zip(outs[1], outs[wpt]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_known_answers_brachistochrone(built, known_answers):
     """tests/unit/test_iteration.py:305-318, 339-354, 371-385 evaluated by the HIP path."""
     eng = _engine(problems.brachistochrone())

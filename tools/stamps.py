@@ -29,14 +29,13 @@ out = np.zeros((nt, 16), dtype=np.int64)
 eng._lib.pc_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 assert eng._lib.pc_debug_stamps(eng._h, 0, out.ctypes.data, nt)
 d = np.diff(out[:, :9], axis=1)
-names = ["loads+staging+sync", "geometry+mu", "eval+LDS f+sync", "path+integral", "hessian", "defect c", "defect G", "partials"]
+names = ["loads+staging+sync", "geometry+mu", "eval+LDS f+sync", "defect c", "path+integral", "hessian+partials", "defect G", "end"]
 print(f"{name} K={K} n={order} TB={tpb}: tiles {nt}; cycles per phase (median over tiles; each stamp costs ~250-500 cycles itself)")
 for i, nm in enumerate(names):
     print(f"  {nm:22s} {np.median(d[:, i]):8.0f}   (min {d[:, i].min():6d}, max {d[:, i].max():6d})")
 print(f"  total                  {np.median(out[:, 8] - out[:, 0]):8.0f} cycles = {np.median(out[:, 8] - out[:, 0]) / 100:.2f} us at 100 MHz stamp clock")
 if out[:, 9].max() > 0:
-    arr = out[:, 9] - out[:, 5 - 1]   # arrival stamp relative to stamp 4 (before the Hessian section)
-    print(f"  fused: hessian+partials+drain+arrival (stamp4->9) median {np.median(out[:, 9] - out[:, 4]):.0f} max {(out[:, 9] - out[:, 4]).max()}")
+        print(f"  fused: hessian+partials+drain+arrival (stamp5->9) median {np.median(out[:, 9] - out[:, 5]):.0f} max {(out[:, 9] - out[:, 5]).max()}")
     lastb = int(np.argmax(out[:, 10]))
     print(f"  fused: last workgroup = tile {lastb}: start->arrival {out[lastb, 9] - out[lastb, 0]}, arrival->own work done {out[lastb, 8] - out[lastb, 9]}, tail {out[lastb, 10] - out[lastb, 8]} cycles")
     print(f"  fused: whole kernel (first start -> tail end) {out[lastb, 10] - out[:, 0].min()} cycles; first start -> last non-tail end {out[:, 8].max() - out[:, 0].min()}")
