@@ -221,6 +221,11 @@ def _waves_per_eu() -> int:
         return 0
 
 
+def _extra_defines() -> list[str]:
+    """Experiment knob: PYCOLLO_AMD_DEFINES="PC_FLUSH_DEPTH=8 PC_PIN_BUDGET=0" adds -D flags to the code-object build."""
+    return [d for d in os.environ.get("PYCOLLO_AMD_DEFINES", "").split() if d]
+
+
 def _occupancy_attr() -> str:
     w = _waves_per_eu()
     return f"__attribute__((amdgpu_waves_per_eu({w},{w}))) " if w > 0 else ""
@@ -251,6 +256,8 @@ def _orders_tag(model: Model, orders) -> str:
 
 def code_object_path(model: Model, orders=None) -> str:
     occ = f"_w{_waves_per_eu()}" if _waves_per_eu() > 0 else ""
+    if _extra_defines():
+        occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
 
 
@@ -272,7 +279,7 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
     # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
     cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
-           f"-I{CSRC}", "-o", out + ".tmp", src]
+           f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)

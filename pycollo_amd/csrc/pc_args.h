@@ -36,6 +36,8 @@ struct PcPhaseArgs {
   double* partials;       // [n_tiles][NRED] per-tile partial sums
   long long* dbg;         // diagnostic builds only: [n_tiles][16] s_memtime stamps (dbg_stage == 9)
   unsigned* sync;         // fused tail: [(PC_SYNC_SHARDS + 1) * 16] arrival counters, all zero between launches
+  const double* tab;      // device copy of scal | goff | hoff (packed, used entries only): staged into LDS by
+                          // the kernels of models whose tables do not fit the scalar register file
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
   int64_t c_off, c_path_off, c_int_off;
   double t_fixed[2];

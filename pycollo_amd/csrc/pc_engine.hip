@@ -113,7 +113,7 @@ struct PinBuf {
 
 struct PhaseDev {
   DevBuf<int32_t> tile_k0, tile_n0, sec_s;
-  DevBuf<double> sec_h, scal, partials;
+  DevBuf<double> sec_h, scal, partials, tab;
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
   DevBuf<long long> dbg;
   int uni_n = 0, spt = 0, lds_out = 0;
@@ -283,6 +283,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
     a.dbg = D.dbg.p;
     a.sync = h->d_sync.p;
+    a.tab = D.tab.p;
     a.x_off = P.x_off;
     a.s_off = Q.s_off;
     a.c_off = P.c_off;
@@ -343,6 +344,19 @@ void upload_scaling(pc_handle* h) {
     if (h->device >= 0) {
       if (D.scal.n != s.size()) D.scal.alloc(s.size());
       HIP_OK(hipMemcpy(D.scal.p, s.data(), s.size() * sizeof(double), hipMemcpyHostToDevice));
+      // scal | goff | hoff as one table (pc::bulk stages it into LDS for models with many variables)
+      std::vector<double> tab(s);
+      auto append = [&](const std::vector<int64_t>& v) {
+        for (int64_t e : v) {
+          double d;
+          std::memcpy(&d, &e, sizeof(d));
+          tab.push_back(d);
+        }
+      };
+      append(P.goff);
+      append(P.hoff);
+      if (D.tab.n != tab.size()) D.tab.alloc(tab.size());
+      HIP_OK(hipMemcpy(D.tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
     }
   }
   if (h->device >= 0) {
@@ -503,12 +517,13 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, Q.n_s, TB);
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
-      // SIMDs each hold a wave instead of a quarter of them holding one long-running wave.  Past one wave per
-      // SIMD the replicas only add redundant node evaluations and LDS (measured: shuttle, 953 tiles, 31 us at
-      // W = 1 against 36-39 us at W = 2, 4), hence the cap.
+      // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
+      // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle
+      // 381 tiles 22.7 / 19.2 / 17.6 us, 953 tiles 25.2 / 23.3 / 31.3 us, 2858 tiles 54 / 60 / 81 us).
       D.wpt = 1;
       if (TB == 64 && !fuse_env) {
-        while (D.wpt < 4 && D.wpt * 2 <= P.n_y && (int64_t)D.n_tiles * D.wpt * 2 <= 1280) D.wpt *= 2;
+        if (P.n_y >= 2 && D.n_tiles <= 1024) D.wpt = 2;
+        if (P.n_y >= 4 && D.n_tiles <= 400) D.wpt = 4;
         if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
           const int v = std::atoi(env);
           if (v == 1 || v == 2 || v == 4) D.wpt = v;

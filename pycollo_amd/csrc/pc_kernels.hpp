@@ -223,11 +223,15 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
   len -= head;
   const int pairs = len >> 1;
   int e = tid;
-  for (; e + TB < pairs; e += 2 * TB) {   // two LDS reads in flight before the first store issues
-    const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
-    const pc_d2_a8 a1 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + TB));
-    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
-    *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + TB)) = a1;
+#ifndef PC_FLUSH_DEPTH
+#define PC_FLUSH_DEPTH 4
+#endif
+  for (; e + (PC_FLUSH_DEPTH - 1) * TB < pairs; e += PC_FLUSH_DEPTH * TB) {   // LDS reads in flight before the first store issues
+    pc_d2_a8 a[PC_FLUSH_DEPTH];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + q * TB));
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)) = a[q];
   }
   for (; e < pairs; e += TB) {
     const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
@@ -247,7 +251,7 @@ struct BulkIn {
   const double* x; const double* lam; double* c; double* G; double* H;
   const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
   const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials; long long* dbg;
-  unsigned* sync;
+  unsigned* sync; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
   int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt;
@@ -259,6 +263,9 @@ struct BulkIn {
 #define PC_PIN(v) asm volatile("" ::"s"(v))
 #ifndef PC_PIN_BUDGET
 #define PC_PIN_BUDGET 40   // SGPRs the per-variable constants may take
+#endif
+#ifndef PC_PIN_BUDGET_FUSED
+#define PC_PIN_BUDGET_FUSED 0   // the fused build also carries the tail's scalars
 #endif
 template <class T>
 __device__ __forceinline__ void pin_one(T v) {
@@ -301,7 +308,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
   A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; A.sec_h = KA.sec_h; A.sec_E = KA.sec_E;
   A.qa = KA.qa; A.qw = KA.qw; A.hslot0 = KA.hslot0; A.hslotN = KA.hslotN; A.partials = KA.partials; A.dbg = KA.dbg;
-  A.sync = KA.sync;
+  A.sync = KA.sync; A.tab = KA.tab;
   A.x_off = KA.x_off; A.s_off = KA.s_off; A.c_off = KA.c_off; A.c_path_off = KA.c_path_off; A.c_int_off = KA.c_int_off;
   A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
   A.N = KA.N; A.K = KA.K; A.flags = KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
@@ -312,7 +319,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
   PC_PIN(A.x); PC_PIN(A.lam); PC_PIN(A.c); PC_PIN(A.G); PC_PIN(A.H); PC_PIN(A.tile_k0); PC_PIN(A.tile_n0);
   PC_PIN(A.sec_s); PC_PIN(A.sec_h); PC_PIN(A.sec_E); PC_PIN(A.qa); PC_PIN(A.qw); PC_PIN(A.hslot0); PC_PIN(A.hslotN);
-  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
+  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.tab); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
   PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
   PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
   PC_PIN(A.dbg_stage); PC_PIN(A.wpt);
@@ -321,7 +328,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
   // copy instead (uniform-address ds_read, staged with the quadrature tables).
   constexpr int NHO = 3 * NZ + NS * NZ;
-  constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= PC_PIN_BUDGET;
+  constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= (FUSED ? PC_PIN_BUDGET_FUSED : PC_PIN_BUDGET);
   if constexpr (PINNED) {
     pin_array<St::NSCAL>(A.scal);
     pin_array<NFN>(A.goff);
@@ -464,11 +471,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if (tid < A.qa_total) s_qa[tid] = r_qa;
   if (tid < A.qw_total) s_qw[tid] = r_qw;
   if (tid < nsec) s_h[tid] = r_h;
-  if constexpr (!PINNED) {   // the kernarg segment is ordinary memory: lane-indexed loads of the three tables
-    for (int i = tid; i < St::NSCAL; i += TB) s_tab[i] = KA.scal[i];
-    int64_t* s_go = reinterpret_cast<int64_t*>(s_tab + St::NSCAL);
-    for (int i = tid; i < NFN; i += TB) s_go[i] = KA.goff[i];
-    for (int i = tid; i < NHO; i += TB) s_go[NFN + i] = KA.hoff[i];
+  if constexpr (!PINNED) {   // scal | goff | hoff, packed by the host in exactly this order
+    for (int i = tid; i < St::NSCAL + NFN + NHO; i += TB) s_tab[i] = A.tab[i];
   }
   for (int i = tid + TB; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
   for (int i = tid + TB; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
@@ -552,6 +556,33 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
   }
 
+  // ---- h_k A[j][pos]: the node's column of the integration matrix in the section it closes (cr) and in the
+  //      section it opens (cs).  Both the adjoint weights and the defect Jacobian are built from these; with a
+  //      compile-time order they are read from LDS once, here, instead of once per state and use
+#ifndef PC_HOIST_MAX
+#define PC_HOIST_MAX 8
+#endif
+  constexpr bool HOIST = (UN > 0 && UN <= PC_HOIST_MAX);
+  constexpr int NC = HOIST ? UN - 1 : 1;
+  double cr[NC], cs[NC];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) cr[j] = cs[j] = 0.0;
+    if (active) {
+      const double* At = s_qa + s_off[UN];
+      if (ls_r >= 0) {
+        const double h = S_h(ls_r);
+#pragma unroll
+        for (int j = 1; j < UN; ++j) cr[j - 1] = h * At[(j - 1) * UN + pos_r];
+      }
+      if (has_start) {
+        const double h = S_h(ls_s);
+#pragma unroll
+        for (int j = 1; j < UN; ++j) cs[j - 1] = h * At[(j - 1) * UN];
+      }
+    }
+  }
+
   // ---- adjoint node weights mu (iteration.py:1078-1103) ------------------------------------------
   static_for<0, NFN>([&](auto r_) { mu[decltype(r_)::value] = 0.0; });
   if (owns && wantH) {
@@ -559,21 +590,36 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       constexpr int a = decltype(a_)::value;
       const double* la = s_lam + a * (TN + PC_MAX_ORDER);
       double acc = 0.0;
-      if (ls_r >= 0) {
-        const double* At = s_qa + s_off[n_r];
-        const int base = S_s(ls_r) - lam0;
-        double a2 = 0.0;
+      if constexpr (HOIST) {
+        if (ls_r >= 0) {
+          const int base = S_s(ls_r) - lam0;
 #pragma unroll
-        for (int j = 1; j < n_r; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_r + pos_r];
-        acc += S_h(ls_r) * a2;
-      }
-      if (has_start) {
-        const double* At = s_qa + s_off[n_s];
-        const int base = S_s(ls_s) - lam0;
-        double a2 = 0.0;
+          for (int j = 1; j < UN; ++j) acc += la[base + j - 1] * cr[j - 1];
+        }
+        if (has_start) {
+          const int base = S_s(ls_s) - lam0;
+          double a2 = 0.0;
 #pragma unroll
-        for (int j = 1; j < n_s; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_s];
-        acc += S_h(ls_s) * a2;
+          for (int j = 1; j < UN; ++j) a2 += la[base + j - 1] * cs[j - 1];
+          acc += a2;
+        }
+      } else {
+        if (ls_r >= 0) {
+          const double* At = s_qa + s_off[n_r];
+          const int base = S_s(ls_r) - lam0;
+          double a2 = 0.0;
+#pragma unroll
+          for (int j = 1; j < n_r; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_r + pos_r];
+          acc += S_h(ls_r) * a2;
+        }
+        if (has_start) {
+          const double* At = s_qa + s_off[n_s];
+          const int base = S_s(ls_s) - lam0;
+          double a2 = 0.0;
+#pragma unroll
+          for (int j = 1; j < n_s; ++j) a2 += la[base + j - 1] * At[(j - 1) * n_s];
+          acc += S_h(ls_s) * a2;
+        }
       }
       mu[a] = sc[St::O_WD + a] * acc;
     });
@@ -837,12 +883,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           constexpr int b = decltype(b_)::value;
           if constexpr (St::dep(a, b)) js[St::ndep_before(a, b)] = WS * (Jv[St::jidx(a, b)] * sc[St::O_VZ + b]);
         });
-        auto write_cols = [&](int ls, int pos, int n) {
-          const double h = S_h(ls);
-          const double* At = s_qa + s_off[n];
+        auto write_cols = [&](int ls, int pos, int n, const double* cc) {
+          const double h = HOIST ? 0.0 : S_h(ls);
+          const double* At = s_qa + (HOIST ? 0 : s_off[n]);
 #pragma unroll
           for (int j = 1; j < n; ++j) {
-            const double coef = h * At[(j - 1) * n + pos];
+            const double coef = HOIST ? cc[j - 1] : h * At[(j - 1) * n + pos];
             const int rs = row_off(ls, j, n);
             static_for<0, NZ>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
@@ -861,8 +907,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
             }
           }
         };
-        if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r);
-        if (has_start) write_cols(ls_s, 0, n_s);
+        if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r, cr);
+        if (has_start) write_cols(ls_s, 0, n_s, cs);
         if constexpr (NT + St::nsdep(a) > 0) {
           if (rowthr) {   // t and s columns of this lane's own row
             const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;

@@ -35,7 +35,7 @@ for i, nm in enumerate(names):
     print(f"  {nm:22s} {np.median(d[:, i]):8.0f}   (min {d[:, i].min():6d}, max {d[:, i].max():6d})")
 print(f"  total                  {np.median(out[:, 8] - out[:, 0]):8.0f} cycles = {np.median(out[:, 8] - out[:, 0]) / 100:.2f} us at 100 MHz stamp clock")
 if out[:, 9].max() > 0:
-        print(f"  fused: hessian+partials+drain+arrival (stamp5->9) median {np.median(out[:, 9] - out[:, 5]):.0f} max {(out[:, 9] - out[:, 5]).max()}")
+    print(f"  fused: hessian+partials+drain+arrival (stamp5->9) median {np.median(out[:, 9] - out[:, 5]):.0f} max {(out[:, 9] - out[:, 5]).max()}")
     lastb = int(np.argmax(out[:, 10]))
     print(f"  fused: last workgroup = tile {lastb}: start->arrival {out[lastb, 9] - out[lastb, 0]}, arrival->own work done {out[lastb, 8] - out[lastb, 9]}, tail {out[lastb, 10] - out[lastb, 8]} cycles")
     print(f"  fused: whole kernel (first start -> tail end) {out[lastb, 10] - out[:, 0].min()} cycles; first start -> last non-tail end {out[:, 8].max() - out[:, 0].min()}")
