@@ -431,6 +431,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       P.hess_row.assign(s.hess_row, s.hess_row + s.n_hess);
       P.hess_col.assign(s.hess_col, s.hess_col + s.n_hess);
       P.bulk_kernel = s.bulk_kernel ? s.bulk_kernel : "";
+      P.eval_ops = s.eval_ops;
       for (int k = 0; k < s.K; ++k)
         if (s.compiled_order > 0 && s.n_k[k] != s.compiled_order)
           throw std::runtime_error("phase kernel was compiled for a fixed section order that the mesh does not have");
@@ -522,8 +523,11 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       // 381 tiles 22.7 / 19.2 / 17.6 us, 953 tiles 25.2 / 23.3 / 31.3 us, 2858 tiles 54 / 60 / 81 us).
       D.wpt = 1;
       if (TB == 64 && !fuse_env) {
-        if (P.n_y >= 2 && D.n_tiles <= 1024) D.wpt = 2;
-        if (P.n_y >= 4 && D.n_tiles <= 400) D.wpt = 4;
+        // (one state: W = 2 measured no faster, 5.58 vs 5.49 us.  A heavy model -- Delta III, ~10k operations --
+        //  loses at 834 tiles, 358 / 410 / 522 us: every sharing wave re-evaluates the node functions)
+        const bool heavy = P.eval_ops > 4000;
+        if (P.n_y >= 2 && D.n_tiles <= (heavy ? 512 : 1024)) D.wpt = 2;
+        if (P.n_y >= 3 && D.n_tiles <= 400) D.wpt = 4;
         if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
           const int v = std::atoi(env);
           if (v == 1 || v == 2 || v == 4) D.wpt = v;

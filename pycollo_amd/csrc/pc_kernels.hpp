@@ -141,6 +141,60 @@ struct S {
   // goff / hoff layout
   static constexpr int GO_D = 0, GO_P = NY, GO_Q = NY + NP;
   static constexpr int HO_Z = 0, HO_T = NZ, HO_S = 3 * NZ;
+
+  // ---- output items of a tile, dealt to the W waves ("replicas") that share it.  One item = one group of
+  //      CSR runs a single replica produces: a state's defect rows (c~ and its G~ block), a path row, an
+  //      integral row (its G~ entries and partial sums), a Hessian row block, the s-/t-strip of one z column,
+  //      the (t,s)/(s,s) partial sums.  Items are weighed by the entries they emit per node and assigned
+  //      largest-first to the least loaded replica; Hessian items break ties towards the last replica and the
+  //      others towards the first, so that replicas without a Hessian item exist and skip the adjoint weights.
+  static constexpr int IT_D = 0, IT_P = NY, IT_Q = NY + NP, IT_HB = NY + NP + NQ, IT_HS = IT_HB + NZ,
+                       IT_HT = IT_HS + NZ, IT_HSUM = IT_HT + NZ, NITEMS = IT_HSUM + 1;
+  struct Deal {
+    int own[NITEMS];
+    unsigned hmask;   // bit w: replica w owns a Hessian item
+  };
+  template <int W, int NN>
+  static constexpr Deal deal() {
+    Deal d{};
+    int wt[NITEMS] = {};
+    bool done[NITEMS] = {};
+    for (int a = 0; a < NY; ++a) wt[IT_D + a] = D(a) * NN + C(a) + 1;
+    for (int m = 0; m < NP; ++m) wt[IT_P + m] = nzdep(NY + m) + nsdep(NY + m) + 1;
+    for (int m = 0; m < NQ; ++m) wt[IT_Q + m] = nzdep(NY + NP + m) + 1;
+    for (int b = 0; b < NZ; ++b) {
+      wt[IT_HB + b] = hrow_count(b) > 0 ? hrow_count(b) + 1 : 0;
+      int ns = 0;
+      for (int e = 0; e < NH; ++e) ns += (M::hr(e) >= NZ && M::hc(e) == b) ? 1 : 0;
+      wt[IT_HS + b] = ns;
+      wt[IT_HT + b] = tz(b) ? NT : 0;
+    }
+    wt[IT_HSUM] = NS > 0 ? NS + NS * (NS + 1) / 2 : 0;
+    int load[W] = {};
+    d.hmask = 0;
+    for (int it = 0; it < NITEMS; ++it) {
+      int best = -1;
+      for (int i = 0; i < NITEMS; ++i)
+        if (!done[i] && (best < 0 || wt[i] > wt[best])) best = i;
+      done[best] = true;
+      const bool hess = best >= IT_HB;
+      int bin = hess ? W - 1 : 0;
+      for (int k = 0; k < W; ++k) {
+        const int b = hess ? W - 1 - k : k;
+        if (load[b] < load[bin]) bin = b;
+      }
+      d.own[best] = wt[best] > 0 ? bin : 0;
+      load[bin] += wt[best];
+      if (hess && wt[best] > 0) d.hmask |= 1u << bin;
+    }
+    return d;
+  }
+  // which item a partial sum belongs to
+  static constexpr int red_item(int r) {
+    if (r < R_QS) return IT_Q + (r - R_Q);
+    if (r < R_TS) return IT_Q + (r - R_QS) / (NS > 0 ? NS : 1);
+    return IT_HSUM;
+  }
 };
 
 // LDS carve-up, shared by host (size query) and device.  All offsets in doubles.
@@ -358,7 +412,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   double* s_lam = smem + lp.lam;
   double* s_red = smem + lp.red;
   double* s_out = smem + lp.out + w * A.lds_out;   // this replica's staging region
-  auto mine = [&](int item) -> bool { return (item & (W - 1)) == w; };
+  // static deal of the tile's output items to the replicas (S<M>::deal); W == 1 owns everything
+  constexpr auto DEAL2 = St::template deal<2, (UN > 0 ? UN : 4)>();
+  constexpr auto DEAL4 = St::template deal<4, (UN > 0 ? UN : 4)>();
+  auto mine = [&](auto item_) -> bool {
+    constexpr int item = decltype(item_)::value;
+    return W == 1 || (W == 2 ? DEAL2.own[item] : DEAL4.own[item]) == w;
+  };
+  // does this replica produce any Hessian output (and hence need the adjoint node weights)?
+  const bool hess_replica = W == 1 || (((W == 2 ? DEAL2.hmask : DEAL4.hmask) >> w) & 1u);
+#define PC_ITEM(i) std::integral_constant<int, (i)>{}
   auto stage_sync = [&]() {
     if (W == 1) lds_barrier();
     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: LDS ops of a wave complete in order
@@ -434,7 +497,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
   double lam_p[NP > 0 ? NP : 1], lam_q[NQ > 0 ? NQ : 1];
-  if (owns && wantH) {
+  if (owns && wantH && hess_replica) {
     static_for<0, NP>([&](auto m_) { lam_p[decltype(m_)::value] = A.lam[A.c_path_off + (int64_t) decltype(m_)::value * N + node]; });
     static_for<0, NQ>([&](auto m_) { lam_q[decltype(m_)::value] = A.lam[A.c_int_off + decltype(m_)::value]; });
   }
@@ -585,7 +648,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   // ---- adjoint node weights mu (iteration.py:1078-1103) ------------------------------------------
   static_for<0, NFN>([&](auto r_) { mu[decltype(r_)::value] = 0.0; });
-  if (owns && wantH) {
+  if (owns && wantH && hess_replica) {
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       const double* la = s_lam + a * (TN + PC_MAX_ORDER);
@@ -666,7 +729,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       accf[a] = 0.0;
-      if (!mine(a)) return;
+      if (!mine(PC_ITEM(St::IT_D + a))) return;
       double acc = 0.0;
 #pragma unroll
       for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TN + sk + i];
@@ -688,8 +751,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     constexpr int r = NY + m;
     constexpr int R = St::nzdep(r) + St::nsdep(r);
     const double Wp = sc[St::O_WP + m];
-    if (owns && wantC && mine(m)) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
-    if (wantG && R > 0 && mine(m)) {
+    if (owns && wantC && mine(PC_ITEM(St::IT_P + m))) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
+    if (wantG && R > 0 && mine(PC_ITEM(St::IT_P + m))) {
       if (owns) {
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
@@ -717,7 +780,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         constexpr int l = decltype(l_)::value;
         if constexpr (St::dep(r, NZ + l)) red[St::R_QS + m * NS + l] = w_node * Jv[St::jidx(r, NZ + l)];
       });
-      if (wantG && mine(m)) {
+      if (wantG && mine(PC_ITEM(St::IT_Q + m))) {
         const double k = -sc[St::O_WI + m] * stretch * w_node;
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
@@ -730,13 +793,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   STAMP(5);
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
-  if (wantH) {
+  if (wantH && hess_replica) {
     const bool edge0 = (node == 0), edgeN = (node == N - 1);
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
     static_for<0, NZ>([&](auto rv_) {
       constexpr int rv = decltype(rv_)::value;
       constexpr int MB = St::hrow_count(rv);
-      if constexpr (MB > 0) if (mine(rv + 1)) {   // shifted by one: states are dealt from replica 0
+      if constexpr (MB > 0) if (mine(PC_ITEM(St::IT_HB + rv))) {
         double vals[MB];
         static_for<0, NH>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
@@ -771,7 +834,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         constexpr int e = decltype(e_)::value;
         constexpr int rv = M::hr(e), cv = M::hc(e);
         if constexpr (rv >= NZ && cv < NZ) {
-          if (mine(cv)) {
+          if (mine(PC_ITEM(St::IT_HS + cv))) {
             double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
             const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
             if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
@@ -792,7 +855,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
               if constexpr (!(r >= NY && r < NY + NP) && St::dep(r, cvar)) acc += mu[r] * Jv[St::jidx(r, cvar)];
             });
             if constexpr (cvar < NZ) {
-              if (mine(cvar)) static_for<0, NT>([&](auto j_) {
+              if (mine(PC_ITEM(St::IT_HT + cvar))) static_for<0, NT>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 double* dstp = A.H + hoff[St::HO_T + j * NZ + cvar] + node;
                 const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
@@ -807,24 +870,29 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
   }
 
-  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile) and, in the fused build, the arrival:
-  //      everything the tail consumes (partials, edge Hessian entries) is out before the bulky c~/G~ runs,
-  //      so the store drain below waits for a handful of stores only
+  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile): every wave deposits its sums here.  In the
+  //      fused build they are combined and stored at once, followed by the arrival: everything the tail consumes
+  //      (partials, edge Hessian entries) is out before the bulky c~/G~ runs, so the store drain below waits for a
+  //      handful of stores only
   bool is_last = false;
   if constexpr (NRED > 0) {
-    if (w != 0) static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });   // replicas hold copies
+    static_for<0, NRED>([&](auto r_) {   // replicas hold copies: the owner of the sum's item contributes
+      constexpr int r = decltype(r_)::value;
+      if (!mine(PC_ITEM(St::red_item(r)))) red[r] = 0.0;
+    });
     const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
     static_for<0, NRED>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
       const double s = wave_sum(red[r]);
       if (lane == 0) s_red[r * 16 + wave] = s;
     });
-    lds_barrier();
-    if (tid < NRED) {
-      double s = 0.0;
-      for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
-      if constexpr (FUSED) store_agent(A.partials + (int64_t)tile * NRED + tid, s);
-      else A.partials[(int64_t)tile * NRED + tid] = s;
+    if constexpr (FUSED) {
+      lds_barrier();
+      if (tid < NRED) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
+        store_agent(A.partials + (int64_t)tile * NRED + tid, s);
+      }
     }
   }
   if constexpr (FUSED) {
@@ -865,7 +933,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     const long long E0 = S_E(lsA), E1 = S_E(nsec);
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
-      if (!mine(a)) return;
+      if (!mine(PC_ITEM(St::IT_D + a))) return;
       constexpr int Da = St::D(a), Ca = St::C(a);
       const double Wd = sc[St::O_WD + a];
       // local offset of row (section ls, row j) inside the run: rows before it in the tile
@@ -938,6 +1006,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
 
+  // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
+  if constexpr (NRED > 0 && !FUSED) {
+    lds_barrier();
+    if (tid < NRED) {
+      const int nw = (TB + 63) >> 6;
+      double s = 0.0;
+      for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
+      A.partials[(int64_t)tile * NRED + tid] = s;
+    }
+  }
   STAMP(7);
   if (A.dbg_stage == 6) return;
   if constexpr (FUSED) {
@@ -954,6 +1032,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
   }
 }
+#undef PC_ITEM
 
 // ---------------------------------------------------------------------------------------------
 // tail kernel pieces (one workgroup)

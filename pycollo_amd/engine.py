@@ -42,7 +42,7 @@ class _PhaseDesc(C.Structure):
                 ("K", C.c_int32), ("n_k", _i32p), ("h_k", _f64p),
                 ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
-                ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32)]
+                ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("eval_ops", C.c_int32)]
 
 
 class _ProblemDesc(C.Structure):
@@ -206,6 +206,7 @@ class NlpEngine:
             d.n_hess, d.hess_row, d.hess_col = len(hr), _ptr(hr, _i32p), _ptr(hc, _i32p)
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
             d.compiled_order = self.orders[i] if self.device >= 0 else 0
+            d.eval_ops = pm.eval_ops
         pt = m.point
         pp = _i32([v.phase for v in pt.vars])
         pk = _i32([_KIND[v.kind] for v in pt.vars])

@@ -67,6 +67,13 @@ class PhaseModel:
     y_tF_bounds: list[tuple[float, float]] = field(default_factory=list)
 
     @property
+    def eval_ops(self) -> int:
+        """Arithmetic operations in the node functions and their derivatives (before common-subexpression
+        elimination): a size measure of the model, used as a launch-shape hint only."""
+        exprs = list(self.f) + list(self.p) + list(self.g) + [e for _, _, e in self.jac] + [e for _, _, e in self.hess]
+        return int(sum(int(sym.count_ops(e)) for e in exprs))
+
+    @property
     def n_z(self) -> int:
         return self.n_y + self.n_u
 
