@@ -188,10 +188,13 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("namespace gen {")
     parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase, then the endpoint block")
     parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a) {")
+    parts.append("    pc::PointIn<Point> pin;")
+    parts.append("    pc::tail_point_load<Point>(a, pin);")
     parts.append("    pc::tail_begin(a);")
     for pm in model.phases:
         parts.append(f"    pc::tail_phase<Phase{pm.index}>(a, {pm.index});")
-    parts.append("    pc::tail_point<Point>(a);")
+    parts.append("    pc::tail_point<Point>(a, pin);")
+    parts.append("    pc::tail_end(a);")
     parts.append("  }")
     parts.append("};")
     parts.append("}  // namespace gen\n")

@@ -59,6 +59,7 @@ struct PcPhaseArgs {
 };
 
 #define PC_MAX_PHASES 8
+#define PC_TAIL_OWNED_MAX 1024   // Hessian entries the tail accumulates in LDS
 #define PC_SYNC_SHARDS 64   // arrival counters of the fused tail, one 64-B line each, plus the top counter
 
 struct PcTailPhase {
@@ -67,6 +68,7 @@ struct PcTailPhase {
   int64_t x_off, s_off, c_int_off;
   int64_t gq_base[8];      // CSR offset of the q column of every integral row (then t, s follow)
   const int64_t* hsum_slot;  // [2*NS] (t_j, s_l) slots then [NS*(NS+1)/2] (s_l, s_l') slots; -1 absent
+  const int32_t* hsum_local; // same shape: index of the slot in tail_owned (the tail accumulates in LDS)
   double t_fixed[2];
   int32_t n_tiles, N;
 };
@@ -86,6 +88,8 @@ struct PcTailArgs {
   const double* W_end;          // [n_b]
   const int64_t* tail_owned;    // [n_tail_owned] H slots written by the tail only (zeroed first)
   const int64_t* pt_hslot;      // [n_pt_hess] H slot of every endpoint Hessian entry
+  const int32_t* pt_hlocal;     // [n_pt_hess] its index in tail_owned, or -1: the slot belongs to an edge node of
+                                //   the bulk kernels and the endpoint term is added to the value they wrote
   int64_t c_end_off;            // first endpoint row of c
   int64_t g_end_base;           // CSR offset of the first endpoint row of G
   int32_t n_tail_owned, flags;

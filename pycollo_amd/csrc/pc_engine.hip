@@ -115,6 +115,7 @@ struct PhaseDev {
   DevBuf<int32_t> tile_k0, tile_n0, sec_s;
   DevBuf<double> sec_h, scal, partials, tab;
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
+  DevBuf<int32_t> hsum_local;
   DevBuf<long long> dbg;
   int uni_n = 0, spt = 0, lds_out = 0;
   int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
@@ -180,6 +181,7 @@ struct pc_handle {
   std::vector<std::unique_ptr<PhaseDev>> pd;
   DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
+  DevBuf<int32_t> d_pt_hlocal;
   DevBuf<unsigned> d_sync;   // arrival counters of the fused tail (zero between launches)
   bool allow_fuse = false;   // PYCOLLO_AMD_FUSE=1 folds the tail into the last bulk launch (experimental:
                              // measured no faster than two launches on MI355X)
@@ -214,6 +216,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.W_end = h->d_Wend.p;
   t.tail_owned = h->d_tail_owned.p;
   t.pt_hslot = h->d_pt_hslot.p;
+  t.pt_hlocal = h->d_pt_hlocal.p;
   t.c_end_off = Q.c_end_off;
   t.g_end_base = Q.g_end_base;
   t.n_tail_owned = (int32_t)Q.tail_owned.size();
@@ -229,6 +232,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
     tp.c_int_off = P.c_int_off;
     for (int m = 0; m < 8; ++m) tp.gq_base[m] = P.gq_base[m];
     tp.hsum_slot = D.hsum_slot.p;
+    tp.hsum_local = D.hsum_local.p;
     tp.t_fixed[0] = P.t_fixed[0];
     tp.t_fixed[1] = P.t_fixed[1];
     tp.n_tiles = D.n_tiles;
@@ -488,6 +492,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->TB = TB;
     if (const char* env = std::getenv("PYCOLLO_AMD_DBG_STAGE")) h->dbg_stage = std::atoi(env);
     pcp::build_all(Q, TB);
+    if (Q.tail_owned.size() > PC_TAIL_OWNED_MAX)
+      throw std::runtime_error("too many Hessian entries owned by the tail kernel (static parameters / endpoint terms)");
     for (auto& P : Q.ph)
       for (int k = 0; k < P.K; ++k)
         if (h->qa_off[P.n_k[k]] < 0) throw std::runtime_error("no quadrature table for a section order in use");
@@ -578,6 +584,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.hslot0.upload(P.hslot0);
       D.hslotN.upload(P.hslotN);
       D.hsum_slot.upload(P.hsum_slot);
+      D.hsum_local.upload(P.hsum_local);
       D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
       if (h->dbg_stage == 9) D.dbg.alloc((size_t)16 * D.n_tiles);
     }
@@ -586,6 +593,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->d_point_x.upload(Q.point_x);
     h->d_tail_owned.upload(Q.tail_owned);
     h->d_pt_hslot.upload(Q.pt_hslot);
+    h->d_pt_hlocal.upload(Q.pt_hlocal);
     h->d_g_indptr.upload(Q.g_indptr);
     const size_t nG = Q.g_row.size(), nH = Q.h_row.size();
     h->d_x.alloc(Q.num_x); h->d_lam.alloc(Q.num_c); h->d_c.alloc(Q.num_c);

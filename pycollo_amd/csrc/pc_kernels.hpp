@@ -1037,10 +1037,23 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 // ---------------------------------------------------------------------------------------------
 // tail kernel pieces (one workgroup)
 // ---------------------------------------------------------------------------------------------
+// Hessian entries only the tail writes (sums over tiles, endpoint terms that meet no node block) are accumulated
+// in LDS and stored once: no zero-fill of global memory to drain, no read-modify-write round trips.
+__device__ __forceinline__ double* tail_acc() {
+  __shared__ double s_acc[PC_TAIL_OWNED_MAX];
+  return s_acc;
+}
 __device__ __forceinline__ void tail_begin(const PcTailArgs& A) {
+  double* acc = tail_acc();
   if (A.flags & PC_FLAG_H)
-    for (int i = threadIdx.x; i < A.n_tail_owned; i += blockDim.x) A.H[A.tail_owned[i]] = 0.0;
-  __syncthreads();
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += blockDim.x) acc[i] = 0.0;
+  lds_barrier();
+}
+__device__ __forceinline__ void tail_end(const PcTailArgs& A) {
+  const double* acc = tail_acc();
+  lds_barrier();
+  if (A.flags & PC_FLAG_H)
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += blockDim.x) A.H[A.tail_owned[i]] = acc[i];
 }
 
 // Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.
@@ -1053,6 +1066,28 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
     __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
     const int tid = threadIdx.x, TB = blockDim.x;  // 1 to 4 waves (64 .. 256 threads)
+    // lane 0's own inputs are requested before the partial sums so that the two round trips overlap
+    const double* sc = P.scal;
+    const int N = P.N;
+    const int64_t q_off = P.x_off + (int64_t)NZ * N, t_off = q_off + NQ;
+    double xt[2] = {0.0, 0.0}, vt[2] = {0.0, 0.0}, rt[2] = {0.0, 0.0}, xq[NQ > 0 ? NQ : 1], wi[NQ > 0 ? NQ : 1];
+    double vq[NQ > 0 ? NQ : 1], rq[NQ > 0 ? NQ : 1], vs[NS > 0 ? NS : 1];
+    if (tid == 0) {
+      static_for<0, NT>([&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        xt[j] = A.x[t_off + j];
+        vt[j] = sc[St::O_VT + j];
+        rt[j] = sc[St::O_RT + j];
+      });
+      static_for<0, NQ>([&](auto m_) {
+        constexpr int m = decltype(m_)::value;
+        xq[m] = A.x[q_off + m];
+        wi[m] = sc[St::O_WI + m];
+        vq[m] = sc[St::O_VQ + m];
+        rq[m] = sc[St::O_RQ + m];
+      });
+      static_for<0, NS>([&](auto l_) { vs[decltype(l_)::value] = sc[St::O_VS + decltype(l_)::value]; });
+    }
     double acc[NRED];
     static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
     for (int b = tid; b < P.n_tiles; b += TB)
@@ -1062,45 +1097,43 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
       const double w = wave_sum(acc[r]);
       if ((tid & 63) == 0) s_part[r * 4 + (tid >> 6)] = w;
     });
-    __syncthreads();
-    if (tid < NRED) {
-      const int nw = (TB + 63) >> 6;
-      double tot = s_part[tid * 4];
-      for (int w = 1; w < nw; ++w) tot += s_part[tid * 4 + w];
-      s_sum[tid] = tot;
-    }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
-      const double* sc = P.scal;
-      const int N = P.N;
+      const int nw = (TB + 63) >> 6;
+      static_for<0, NRED>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        double tot = s_part[r * 4];
+        for (int w = 1; w < nw; ++w) tot += s_part[r * 4 + w];
+        s_sum[r] = tot;
+      });
+      double* hacc = tail_acc();
       double t0 = P.t_fixed[0], tF = P.t_fixed[1], dst[2] = {0.0, 0.0};
-      const int64_t q_off = P.x_off + (int64_t)NZ * N, t_off = q_off + NQ;
       int j = 0;
       if constexpr (M::T0_FREE) {
-        t0 = sc[St::O_VT + j] * A.x[t_off + j] + sc[St::O_RT + j];
-        dst[j] = -0.5 * sc[St::O_VT + j];
+        t0 = vt[j] * xt[j] + rt[j];
+        dst[j] = -0.5 * vt[j];
         ++j;
       }
       if constexpr (M::TF_FREE) {
-        tF = sc[St::O_VT + j] * A.x[t_off + j] + sc[St::O_RT + j];
-        dst[j] = 0.5 * sc[St::O_VT + j];
+        tF = vt[j] * xt[j] + rt[j];
+        dst[j] = 0.5 * vt[j];
       }
       const double stretch = 0.5 * (tF - t0);
       static_for<0, NQ>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
         constexpr int r = NY + NP + m;
-        const double Wi = sc[St::O_WI + m];
+        const double Wi = wi[m];
         if (A.flags & PC_FLAG_C) {
-          const double q = sc[St::O_VQ + m] * A.x[q_off + m] + sc[St::O_RQ + m];
+          const double q = vq[m] * xq[m] + rq[m];
           A.c[P.c_int_off + m] = Wi * (q - stretch * s_sum[St::R_Q + m]);
         }
         if (A.flags & PC_FLAG_G) {
           int64_t o = P.gq_base[m];
-          A.G[o++] = Wi * sc[St::O_VQ + m];
+          A.G[o++] = Wi * vq[m];
           static_for<0, NT>([&](auto jt_) { A.G[o++] = -Wi * dst[decltype(jt_)::value] * s_sum[St::R_Q + m]; });
           static_for<0, NS>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
-            if constexpr (St::dep(r, NZ + l)) A.G[o++] = -Wi * stretch * sc[St::O_VS + l] * s_sum[St::R_QS + m * NS + l];
+            if constexpr (St::dep(r, NZ + l)) A.G[o++] = -Wi * stretch * vs[l] * s_sum[St::R_QS + m * NS + l];
           });
         }
       });
@@ -1110,7 +1143,7 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
           if constexpr (NT > 0 && St::tz(NZ + l)) {
             static_for<0, NT>([&](auto jt_) {
               constexpr int jt = decltype(jt_)::value;
-              A.H[P.hsum_slot[jt * NS + l]] += dst[jt] * sc[St::O_VS + l] * s_sum[St::R_TS + l];
+              hacc[P.hsum_local[jt * NS + l]] += dst[jt] * vs[l] * s_sum[St::R_TS + l];
             });
           }
         });
@@ -1118,55 +1151,80 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
           constexpr int e = decltype(e_)::value;
           if constexpr (M::hc(e) >= NZ) {
             constexpr int l = M::hr(e) - NZ, l2 = M::hc(e) - NZ;
-            A.H[P.hsum_slot[2 * NS + l * (l + 1) / 2 + l2]] += s_sum[St::R_SS + l * (l + 1) / 2 + l2];
+            hacc[P.hsum_local[2 * NS + l * (l + 1) / 2 + l2]] += s_sum[St::R_SS + l * (l + 1) / 2 + l2];
           }
         });
       }
     }
-    __syncthreads();
   }
 }
 
-// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.
+// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  The inputs are fetched
+// by tail_point_load ahead of the phases' sums (their round trips overlap), the block itself runs after them.
 template <class PT>
-__device__ __forceinline__ void tail_point(const PcTailArgs& A) {
+struct PointIn {
+  double xb[PT::NPV > 0 ? PT::NPV : 1], V[PT::NPV > 0 ? PT::NPV : 1], lb[PT::NB > 0 ? PT::NB : 1], We[PT::NB > 0 ? PT::NB : 1];
+  int64_t px[PT::NPV > 0 ? PT::NPV : 1];
+  int64_t hs[PT::NPH > 0 ? PT::NPH : 1];
+  int32_t hl[PT::NPH > 0 ? PT::NPH : 1];
+};
+template <class PT>
+__device__ __forceinline__ void tail_point_load(const PcTailArgs& A, PointIn<PT>& I) {
   if (threadIdx.x != 0) return;
-  constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
-  double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
+  constexpr int NPV = PT::NPV, NB = PT::NB, NPH = PT::NPH;
+  const bool wantH = A.flags & PC_FLAG_H;
+  static_for<0, NPV>([&](auto i_) { I.px[decltype(i_)::value] = A.point_x[decltype(i_)::value]; });
   static_for<0, NPV>([&](auto i_) {
     constexpr int i = decltype(i_)::value;
-    xb[i] = A.point_V[i] * A.x[A.point_x[i]] + A.point_r[i];
+    I.V[i] = A.point_V[i];
+    I.xb[i] = I.V[i] * A.x[I.px[i]] + A.point_r[i];
   });
-  const double sigma = A.sigma, wJ = A.wJ;
-  const bool wantH = A.flags & PC_FLAG_H;
   static_for<0, NB>([&](auto r_) {
     constexpr int r = decltype(r_)::value;
-    lb[r] = wantH ? A.lam[A.c_end_off + r] * A.W_end[r] : 0.0;
+    I.We[r] = A.W_end[r];
+    I.lb[r] = wantH ? A.lam[A.c_end_off + r] * I.We[r] : 0.0;
   });
+  if (wantH)
+    static_for<0, NPH>([&](auto e_) {
+      constexpr int e = decltype(e_)::value;
+      I.hs[e] = A.pt_hslot[e];
+      I.hl[e] = A.pt_hlocal[e];
+    });
+}
+template <class PT>
+__device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT>& I) {
+  if (threadIdx.x != 0) return;
+  constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
+  const double sigma = A.sigma, wJ = A.wJ;
+  const bool wantH = A.flags & PC_FLAG_H;
   double Jval, gJ[NGJ > 0 ? NGJ : 1], b[NB > 0 ? NB : 1], jb[NBJ > 0 ? NBJ : 1], hb[NPH > 0 ? NPH : 1];
-  PT::eval(xb, sigma * wJ, lb, Jval, gJ, b, jb, hb);
+  PT::eval(I.xb, sigma * wJ, I.lb, Jval, gJ, b, jb, hb);
   if (A.fobj) A.fobj[0] = wJ * Jval;
   if (A.grad) {
     static_for<0, NGJ>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      A.grad[A.point_x[PT::gc(e)]] = wJ * gJ[e] * A.point_V[PT::gc(e)];
+      A.grad[I.px[PT::gc(e)]] = wJ * gJ[e] * I.V[PT::gc(e)];
     });
   }
   if (A.flags & PC_FLAG_C)
     static_for<0, NB>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
-      A.c[A.c_end_off + r] = A.W_end[r] * b[r];
+      A.c[A.c_end_off + r] = I.We[r] * b[r];
     });
   if (A.flags & PC_FLAG_G)
     static_for<0, NBJ>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      A.G[A.g_end_base + e] = A.W_end[PT::br(e)] * jb[e] * A.point_V[PT::bc(e)];
+      A.G[A.g_end_base + e] = I.We[PT::br(e)] * jb[e] * I.V[PT::bc(e)];
     });
-  if (wantH)
+  if (wantH) {
+    double* hacc = tail_acc();
     static_for<0, NPH>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      A.H[A.pt_hslot[e]] += hb[e] * A.point_V[PT::phr(e)] * A.point_V[PT::phc(e)];
+      const double val = hb[e] * I.V[PT::phr(e)] * I.V[PT::phc(e)];
+      if (I.hl[e] >= 0) hacc[I.hl[e]] += val;
+      else A.H[I.hs[e]] += val;   // an edge-node entry the bulk kernels wrote: add the endpoint term to it
     });
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

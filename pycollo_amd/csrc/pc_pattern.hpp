@@ -46,6 +46,7 @@ struct Phase {
   int ocp_x_off = 0, ocp_c_off = 0;
   // kernel tables
   std::vector<int64_t> goff, hoff, hslot0, hslotN, hsum_slot;
+  std::vector<int32_t> hsum_local;   // hsum_slot as indices into Problem::tail_owned
   int64_t gq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int32_t> tile_k0;
   int nred = 0;
@@ -83,6 +84,7 @@ struct Problem {
   std::vector<int32_t> g_row, g_col, h_row, h_col;
   int64_t g_end_base = 0;
   std::vector<int64_t> tail_owned, pt_hslot;
+  std::vector<int32_t> pt_hlocal;    // pt_hslot as indices into tail_owned, -1 for slots of the bulk's edge nodes
 };
 
 inline void fail(const std::string& msg) { throw std::runtime_error(msg); }
@@ -459,6 +461,17 @@ inline void build_H(Problem& Q) {
   for (int64_t s : owned)
     if (bulk_edge.count(s)) fail("internal error: Hessian slot has two owners");
   Q.tail_owned.assign(owned.begin(), owned.end());
+  auto local = [&](int64_t slot) -> int32_t {
+    if (slot < 0) return -1;
+    auto it = std::lower_bound(Q.tail_owned.begin(), Q.tail_owned.end(), slot);
+    return (it != Q.tail_owned.end() && *it == slot) ? (int32_t)(it - Q.tail_owned.begin()) : -1;
+  };
+  for (auto& P : Q.ph) {
+    P.hsum_local.clear();
+    for (int64_t sl : P.hsum_slot) P.hsum_local.push_back(local(sl));
+  }
+  Q.pt_hlocal.clear();
+  for (int64_t sl : Q.pt_hslot) Q.pt_hlocal.push_back(local(sl));
 }
 
 inline void build_all(Problem& Q, int TB) {
