@@ -161,6 +161,13 @@ int pc_row_norms_jac(pc_handle* h, const double* x, double* norms);
 int pc_interp_linear(int device, const double* tau_prev, int n_prev, const double* vals_prev, int n_vars,
                      const double* tau_new, int n_new, double* out);
 
+/* Multi-GPU exchange helper (no counterpart in the reference, which is single-process):
+ * copy n_chunks contiguous runs between two device buffers on `stream`; d_chunks = [n_chunks][3] int64
+ * (source offset, destination offset, length <= pc_run_chunk()), all in doubles.  Used to pack one rank's CSR
+ * runs before the all-gather and to unpack the other ranks' runs after it. */
+int pc_copy_runs(const double* d_src, double* d_dst, const int64_t* d_chunks, int64_t n_chunks, void* stream);
+int pc_run_chunk(void);
+
 /* replaces: PattersonRaoMeshRefinement.mesh_error / phase_mesh_error (pycollo/mesh_refinement.py:63-240) with the
  * section polynomial fits of pycollo/solution/solution_abc.py:60-107 folded into per-order tables:
  * for every order n in `orders`, packed back to back, tabB / tabE are (n-1) x n (integral / value of the Lagrange

@@ -163,6 +163,17 @@ __global__ void interp_linear_kernel(const double* __restrict__ tau_prev, int n_
   }
 }
 
+// Copy a list of contiguous runs between two device buffers: the pack / unpack step around the all-gather of the
+// section-sharded evaluation (one rank's share of c~, G~, H~ is a handful of CSR runs per state / variable).
+// One workgroup per chunk of at most PC_RUN_CHUNK doubles; chunks[3*i .. 3*i+2] = (src offset, dst offset, length).
+#define PC_RUN_CHUNK 2048
+__global__ void copy_runs_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                 const int64_t* __restrict__ chunks) {
+  const int64_t so = chunks[3 * (int64_t)blockIdx.x], d0 = chunks[3 * (int64_t)blockIdx.x + 1];
+  const int len = (int)chunks[3 * (int64_t)blockIdx.x + 2];
+  for (int i = threadIdx.x; i < len; i += blockDim.x) dst[d0 + i] = src[so + i];
+}
+
 }  // namespace
 
 struct pc_handle {
@@ -909,6 +920,17 @@ int pc_interp_linear(int device, const double* tau_prev, int n_prev, const doubl
     HIP_OK(hipMemcpy(out, d_out.p, sizeof(double) * (size_t)n_vars * n_new, hipMemcpyDeviceToHost));
   });
 }
+
+int pc_copy_runs(const double* d_src, double* d_dst, const int64_t* d_chunks, int64_t n_chunks, void* stream) {
+  return guarded([&] {
+    if (n_chunks <= 0) return;
+    if (!d_src || !d_dst || !d_chunks) throw std::runtime_error("null argument");
+    hipLaunchKernelGGL(copy_runs_kernel, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, d_src, d_dst, d_chunks);
+    HIP_OK(hipGetLastError());
+  });
+}
+
+int pc_run_chunk(void) { return PC_RUN_CHUNK; }
 
 int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const int32_t* orders, const double* tabB,
                   const double* tabE, const double* tabA, double* max_rel, double* max_abs) {

@@ -108,6 +108,8 @@ def load_library() -> C.CDLL:
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_interp_linear.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
+    lib.pc_copy_runs.argtypes = [vp, vp, vp, C.c_int64, vp]
+    lib.pc_run_chunk.argtypes = []
     lib.pc_mesh_error.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.pc_stream.argtypes = [vp]
     lib.pc_stream.restype = vp

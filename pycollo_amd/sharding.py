@@ -112,40 +112,86 @@ class ShardPlan:
         self.maxlen = max(self.lengths) if self.lengths else 0
 
 
+def _chunk_table(runs, chunk: int) -> np.ndarray:
+    """[(src offset, dst offset, length)] of contiguous runs, cut into pieces of at most ``chunk`` elements."""
+    out = []
+    for so, do, n in runs:
+        for o in range(0, n, chunk):
+            out.append((so + o, do + o, min(chunk, n - o)))
+    return np.asarray(out, dtype=np.int64).reshape(-1, 3)
+
+
 class SegmentExchange:
-    """pack -> all_gather_into_tensor -> unpack on one combined buffer; torch ops only."""
+    """pack -> all_gather_into_tensor -> unpack on one combined buffer.
+
+    On GPU tensors over RCCL the pack and the unpack are one launch each of the library's run-copy kernel
+    (``pc_copy_runs``): a rank's share is a handful of contiguous runs, so no index arrays are read; the pack
+    writes straight into this rank's slot of the receive buffer and the all-gather runs in place.  On CPU
+    tensors (gloo, the tests) and in the several-ranks-on-one-GPU rehearsal the same moves are torch index ops."""
 
     def __init__(self, plan: ShardPlan, rank: int, device, group=None):
         import torch
         self.torch = torch
         self.plan, self.rank, self.group = plan, rank, group
         self.world = plan.world
+        self.maxlen = ml = max(plan.maxlen, 1)
         self.idx_me = torch.from_numpy(plan.index[rank]).to(device)
-        self.send = torch.zeros(max(plan.maxlen, 1), dtype=torch.float64, device=device)
-        self.recv = torch.zeros(self.world * max(plan.maxlen, 1), dtype=torch.float64, device=device)
+        self.recv = torch.zeros(self.world * ml, dtype=torch.float64, device=device)
+        self.send = self.recv[rank * ml:(rank + 1) * ml]       # in-place all-gather: my slot of the receive buffer
         src, dst = [], []
         for r in range(self.world):
             if r == rank:
                 continue
-            src.append(np.arange(plan.lengths[r], dtype=np.int64) + r * max(plan.maxlen, 1))
+            src.append(np.arange(plan.lengths[r], dtype=np.int64) + r * ml)
             dst.append(plan.index[r])
         self.unpack_src = torch.from_numpy(np.concatenate(src) if src else np.zeros(0, np.int64)).to(device)
         self.unpack_dst = torch.from_numpy(np.concatenate(dst) if dst else np.zeros(0, np.int64)).to(device)
+        self.lib = None
+        if torch.device(device).type == "cuda":
+            from .engine import load_library
+            self.lib = load_library()
+            chunk = int(self.lib.pc_run_chunk())
+            runs, o = [], rank * ml
+            for a, b in plan.segments[rank]:
+                runs.append((a, o, b - a))
+                o += b - a
+            self.pack_tab = torch.from_numpy(_chunk_table(runs, chunk)).to(device)
+            runs = []
+            for r in range(self.world):
+                if r == rank:
+                    continue
+                o = r * ml
+                for a, b in plan.segments[r]:
+                    runs.append((o, a, b - a))
+                    o += b - a
+            self.unpack_tab = torch.from_numpy(_chunk_table(runs, chunk)).to(device)
+
+    def _copy_runs(self, src, dst, tab):
+        if tab.shape[0] == 0:
+            return
+        stream = self.torch.cuda.current_stream().cuda_stream
+        if not self.lib.pc_copy_runs(src.data_ptr(), dst.data_ptr(), tab.data_ptr(), tab.shape[0], stream):
+            raise RuntimeError("pc_copy_runs failed: " + self.lib.pc_last_error().decode())
 
     def run(self, buf):
         import torch.distributed as dist
         torch = self.torch
         n = self.idx_me.numel()
-        if n:
+        rehearsal = buf.is_cuda and dist.get_backend(self.group) == "gloo"
+        if buf.is_cuda:
+            self._copy_runs(buf, self.recv, self.pack_tab)
+        elif n:
             torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
-        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+        if rehearsal:
             # rehearsal only (several ranks sharing one GPU cannot form an RCCL group): stage through the host
             recv = torch.empty(self.recv.shape, dtype=self.recv.dtype)
             dist.all_gather_into_tensor(recv, self.send.cpu(), group=self.group)
             self.recv.copy_(recv)
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        if self.unpack_dst.numel():
+        if buf.is_cuda:
+            self._copy_runs(self.recv, buf, self.unpack_tab)
+        elif self.unpack_dst.numel():
             buf.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
         return buf
 

@@ -312,6 +312,47 @@ def test_sharded_ranks_reassemble_bitwise(built, name, kw, world):
     eng.close()
 
 
+@pytest.mark.parametrize("name,kw,world", [("shuttle", dict(K=300, order=5), 3), ("delta_iii", dict(K=40, order=4), 2)])
+def test_exchange_run_copy_tables(built, name, kw, world):
+    """The GPU pack / unpack of SegmentExchange (pc_copy_runs over run tables) against the index form of the same
+    plan: every rank packs its runs into its slot, the slots are copied between the ranks' receive buffers (what
+    the in-place all-gather does), every rank unpacks -- all ranks must hold the same complete buffer."""
+    import torch
+    from pycollo_amd.sharding import SegmentExchange, ShardPlan
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob)
+    plan = ShardPlan(eng, world)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    truth = torch.from_numpy(rng.normal(size=plan.total)).to(dev)
+    covered = np.zeros(plan.total, bool)
+    for r in range(world):
+        covered[plan.index[r]] = True
+    bufs, exs = [], []
+    for r in range(world):
+        b = torch.full((plan.total,), float("nan"), dtype=torch.float64, device=dev)
+        idx = torch.from_numpy(plan.index[r]).to(dev)
+        b[idx] = truth[idx]                       # what rank r's bulk kernels would have produced
+        bufs.append(b)
+        exs.append(SegmentExchange(plan, r, dev))
+    for r in range(world):
+        exs[r]._copy_runs(bufs[r], exs[r].recv, exs[r].pack_tab)
+    torch.cuda.synchronize()
+    ml = exs[0].maxlen
+    for r in range(world):                        # the all-gather, by hand
+        for q in range(world):
+            exs[r].recv[q * ml:(q + 1) * ml] = exs[q].recv[q * ml:(q + 1) * ml]
+    for r in range(world):
+        exs[r]._copy_runs(exs[r].recv, bufs[r], exs[r].unpack_tab)
+    torch.cuda.synchronize()
+    want = truth.cpu().numpy()
+    for r in range(world):
+        got = bufs[r].cpu().numpy()
+        assert np.array_equal(got[covered], want[covered])
+        assert np.isnan(got[~covered]).all()
+    eng.close()
+
+
 def test_sharded_world1_nccl(built):
     """ShardedNlp end to end with a 1-rank RCCL group (the only group size one GPU allows)."""
     import os
