@@ -352,6 +352,11 @@ __device__ __forceinline__ void store_agent(double* p, double v) {
 // arrival counter (two levels: PC_SYNC_SHARDS shards, then a top counter, so that tens of thousands of
 // workgroups do not serialise on one word); the workgroup whose add completes the count issues ONE
 // agent-scope acquire and then reads with vector loads.  Counters reset themselves for the next launch.
+// Force compile-time evaluation of a structure helper: `constexpr` alone lets the compiler emit the helper's search
+// loop at run time (it did, 134 times in the Delta III kernel), and an array subscripted by such a run-time value
+// is demoted from registers to scratch memory.
+#define PC_CE(expr) (std::integral_constant<int, (expr)>::value)
+
 template <class M, int UN, class TAIL = void>
 __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr) {
   constexpr bool FUSED = !std::is_void<TAIL>::value;
@@ -564,7 +569,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   // section accessors (local index ls counts from section kp)
   auto S_s = [&](int ls) -> int { return uni ? (kp + ls) * (un - 1) : s_s[ls]; };
-  auto S_n = [&](int ls) -> int { return uni ? un : s_s[ls + 1] - s_s[ls] + 1; };
+  // (UN > 0 spelled out: the loops over a section's rows must see a compile-time trip count even when this
+  //  lambda is inlined late -- otherwise they stay rolled and every array they index lands in scratch memory)
+  auto S_n = [&](int ls) -> int { return UN > 0 ? UN : (uni ? un : s_s[ls + 1] - s_s[ls] + 1); };
   auto S_h = [&](int ls) -> double { return s_h[ls]; };
   auto S_E = [&](int ls) -> long long { return uni ? (long long)(kp + ls) * (un - 1) * un : s_E[ls]; };
 
@@ -711,7 +718,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       s_yu[a * TN + t] = v[a];
       static_for<0, NS>([&](auto l_) {
         constexpr int l = decltype(l_)::value;
-        if constexpr (St::dep(a, NZ + l)) s_fs[St::fs_slot(a, l) * TN + t] = Jv[St::jidx(a, NZ + l)];
+        if constexpr (PC_CE(St::dep(a, NZ + l))) s_fs[PC_CE(St::fs_slot(a, l)) * TN + t] = Jv[PC_CE(St::jidx(a, NZ + l))];
       });
     });
   }
@@ -723,7 +730,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   double accf[NY > 0 ? NY : 1];
   const bool rowthr = active && t >= 1;
   if (rowthr && (wantC || wantG)) {
-    const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
+    const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
     const double h = S_h(ls_r);
     const double* Arow = s_qa + s_off[n] + (j - 1) * n;
     static_for<0, NY>([&](auto a_) {
@@ -749,19 +756,19 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   static_for<0, NP>([&](auto m_) {
     constexpr int m = decltype(m_)::value;
     constexpr int r = NY + m;
-    constexpr int R = St::nzdep(r) + St::nsdep(r);
+    constexpr int R = PC_CE(St::nzdep(r)) + PC_CE(St::nsdep(r));
     const double Wp = sc[St::O_WP + m];
     if (owns && wantC && mine(PC_ITEM(St::IT_P + m))) A.c[A.c_path_off + (int64_t)m * N + node] = Wp * F[r];
     if (wantG && R > 0 && mine(PC_ITEM(St::IT_P + m))) {
       if (owns) {
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
-          if constexpr (St::dep(r, b)) s_out[t * R + St::zrank(r, b)] = Wp * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
+          if constexpr (PC_CE(St::dep(r, b))) s_out[t * R + PC_CE(St::zrank(r, b))] = Wp * sc[St::O_VZ + b] * Jv[PC_CE(St::jidx(r, b))];
         });
         static_for<0, NS>([&](auto l_) {
           constexpr int l = decltype(l_)::value;
-          if constexpr (St::dep(r, NZ + l))
-            s_out[t * R + St::nzdep(r) + St::srank(r, l)] = Wp * sc[St::O_VS + l] * Jv[St::jidx(r, NZ + l)];
+          if constexpr (PC_CE(St::dep(r, NZ + l)))
+            s_out[t * R + PC_CE(St::nzdep(r)) + PC_CE(St::srank(r, l))] = Wp * sc[St::O_VS + l] * Jv[PC_CE(St::jidx(r, NZ + l))];
         });
       }
       stage_sync();
@@ -778,14 +785,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       red[St::R_Q + m] = w_node * F[r];
       static_for<0, NS>([&](auto l_) {
         constexpr int l = decltype(l_)::value;
-        if constexpr (St::dep(r, NZ + l)) red[St::R_QS + m * NS + l] = w_node * Jv[St::jidx(r, NZ + l)];
+        if constexpr (PC_CE(St::dep(r, NZ + l))) red[St::R_QS + m * NS + l] = w_node * Jv[PC_CE(St::jidx(r, NZ + l))];
       });
       if (wantG && mine(PC_ITEM(St::IT_Q + m))) {
         const double k = -sc[St::O_WI + m] * stretch * w_node;
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
-          if constexpr (St::dep(r, b))
-            A.G[goff[St::GO_Q + m] + (int64_t)St::zrank(r, b) * N + node] = k * sc[St::O_VZ + b] * Jv[St::jidx(r, b)];
+          if constexpr (PC_CE(St::dep(r, b)))
+            A.G[goff[St::GO_Q + m] + (int64_t)PC_CE(St::zrank(r, b)) * N + node] = k * sc[St::O_VZ + b] * Jv[PC_CE(St::jidx(r, b))];
         });
       }
     });
@@ -798,21 +805,21 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
     static_for<0, NZ>([&](auto rv_) {
       constexpr int rv = decltype(rv_)::value;
-      constexpr int MB = St::hrow_count(rv);
+      constexpr int MB = PC_CE(St::hrow_count(rv));
       if constexpr (MB > 0) if (mine(PC_ITEM(St::IT_HB + rv))) {
         double vals[MB];
         static_for<0, NH>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
           if constexpr (M::hr(e) == rv)
-            vals[St::hpos(e)] = sc[St::O_VZ + rv] * sc[St::O_VZ + M::hc(e)] * Hv[e];
+            vals[PC_CE(St::hpos(e))] = sc[St::O_VZ + rv] * sc[St::O_VZ + M::hc(e)] * Hv[e];
         });
         if (owns && (edge0 || edgeN)) {   // edge rows may interleave endpoint entries: explicit slots
           static_for<0, NH>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr (M::hr(e) == rv)
               {
-                double* dstp = A.H + (edge0 ? A.hslot0 : A.hslotN)[St::hzz_index(e)];
-                if constexpr (FUSED) store_agent(dstp, vals[St::hpos(e)]); else *dstp = vals[St::hpos(e)];
+                double* dstp = A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))];
+                if constexpr (FUSED) store_agent(dstp, vals[PC_CE(St::hpos(e))]); else *dstp = vals[PC_CE(St::hpos(e))];
               }
           });
         }
@@ -848,11 +855,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       if constexpr (NT > 0) {
         static_for<0, NV>([&](auto c_) {
           constexpr int cvar = decltype(c_)::value;
-          if constexpr (St::tz(cvar)) {
+          if constexpr (PC_CE(St::tz(cvar))) {
             double acc = 0.0;
             static_for<0, NFN>([&](auto r_) {
               constexpr int r = decltype(r_)::value;
-              if constexpr (!(r >= NY && r < NY + NP) && St::dep(r, cvar)) acc += mu[r] * Jv[St::jidx(r, cvar)];
+              if constexpr (!(r >= NY && r < NY + NP) && PC_CE(St::dep(r, cvar))) acc += mu[r] * Jv[PC_CE(St::jidx(r, cvar))];
             });
             if constexpr (cvar < NZ) {
               if (mine(PC_ITEM(St::IT_HT + cvar))) static_for<0, NT>([&](auto j_) {
@@ -878,7 +885,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if constexpr (NRED > 0) {
     static_for<0, NRED>([&](auto r_) {   // replicas hold copies: the owner of the sum's item contributes
       constexpr int r = decltype(r_)::value;
-      if (!mine(PC_ITEM(St::red_item(r)))) red[r] = 0.0;
+      if (!mine(PC_ITEM(PC_CE(St::red_item(r))))) red[r] = 0.0;
     });
     const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
     static_for<0, NRED>([&](auto r_) {
@@ -949,9 +956,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         const double WS = Wd * stretch, WV = Wd * sc[St::O_VZ + a];
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
-          if constexpr (St::dep(a, b)) js[St::ndep_before(a, b)] = WS * (Jv[St::jidx(a, b)] * sc[St::O_VZ + b]);
+          if constexpr (PC_CE(St::dep(a, b))) js[PC_CE(St::ndep_before(a, b))] = WS * (Jv[PC_CE(St::jidx(a, b))] * sc[St::O_VZ + b]);
         });
-        auto write_cols = [&](int ls, int pos, int n, const double* cc) {
+        auto write_cols = [&](int ls, int pos, int n_in, const double* cc) {
+          const int n = UN > 0 ? UN : n_in;
           const double h = HOIST ? 0.0 : S_h(ls);
           const double* At = s_qa + (HOIST ? 0 : s_off[n]);
 #pragma unroll
@@ -960,16 +968,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
             const int rs = row_off(ls, j, n);
             static_for<0, NZ>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
-              if constexpr (St::dep(a, b)) {
-                constexpr int before = St::ndep_before(a, b);
-                constexpr int extra = (St::own_sparse(a) && a < b) ? 2 : 0;
+              if constexpr (PC_CE(St::dep(a, b))) {
+                constexpr int before = PC_CE(St::ndep_before(a, b));
+                constexpr int extra = (PC_CE(St::own_sparse(a)) && a < b) ? 2 : 0;
                 double val = coef * js[before];
                 if constexpr (a == b) val += WV * ((pos == 0 ? 1.0 : 0.0) - (pos == j ? 1.0 : 0.0));
                 s_out[rs + before * n + extra + pos] = val;
               }
             });
-            if constexpr (St::own_sparse(a)) {
-              const int o = rs + St::ndep_before(a, a) * n;
+            if constexpr (PC_CE(St::own_sparse(a))) {
+              const int o = rs + PC_CE(St::ndep_before(a, a)) * n;
               if (pos == 0) s_out[o] = WV;
               if (pos == j) s_out[o + 1] = -WV;
             }
@@ -977,22 +985,22 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         };
         if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r, cr);
         if (has_start) write_cols(ls_s, 0, n_s, cs);
-        if constexpr (NT + St::nsdep(a) > 0) {
+        if constexpr (NT + PC_CE(St::nsdep(a)) > 0) {
           if (rowthr) {   // t and s columns of this lane's own row
-            const int n = n_r, j = pos_r, sk = S_s(ls_r) - n0;
-            const int rs = row_off(ls_r, j, n) + Da * n + (St::own_sparse(a) ? 2 : 0);
+            const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
+            const int rs = row_off(ls_r, j, n) + Da * n + (PC_CE(St::own_sparse(a)) ? 2 : 0);
             static_for<0, NT>([&](auto jt_) {
               constexpr int jt = decltype(jt_)::value;
               s_out[rs + jt] = Wd * dst[jt] * accf[a];
             });
             static_for<0, NS>([&](auto l_) {
               constexpr int l = decltype(l_)::value;
-              if constexpr (St::dep(a, NZ + l)) {
+              if constexpr (PC_CE(St::dep(a, NZ + l))) {
                 const double* Arow = s_qa + s_off[n] + (j - 1) * n;
                 double as = 0.0;
 #pragma unroll
-                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[St::fs_slot(a, l) * TN + sk + i];
-                s_out[rs + NT + St::srank(a, l)] = Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
+                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
+                s_out[rs + NT + PC_CE(St::srank(a, l))] = Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
               }
             });
           }
@@ -1133,14 +1141,14 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
           static_for<0, NT>([&](auto jt_) { A.G[o++] = -Wi * dst[decltype(jt_)::value] * s_sum[St::R_Q + m]; });
           static_for<0, NS>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
-            if constexpr (St::dep(r, NZ + l)) A.G[o++] = -Wi * stretch * vs[l] * s_sum[St::R_QS + m * NS + l];
+            if constexpr (PC_CE(St::dep(r, NZ + l))) A.G[o++] = -Wi * stretch * vs[l] * s_sum[St::R_QS + m * NS + l];
           });
         }
       });
       if (A.flags & PC_FLAG_H) {
         static_for<0, NS>([&](auto l_) {
           constexpr int l = decltype(l_)::value;
-          if constexpr (NT > 0 && St::tz(NZ + l)) {
+          if constexpr (NT > 0 && PC_CE(St::tz(NZ + l))) {
             static_for<0, NT>([&](auto jt_) {
               constexpr int jt = decltype(jt_)::value;
               hacc[P.hsum_local[jt * NS + l]] += dst[jt] * vs[l] * s_sum[St::R_TS + l];

@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: tools/collect_profiles.sh <tag>      (on the GPU box; writes gpurun_out/profiles_<tag>/)
+# For each workload: rocprofv3 --kernel-trace --stats of the bench command, then FETCH_SIZE and WRITE_SIZE in two
+# separate --pmc passes (kernel-trace only, as the MI355X guide prescribes).  Summaries are collected by
+# tools/summarise_profiles.py into profiles/.
+export TMPDIR=/tmp
+R=$PWD; TAG=${1:-r01}; OUT=$R/gpurun_out/profiles_$TAG; mkdir -p $OUT; cd /tmp
+run() {  # name, bench args...
+  local name=$1; shift
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/stats -- python3 $R/bench.py --no-cpu "$@" > $OUT/$name.stats.log 2>&1 || { echo "$name stats failed"; return 1; }
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$name/$c -- python3 $R/bench.py --no-cpu "$@" > $OUT/$name.$c.log 2>&1 || { echo "$name $c failed"; return 1; }
+  done
+  echo "$name done: $(tail -1 $OUT/$name.stats.log | cut -c1-160)"
+}
+run hypersensitive10k --steps 3000 --warmup 300 &&
+run hypersensitive1M --sections 200000 --steps 50 --warmup 10 &&
+run cart_pole15k --problem cart_pole --sections 5000 --order 4 --steps 1000 --warmup 100 &&
+run shuttle60k --problem shuttle --sections 20000 --order 4 --steps 300 --warmup 30 &&
+run shuttle600k --problem shuttle --sections 200000 --order 4 --steps 50 --warmup 10 &&
+run delta_iii12k --problem delta_iii --sections 3125 --order 5 --steps 100 --warmup 10
