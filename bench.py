@@ -115,8 +115,9 @@ def main():
 
         info = eng.info
         alg_bytes = info["algorithmic_bytes"]
-        workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes "
-                    f"= {eng.layout.phases[0].N} collocation nodes")
+        nph = len(prob.phases)
+        workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {K_total} mesh sections x {args.order} Lobatto nodes "
+                    f"= {eng.layout.phases[0].N} collocation nodes{' per phase' if nph > 1 else ''}")
         extra = {"num_x": eng.num_x, "num_c": eng.num_c, "nnz_jac": eng.nnz_jac, "nnz_hess": eng.nnz_hess,
                  "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"], "waves_per_tile": info["waves_per_tile"],
                  "launches_per_eval": info["n_launches"], "launch_thread_cpu": pinned_cpu}
@@ -147,7 +148,8 @@ def main():
                 raise SystemExit("sharded evaluation differs from the unsharded one")
             ref.close()
         alg_bytes = sh.local_algorithmic_bytes
-        workload = (f"{args.problem}, 1 phase, {K_total} mesh sections x {args.order} Lobatto nodes sharded by "
+        nph = len(prob.phases)
+        workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {K_total} mesh sections x {args.order} Lobatto nodes sharded by "
                     f"section over {world} GPUs ({args.sections} sections = {args.sections * (args.order - 1) + 1} "
                     f"nodes per GPU)")
         extra = {"num_x": sh.num_x, "num_c": sh.num_c, "nnz_jac": sh.nnz_jac, "nnz_hess": sh.nnz_hess,

@@ -202,6 +202,14 @@ def generate_source(model: Model, orders=None) -> str:
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(PcPhaseArgs a) '
                      f'{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a); }}')
+    if len(model.phases) > 1:
+        parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(PcMultiArgs m) {')
+        parts.append("  const int b = blockIdx.x;")
+        for i, pm in enumerate(model.phases):
+            cond = f"if (b < m.first_block[{i + 1}]) " if i + 1 < len(model.phases) else ""
+            parts.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(m.ph[{i}], nullptr, &m, m.first_block[{i}]); return; }}")
+        parts.append("}")
     last = model.phases[-1].index
     parts.append("// last phase with the tail folded in: the last workgroup to arrive finishes the evaluation")
     parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{last}_f(PcPhaseArgs a, PcTailArgs t) '

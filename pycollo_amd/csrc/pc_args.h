@@ -59,6 +59,21 @@ struct PcPhaseArgs {
 };
 
 #define PC_MAX_PHASES 8
+
+// One launch for the bulk kernels of every phase of a multi-phase problem (`pc_bulk_all`): workgroup b belongs to
+// the phase p with first_block[p] <= b < first_block[p + 1] and runs that phase's tile b - first_block[p] +
+// tile_begin.  The per-phase argument blocks live in device memory (they only change with the scaling or the
+// tile ranges); what changes from call to call travels in this small kernarg block.
+struct PcMultiArgs {
+  const double* x;
+  const double* lam;
+  double* c;
+  double* G;
+  double* H;
+  const PcPhaseArgs* ph;                  // [n_phases], device memory
+  int32_t flags, n_phases;
+  int32_t first_block[PC_MAX_PHASES + 1];
+};
 #define PC_TAIL_OWNED_MAX 1024   // Hessian entries the tail accumulates in LDS
 #define PC_SYNC_SHARDS 64   // arrival counters of the fused tail, one 64-B line each, plus the top counter
 

@@ -189,6 +189,10 @@ struct pc_handle {
   hipStream_t stream = nullptr;
   hipModule_t module = nullptr;
   hipFunction_t tail_fn = nullptr;
+  hipFunction_t bulk_all_fn = nullptr;   // multi-phase problems: every phase's bulk kernel in one launch
+  DevBuf<char> d_phase_args;             // [n_phases] PcPhaseArgs read by pc_bulk_all
+  bool args_dirty = true;                // scaling / tile range / partials buffer changed since the last upload
+  int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
   std::vector<std::unique_ptr<PhaseDev>> pd;
   DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
@@ -251,6 +255,58 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   }
 }
 
+// The argument block of one phase's bulk kernel (everything but the per-call pointers and flags when `d_x` is null).
+void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x, const double* d_lam, double* d_c,
+                     double* d_G, double* d_H, int flags, int wpt) {
+  auto& Q = h->Q;
+  auto& P = Q.ph[ip];
+  auto& D = *h->pd[ip];
+  std::memset(&a, 0, sizeof(a));
+  a.x = d_x;
+  a.lam = d_lam;
+  a.c = d_c;
+  a.G = d_G;
+  a.H = d_H;
+  a.tile_k0 = D.tile_k0.p;
+  a.tile_n0 = D.tile_n0.p;
+  a.sec_s = D.sec_s.p;
+  a.sec_h = D.sec_h.p;
+  a.sec_E = D.sec_E.p;
+  a.qa = h->d_qa.p;
+  a.qw = h->d_qw.p;
+  if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
+  for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
+  for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
+  for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
+  a.uni_n = D.uni_n;
+  a.spt = D.spt;
+  a.lds_out = D.lds_out;
+  a.wpt = wpt;
+  a.dbg_stage = h->dbg_stage;
+  a.hslot0 = D.hslot0.p;
+  a.hslotN = D.hslotN.p;
+  a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
+  a.dbg = D.dbg.p;
+  a.sync = h->d_sync.p;
+  a.tab = D.tab.p;
+  a.x_off = P.x_off;
+  a.s_off = Q.s_off;
+  a.c_off = P.c_off;
+  a.c_path_off = P.c_path_off;
+  a.c_int_off = P.c_int_off;
+  a.t_fixed[0] = P.t_fixed[0];
+  a.t_fixed[1] = P.t_fixed[1];
+  a.N = P.N;
+  a.K = P.K;
+  a.n_tiles = D.n_tiles;
+  a.flags = flags;
+  a.tile_begin = D.tile_begin;
+  a.qa_total = (int32_t)h->qa.size();
+  a.qw_total = (int32_t)h->qw.size();
+  std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
+  std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
+}
+
 void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
                 double* d_fobj, double* d_grad, int flags, hipStream_t st, double sigma, bool bulk = true,
                 bool tail = true) {
@@ -260,61 +316,50 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   bool fuse = false;
   if (bulk && tail && h->allow_fuse && (h->dbg_stage == 0 || h->dbg_stage == 9)) {
     auto& D = *h->pd[last];
-    fuse = D.fn_fused && D.tile_begin == 0 && D.tile_end == D.n_tiles && D.n_tiles <= 8192;
+    fuse = !h->bulk_all_fn && D.fn_fused && D.tile_begin == 0 && D.tile_end == D.n_tiles && D.n_tiles <= 8192;
   }
   struct Both {
     PcPhaseArgs a;
     PcTailArgs t;
   };
+  if (bulk && h->bulk_all_fn) {
+    // several phases, one launch: the phases' workgroups run side by side instead of one kernel after another
+    if (h->args_dirty) {
+      std::vector<PcPhaseArgs> blocks(Q.ph.size());
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip)
+        fill_phase_args(h, ip, blocks[ip], nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->wpt_all);
+      HIP_OK(hipDeviceSynchronize());   // no launch in flight may still read the old blocks
+      HIP_OK(hipMemcpy(h->d_phase_args.p, blocks.data(), blocks.size() * sizeof(PcPhaseArgs), hipMemcpyHostToDevice));
+      h->args_dirty = false;
+    }
+    PcMultiArgs m;
+    std::memset(&m, 0, sizeof(m));
+    m.x = d_x;
+    m.lam = d_lam;
+    m.c = d_c;
+    m.G = d_G;
+    m.H = d_H;
+    m.ph = reinterpret_cast<const PcPhaseArgs*>(h->d_phase_args.p);
+    m.flags = flags;
+    m.n_phases = (int32_t)Q.ph.size();
+    int nb = 0;
+    for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+      m.first_block[ip] = nb;
+      nb += std::max(0, h->pd[ip]->tile_end - h->pd[ip]->tile_begin);
+    }
+    for (size_t ip = Q.ph.size(); ip <= PC_MAX_PHASES; ++ip) m.first_block[ip] = nb;
+    if (nb > 0) {
+      size_t sz = sizeof(m);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &m, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      HIP_OK(hipModuleLaunchKernel(h->bulk_all_fn, nb, 1, 1, h->TB * h->wpt_all, 1, 1, h->lds_all, st, nullptr, cfg));
+    }
+    bulk = false;
+  }
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
-    auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
     Both both;
     PcPhaseArgs& a = both.a;
-    std::memset(&a, 0, sizeof(a));
-    a.x = d_x;
-    a.lam = d_lam;
-    a.c = d_c;
-    a.G = d_G;
-    a.H = d_H;
-    a.tile_k0 = D.tile_k0.p;
-    a.tile_n0 = D.tile_n0.p;
-    a.sec_s = D.sec_s.p;
-    a.sec_h = D.sec_h.p;
-    a.sec_E = D.sec_E.p;
-    a.qa = h->d_qa.p;
-    a.qw = h->d_qw.p;
-    if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
-    for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
-    for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
-    for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
-    a.uni_n = D.uni_n;
-    a.spt = D.spt;
-    a.lds_out = D.lds_out;
-    a.wpt = (fuse && ip == last) ? 1 : D.wpt;
-    a.dbg_stage = h->dbg_stage;
-    a.hslot0 = D.hslot0.p;
-    a.hslotN = D.hslotN.p;
-    a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
-    a.dbg = D.dbg.p;
-    a.sync = h->d_sync.p;
-    a.tab = D.tab.p;
-    a.x_off = P.x_off;
-    a.s_off = Q.s_off;
-    a.c_off = P.c_off;
-    a.c_path_off = P.c_path_off;
-    a.c_int_off = P.c_int_off;
-    a.t_fixed[0] = P.t_fixed[0];
-    a.t_fixed[1] = P.t_fixed[1];
-    a.N = P.N;
-    a.K = P.K;
-    a.n_tiles = D.n_tiles;
-    a.flags = flags;
-    a.tile_begin = D.tile_begin;
-    a.qa_total = (int32_t)h->qa.size();
-    a.qw_total = (int32_t)h->qw.size();
-    std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
-    std::memcpy(a.qw_off, h->qw_off, sizeof(a.qw_off));
+    fill_phase_args(h, ip, a, d_x, d_lam, d_c, d_G, d_H, flags, (fuse && ip == last) ? 1 : D.wpt);
     if (D.tile_end <= D.tile_begin) continue;
     if (fuse && ip == last) {
       fill_tail_args(h, both.t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
@@ -562,6 +607,36 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         throw std::runtime_error("too many variables/constraints per phase for the kernel argument block");
     }
     h->n_launches = (int)Q.ph.size() + 1;   // refined after the module is loaded (fused tail: one fewer)
+    // launch shape of the all-phases kernel: the phases share one workgroup size, chosen from the total tile count
+    if (Q.ph.size() > 1) {
+      int total = 0, min_ny = 1 << 30;
+      bool heavy = false;
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+        total += h->pd[ip]->n_tiles;
+        min_ny = std::min(min_ny, Q.ph[ip].n_y);
+        heavy = heavy || Q.ph[ip].eval_ops > 4000;
+      }
+      h->wpt_all = 1;
+      auto lds_for = [&](int w) {
+        int mx = 0;
+        for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+          auto& P = Q.ph[ip];
+          auto& D = *h->pd[ip];
+          mx = std::max(mx, 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, D.nfs, P.nred, D.lds_out * w));
+        }
+        return mx;
+      };
+      if (TB == 64 && !fuse_env) {
+        if (min_ny >= 2 && total <= (heavy ? 512 : 1024)) h->wpt_all = 2;
+        if (min_ny >= 3 && total <= 400) h->wpt_all = 4;
+        if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
+          const int v = std::atoi(env);
+          if (v == 1 || v == 2 || v == 4) h->wpt_all = v;
+        }
+        while (h->wpt_all > 1 && lds_for(h->wpt_all) > h->lds_limit) h->wpt_all /= 2;
+      }
+      h->lds_all = lds_for(h->wpt_all);
+    }
     if (h->device < 0) return;  // structure-only handle
 
     // ---- device side ----------------------------------------------------------------------------
@@ -573,6 +648,15 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_OK(hipModuleLoad(&h->module, d->code_object));
     HIP_OK(hipModuleGetFunction(&h->tail_fn, h->module, d->tail_kernel));
+    if (Q.ph.size() > 1) {
+      bool merge = true;
+      if (const char* env = std::getenv("PYCOLLO_AMD_MERGE")) merge = std::atoi(env) != 0;
+      if (!merge || hipModuleGetFunction(&h->bulk_all_fn, h->module, "pc_bulk_all") != hipSuccess) h->bulk_all_fn = nullptr;
+      if (h->bulk_all_fn) {
+        h->d_phase_args.alloc(Q.ph.size() * sizeof(PcPhaseArgs));
+        h->n_launches = 2;
+      }
+    }
     h->d_qa.upload(h->qa);
     h->d_qw.upload(h->qw);
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
@@ -614,7 +698,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_fobj.alloc(1);
     h->h_grad.alloc(Q.num_x); h->h_norms.alloc(Q.num_c);
     HIP_OK(hipMemset(h->d_lam.p, 0, Q.num_c * sizeof(double)));
-    if (h->allow_fuse && h->pd.back()->fn_fused && h->pd.back()->n_tiles <= 8192) h->n_launches = (int)Q.ph.size();
+    if (!h->bulk_all_fn && h->allow_fuse && h->pd.back()->fn_fused && h->pd.back()->n_tiles <= 8192)
+      h->n_launches = (int)Q.ph.size();
   });
   if (!ok) return 0;
   *out = h.release();
@@ -650,6 +735,7 @@ int pc_get_info(const pc_handle* h, pc_info* info) {
     info->n_launches = h->n_launches;
     info->waves_per_tile = 1;
     for (auto& D : h->pd) info->waves_per_tile = std::max(info->waves_per_tile, (int32_t)D->wpt);
+    if (h->bulk_all_fn) info->waves_per_tile = h->wpt_all;
     info->reserved = 0;
   });
 }
@@ -693,6 +779,7 @@ int pc_set_scaling(pc_handle* h, const double* V, const double* r, const double*
     h->w_J = w_J;
     upload_scaling(h);
     h->scaling_set = true;
+    h->args_dirty = true;
   });
 }
 
@@ -734,6 +821,7 @@ int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end) {
     D.tile_begin = tile_begin;
     D.tile_end = tile_end;
     h->have_cG = false;
+    h->args_dirty = true;
   });
 }
 
@@ -751,6 +839,7 @@ int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials) {
   return guarded([&] {
     if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
     h->pd[phase]->partials_ext = d_partials;
+    h->args_dirty = true;
   });
 }
 

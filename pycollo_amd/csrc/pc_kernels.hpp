@@ -357,20 +357,27 @@ __device__ __forceinline__ void store_agent(double* p, double v) {
 // is demoted from registers to scratch memory.
 #define PC_CE(expr) (std::integral_constant<int, (expr)>::value)
 
+// MA != null: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call
+// pointers and flags come from MA, the workgroup's tile from its index relative to the phase's first block.
 template <class M, int UN, class TAIL = void>
-__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr) {
+__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr, const PcMultiArgs* MA = nullptr,
+                                     int first_block = 0) {
   constexpr bool FUSED = !std::is_void<TAIL>::value;
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
   BulkIn<St> A;
-  A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
+  if (MA) {
+    A.x = MA->x; A.lam = MA->lam; A.c = MA->c; A.G = MA->G; A.H = MA->H;
+  } else {
+    A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
+  }
   A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; A.sec_h = KA.sec_h; A.sec_E = KA.sec_E;
   A.qa = KA.qa; A.qw = KA.qw; A.hslot0 = KA.hslot0; A.hslotN = KA.hslotN; A.partials = KA.partials; A.dbg = KA.dbg;
   A.sync = KA.sync; A.tab = KA.tab;
   A.x_off = KA.x_off; A.s_off = KA.s_off; A.c_off = KA.c_off; A.c_path_off = KA.c_path_off; A.c_int_off = KA.c_int_off;
   A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
-  A.N = KA.N; A.K = KA.K; A.flags = KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
+  A.N = KA.N; A.K = KA.K; A.flags = MA ? MA->flags : KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
   A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
   A.wpt = KA.wpt;
   static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
@@ -434,7 +441,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
   const int N = A.N;
-  const int tile = blockIdx.x + A.tile_begin;
+  const int tile = (int)blockIdx.x - first_block + A.tile_begin;
   if (A.dbg_stage == 1) return;
   // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of every tile
   // stamps s_memtime at the phase boundaries into a buffer of its own
