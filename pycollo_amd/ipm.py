@@ -1,0 +1,366 @@
+"""A compact primal-dual interior-point NLP solver behind the cyipopt ``problem_obj`` protocol.
+
+SURVEY.md section 8f row N3.  The reference hands its callbacks to IPOPT (pycollo/nlp.py:84-115, cyipopt, or
+``ca.nlpsol(..., "ipopt")``, pycollo/backend.py:1681-1711); neither IPOPT nor cyipopt exists in this image, so
+this module stands in for it: it drives *exactly* the callback surface IPOPT would -- ``objective``, ``gradient``,
+``constraints``, ``jacobian`` / ``jacobianstructure``, ``hessian(x, lagrange, obj_factor)`` / ``hessianstructure``
+of :class:`pycollo_amd.engine.PycolloGpuProblem` -- so the end-to-end ``solve()`` objectives of the reference's
+integration tests can be used as tests of the GPU path.
+
+Algorithm: the line-search filter interior-point method of Waechter & Biegler (Math. Program. 106, 2006), the
+method IPOPT implements, without its restoration phase and second-order correction:
+
+  min f(x)  s.t.  c_E(x) = c_E^L,  c_I^L <= c_I(x) <= c_I^U,  x^L <= x <= x^U
+  ->  slacks s for the inequality rows;  barrier  phi_mu = f - mu sum log(v - v^L) - mu sum log(v^U - v);
+  Newton on the primal-dual equations with Sigma = Z^L/(v - v^L) + Z^U/(v^U - v) folded into the (1,1) block,
+  inertia-free regularisation (curvature test on the step), fraction-to-the-boundary rule, filter on
+  (constraint violation, barrier objective), monotone mu update.
+
+The KKT systems are solved on the host with SuperLU (``scipy.sparse.linalg.splu``); row N4 (that solve on the GPU)
+is not started.  Multiplier sign convention: L = obj_factor f + lambda^T c, as IPOPT's ``eval_h`` expects.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+INF = 1e19   # IPOPT's nlp_lower/upper_bound_inf
+
+
+@dataclass
+class IpmResult:
+    x: np.ndarray
+    lam: np.ndarray
+    objective: float
+    status: str
+    iterations: int
+    inf_pr: float
+    inf_du: float
+    mu: float
+    seconds: float
+    evaluations: dict = field(default_factory=dict)
+    history: list = field(default_factory=list)
+
+    @property
+    def success(self) -> bool:
+        return self.status in ("optimal", "acceptable")
+
+
+class InteriorPointSolver:
+    def __init__(self, problem_obj, n: int, m: int, lb, ub, cl, cu, tol: float = 1e-8, acceptable_tol: float = 1e-6,
+                 max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0):
+        self.p, self.n, self.m = problem_obj, int(n), int(m)
+        self.lb, self.ub = np.asarray(lb, float).copy(), np.asarray(ub, float).copy()
+        self.cl, self.cu = np.asarray(cl, float).copy(), np.asarray(cu, float).copy()
+        self.tol, self.acceptable_tol, self.max_iter, self.mu_init, self.verbose = tol, acceptable_tol, max_iter, mu_init, verbose
+        self.eq = np.isclose(self.cl, self.cu, rtol=0, atol=0) | (np.abs(self.cu - self.cl) <= 1e-14 * np.maximum(1.0, np.abs(self.cl)))
+        self.ineq = np.nonzero(~self.eq)[0]
+        self.ns = len(self.ineq)
+        self.nv = self.n + self.ns
+        # bounds on v = [x ; s]
+        self.vl = np.concatenate([self.lb, self.cl[self.ineq]])
+        self.vu = np.concatenate([self.ub, self.cu[self.ineq]])
+        # fixed variables (x^L = x^U: pinned initial states, fixed times) are parameters, as in IPOPT's default
+        # fixed_variable_treatment = make_parameter: no barrier terms, no step components
+        self.fixed = (self.vu - self.vl) <= 1e-12 * np.maximum(1.0, np.abs(self.vl))
+        self.free = np.nonzero(~self.fixed)[0]
+        self.nf = len(self.free)
+        self.hasl = (self.vl > -INF) & ~self.fixed
+        self.hasu = (self.vu < INF) & ~self.fixed
+        jr, jc = problem_obj.jacobianstructure()
+        hr, hc = problem_obj.hessianstructure()
+        self.jr, self.jc = np.asarray(jr, np.int64), np.asarray(jc, np.int64)
+        self.hr, self.hc = np.asarray(hr, np.int64), np.asarray(hc, np.int64)
+        self.hoff = self.hr != self.hc
+        # constant part of the constraint Jacobian w.r.t. the slacks
+        self.Js = sp.csr_matrix((-np.ones(self.ns), (self.ineq, np.arange(self.ns))), shape=(self.m, self.ns))
+        self.rhs_c = np.where(self.eq, self.cl, 0.0)
+        self.counts = {"objective": 0, "gradient": 0, "constraints": 0, "jacobian": 0, "hessian": 0, "factorisations": 0}
+
+    # ---- callbacks --------------------------------------------------------------------------------
+    def _f(self, x):
+        self.counts["objective"] += 1
+        return float(self.p.objective(x))
+
+    def _g(self, x):
+        self.counts["gradient"] += 1
+        return np.asarray(self.p.gradient(x), float)
+
+    def _c(self, v):
+        self.counts["constraints"] += 1
+        c = np.asarray(self.p.constraints(v[:self.n]), float) - self.rhs_c
+        if self.ns:
+            c[self.ineq] -= v[self.n:]
+        return c
+
+    def _J(self, x):
+        self.counts["jacobian"] += 1
+        Jx = sp.csr_matrix((np.asarray(self.p.jacobian(x), float), (self.jr, self.jc)), shape=(self.m, self.n))
+        return sp.hstack([Jx, self.Js], format="csr") if self.ns else Jx
+
+    def _W(self, x, lam):
+        self.counts["hessian"] += 1
+        vals = np.asarray(self.p.hessian(x, lam, 1.0), float)
+        W = sp.coo_matrix((vals, (self.hr, self.hc)), shape=(self.nv, self.nv))
+        Wt = sp.coo_matrix((vals[self.hoff], (self.hc[self.hoff], self.hr[self.hoff])), shape=(self.nv, self.nv))
+        return (W + Wt).tocsr()
+
+    # ---- pieces -----------------------------------------------------------------------------------
+    def _push_interior(self, v, k1=1e-2, k2=1e-2):
+        v = v.copy()
+        pl = np.minimum(k1 * np.maximum(1.0, np.abs(self.vl)), k2 * (self.vu - self.vl))
+        pu = np.minimum(k1 * np.maximum(1.0, np.abs(self.vu)), k2 * (self.vu - self.vl))
+        both = self.hasl & self.hasu
+        onlyl = self.hasl & ~self.hasu
+        onlyu = self.hasu & ~self.hasl
+        v[both] = np.clip(v[both], (self.vl + pl)[both], (self.vu - pu)[both])
+        v[onlyl] = np.maximum(v[onlyl], (self.vl + k1 * np.maximum(1.0, np.abs(self.vl)))[onlyl])
+        v[onlyu] = np.minimum(v[onlyu], (self.vu - k1 * np.maximum(1.0, np.abs(self.vu)))[onlyu])
+        return v
+
+    def _barrier(self, v, f, mu):
+        b = 0.0
+        if self.hasl.any():
+            b -= np.sum(np.log((v - self.vl)[self.hasl]))
+        if self.hasu.any():
+            b -= np.sum(np.log((self.vu - v)[self.hasu]))
+        return f + mu * b
+
+    def _alpha_max(self, v, dv, tau):
+        a = 1.0
+        dl = (v - self.vl)
+        du = (self.vu - v)
+        neg = self.hasl & (dv < 0)
+        if neg.any():
+            a = min(a, float(np.min(-tau * dl[neg] / dv[neg])))
+        pos = self.hasu & (dv > 0)
+        if pos.any():
+            a = min(a, float(np.min(tau * du[pos] / dv[pos])))
+        return a
+
+    @staticmethod
+    def _alpha_dual(z, dz, tau):
+        neg = dz < 0
+        return min(1.0, float(np.min(-tau * z[neg] / dz[neg]))) if neg.any() else 1.0
+
+    def _solve_kkt(self, W, Sigma, J, r1, r2, dw_last):
+        """Solve [[W + Sigma + dw I, J^T], [J, -dc I]] [dv; dlam] = [r1; r2] with the inertia-free curvature test."""
+        nv, m, fr = self.nf, self.m, self.free
+        dw, dc = 0.0, 0.0
+        base = (W + sp.diags(Sigma))[fr][:, fr]
+        J = J[:, fr]
+        r1 = r1[fr]
+        for attempt in range(40):
+            K = sp.bmat([[base + dw * sp.identity(nv), J.T], [J, -dc * sp.identity(m) if dc > 0 else None]], format="csc")
+            self.counts["factorisations"] += 1
+            ok = True
+            try:
+                with np.errstate(all="ignore"):
+                    lu = spla.splu(K)
+                    sol = lu.solve(np.concatenate([r1, r2]))
+                if not np.all(np.isfinite(sol)):
+                    ok = False
+            except RuntimeError:
+                ok = False
+                dc = 1e-8 if dc == 0.0 else dc   # singular: rank-deficient Jacobian
+            if ok:
+                dv, dlam = sol[:nv], sol[nv:]
+                curv = dv @ (base @ dv) + dw * (dv @ dv)
+                if curv >= 1e-11 * (dv @ dv) or dw >= 1e20:
+                    full = np.zeros(self.nv)
+                    full[fr] = dv
+                    return full, dlam, dw
+            # wrong curvature (or singular): raise the primal regularisation, IPOPT's delta_w schedule
+            if dw == 0.0:
+                dw = 1e-4 if dw_last == 0.0 else max(1e-20, dw_last / 3.0)
+            else:
+                dw *= 100.0 if dw_last == 0.0 else 8.0
+            if dw > 1e20:
+                break
+        raise RuntimeError("KKT regularisation failed")
+
+    # ---- main loop --------------------------------------------------------------------------------
+    def solve(self, x0) -> IpmResult:
+        t_start = time.perf_counter()
+        n, nv, m = self.n, self.nv, self.m
+        x0 = np.asarray(x0, float)
+        v = np.concatenate([x0, np.zeros(self.ns)])
+        if self.ns:
+            v[n:] = np.asarray(self.p.constraints(x0), float)[self.ineq]
+        v = self._push_interior(v)
+        v[self.fixed] = self.vl[self.fixed]
+        mu = self.mu_init
+        zl = np.where(self.hasl, 1.0, 0.0)
+        zu = np.where(self.hasu, 1.0, 0.0)
+        f, g = self._f(v[:n]), np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+        c, J = self._c(v), self._J(v[:n])
+        # least-squares multipliers
+        lam = np.zeros(m)
+        try:
+            Jf = J[:, self.free]
+            K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, None]], format="csc")
+            sol = spla.splu(K).solve(np.concatenate([-(g - zl + zu)[self.free], np.zeros(m)]))
+            if m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[self.nf:])) <= 1e3:
+                lam = sol[self.nf:]
+        except RuntimeError:
+            pass
+        filt: list[tuple[float, float]] = []
+        theta0 = float(np.sum(np.abs(c)))
+        theta_max, theta_min = 1e4 * max(1.0, theta0), 1e-4 * max(1.0, theta0)
+        dw_last = 0.0
+        status, hist = "max_iter", []
+        k_eps, k_mu, th_mu, s_max, g_th, g_phi, eta = 10.0, 0.2, 1.5, 100.0, 1e-5, 1e-8, 1e-4
+        accept_count = 0
+        it = 0
+        inf_pr = inf_du = np.inf
+
+        def errors(mu_):
+            dL = (g + J.T @ lam - zl + zu)[self.free]
+            nz = max(1, int(self.hasl.sum() + self.hasu.sum()))
+            sd = max(s_max, (np.sum(np.abs(lam)) + np.sum(zl) + np.sum(zu)) / (m + nz)) / s_max
+            scz = max(s_max, (np.sum(zl) + np.sum(zu)) / nz) / s_max
+            comp = 0.0
+            if self.hasl.any():
+                comp = max(comp, float(np.max(np.abs(((v - self.vl) * zl - mu_)[self.hasl]))))
+            if self.hasu.any():
+                comp = max(comp, float(np.max(np.abs(((self.vu - v) * zu - mu_)[self.hasu]))))
+            e_du = float(np.max(np.abs(dL))) if self.nf else 0.0
+            e_pr = float(np.max(np.abs(c))) if m else 0.0
+            return max(e_du / sd, e_pr, comp / scz), e_pr, e_du
+
+        for it in range(self.max_iter + 1):
+            e0, inf_pr, inf_du = errors(0.0)
+            hist.append((it, f, inf_pr, inf_du, mu))
+            if self.verbose:
+                print(f"{it:4d}  f {f: .8e}  inf_pr {inf_pr:.2e}  inf_du {inf_du:.2e}  lg(mu) {np.log10(mu):5.1f}  dw {dw_last:.1e}")
+            if e0 <= self.tol:
+                status = "optimal"
+                break
+            accept_count = accept_count + 1 if e0 <= self.acceptable_tol else 0
+            if accept_count >= 15:
+                status = "acceptable"
+                break
+            if it == self.max_iter:
+                break
+            while errors(mu)[0] <= k_eps * mu and mu > self.tol / 10:
+                mu = max(self.tol / 10, min(k_mu * mu, mu ** th_mu))
+                filt = []
+            tau = max(0.99, 1.0 - mu)
+            # Newton step
+            dlv, duv = np.where(self.hasl, v - self.vl, 1.0), np.where(self.hasu, self.vu - v, 1.0)
+            Sigma = np.where(self.hasl, zl / dlv, 0.0) + np.where(self.hasu, zu / duv, 0.0)
+            W = self._W(v[:n], lam)
+            grad_phi = g - np.where(self.hasl, mu / dlv, 0.0) + np.where(self.hasu, mu / duv, 0.0)
+            try:
+                dv, dlam, dw_last = self._solve_kkt(W, Sigma, J, -(grad_phi + J.T @ lam), -c, dw_last)
+            except RuntimeError:
+                status = "kkt_failure"
+                break
+            dzl = np.where(self.hasl, mu / dlv - zl - zl / dlv * dv, 0.0)
+            dzu = np.where(self.hasu, mu / duv - zu + zu / duv * dv, 0.0)
+            a_max = self._alpha_max(v, dv, tau)
+            a_z = min(self._alpha_dual(zl[self.hasl], dzl[self.hasl], tau) if self.hasl.any() else 1.0,
+                      self._alpha_dual(zu[self.hasu], dzu[self.hasu], tau) if self.hasu.any() else 1.0)
+            # filter line search
+            theta = float(np.sum(np.abs(c)))
+            phi = self._barrier(v, f, mu)
+            dphi = float(grad_phi @ dv)
+            alpha, accepted = a_max, False
+            a_min = 1e-12
+            while alpha > a_min:
+                vt = v + alpha * dv
+                with np.errstate(all="ignore"):
+                    ft = self._f(vt[:n])
+                    ct = self._c(vt)
+                    th_t = float(np.sum(np.abs(ct)))
+                    phi_t = self._barrier(vt, ft, mu)
+                if np.isfinite(ft) and np.isfinite(th_t) and np.isfinite(phi_t) and th_t <= theta_max:
+                    in_filter = any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt)
+                    if not in_filter:
+                        switching = dphi < 0 and alpha * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min
+                        if switching:
+                            if phi_t <= phi + eta * alpha * dphi:
+                                accepted = True
+                        elif th_t <= (1 - g_th) * theta or phi_t <= phi - g_phi * theta:
+                            accepted = True
+                            filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                        if accepted:
+                            break
+                alpha *= 0.5
+            if not accepted:
+                # feasibility restoration, reduced to its core: Gauss-Newton steps on ||c||_1 (minimum-norm
+                # solution of the linearised constraints, fraction-to-the-boundary, backtracking) until the
+                # violation has dropped by a tenth and the point is acceptable to the filter
+                filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                vr, cr_, Jr, ok_r = v.copy(), c, J, False
+                for _ in range(30):
+                    th_r = float(np.sum(np.abs(cr_)))
+                    Jf = Jr[:, self.free]
+                    try:
+                        self.counts["factorisations"] += 1
+                        K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, -1e-10 * sp.identity(m)]], format="csc")
+                        sol = spla.splu(K).solve(np.concatenate([np.zeros(self.nf), -cr_]))
+                    except RuntimeError:
+                        break
+                    dr = np.zeros(nv)
+                    dr[self.free] = sol[:self.nf]
+                    if not np.all(np.isfinite(dr)):
+                        break
+                    a = self._alpha_max(vr, dr, tau)
+                    moved = False
+                    while a > 1e-10:
+                        vt = vr + a * dr
+                        with np.errstate(all="ignore"):
+                            ct = self._c(vt)
+                        if np.all(np.isfinite(ct)) and float(np.sum(np.abs(ct))) < (1 - 1e-4 * a) * th_r:
+                            vr, cr_, moved = vt, ct, True
+                            break
+                        a *= 0.5
+                    if not moved:
+                        break
+                    Jr = self._J(vr[:n])
+                    th_t = float(np.sum(np.abs(cr_)))
+                    if th_t <= 0.9 * theta:
+                        with np.errstate(all="ignore"):
+                            ft = self._f(vr[:n])
+                            phi_t = self._barrier(vr, ft, mu)
+                        if np.isfinite(phi_t) and not any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt):
+                            ok_r = True
+                            break
+                if not ok_r:
+                    status = "restoration_failed"
+                    break
+                v, c, J, f = vr, cr_, Jr, ft
+                g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+                # multipliers after restoration: least squares, as at the start
+                try:
+                    Jf = J[:, self.free]
+                    K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, None]], format="csc")
+                    sol = spla.splu(K).solve(np.concatenate([-(g - zl + zu)[self.free], np.zeros(m)]))
+                    lam = sol[self.nf:] if m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[self.nf:])) <= 1e3 else np.zeros(m)
+                except RuntimeError:
+                    lam = np.zeros(m)
+                continue
+            v = v + alpha * dv
+            lam = lam + alpha * dlam
+            zl = zl + a_z * dzl
+            zu = zu + a_z * dzu
+            # keep the duals within a factor of the primal estimates
+            ks = 1e10
+            dlv, duv = np.where(self.hasl, v - self.vl, 1.0), np.where(self.hasu, self.vu - v, 1.0)
+            zl = np.where(self.hasl, np.clip(zl, mu / (ks * dlv), ks * mu / dlv), 0.0)
+            zu = np.where(self.hasu, np.clip(zu, mu / (ks * duv), ks * mu / duv), 0.0)
+            f, c = ft, ct
+            g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+            J = self._J(v[:n])
+        return IpmResult(x=v[:n].copy(), lam=lam.copy(), objective=f, status=status, iterations=it, inf_pr=inf_pr,
+                         inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=dict(self.counts), history=hist)
+
+
+def solve_nlp(problem_obj, x0, lb, ub, cl, cu, **options) -> IpmResult:
+    """``ipopt.problem(n, m, problem_obj, lb, ub, cl, cu).solve(x0)`` with the stand-in solver."""
+    return InteriorPointSolver(problem_obj, len(x0), len(cl), lb, ub, cl, cu, **options).solve(x0)

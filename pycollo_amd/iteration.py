@@ -107,6 +107,35 @@ class MeshIteration:
         return ((xb[:, 0] - self.r) / self.V, (xb[:, 1] - self.r) / self.V, W * cb[:, 0], W * cb[:, 1])
 
     # ---- solve -------------------------------------------------------------------------------------
+    def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0):
+        """Solve the scaled NLP with the interior-point stand-in for IPOPT (``pycollo_amd.ipm``), driven through
+        the cyipopt-protocol object exactly as ``ipopt.problem(...).solve(x0)`` would be (pycollo/nlp.py:84-115)."""
+        from .engine import PycolloGpuProblem
+        from .ipm import InteriorPointSolver
+        pobj = PycolloGpuProblem(self.engine)
+        solver = InteriorPointSolver(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
+                                     tol=tol, max_iter=max_iter, verbose=verbose)
+        res = solver.solve(self.guess_x_tilde)
+        self.result = res
+        self.x_tilde = res.x
+        self.objective = res.objective / self.w                                 # scaling.py:186-189
+        return res
+
+    def solution(self):
+        """The NLP point ``x_tilde`` as unscaled (tau, y, u, q, t) per phase and s -- the ``prev`` of the next mesh
+        iteration (pycollo/solution/solution_abc.py:37-58 extraction, pycollo/iteration.py:86-194 consumer)."""
+        x = self.V * self.x_tilde + self.r
+        taus, ys, us, qs, ts = [], [], [], [], []
+        for pm, pl, mesh in zip(self.model.phases, self.layout.phases, self.meshes):
+            N = pl.N
+            z = x[pl.x_off:pl.x_off + pm.n_z * N].reshape(pm.n_z, N)
+            taus.append(np.asarray(mesh.tau, dtype=float))
+            ys.append(z[:pm.n_y].copy())
+            us.append(z[pm.n_y:].copy())
+            qs.append(x[pl.q_off:pl.q_off + pm.n_q].copy())
+            ts.append(x[pl.t_off:pl.t_off + pl.n_t].copy())
+        return taus, ys, us, qs, ts, x[self.layout.s_off:self.layout.s_off + self.layout.n_s].copy()
+
     def solve_with_scipy(self, maxiter: int = 500, tol: float = 1e-9, verbose: int = 0):
         """Solve the scaled NLP with scipy's trust-region interior point method (stand-in for IPOPT)."""
         import scipy.sparse as sp

@@ -334,6 +334,41 @@ def two_phase_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
     return prob
 
 
+def sliding_mass(num_phases: int = 2, K: int = 10, order: int = 4) -> ProblemSpec:
+    """Unit mass slid from x = 0 to x = 1 in minimum time, at rest at both ends, split into ``num_phases`` phases
+    of equal distance with velocity / time continuity as endpoint constraints -- the problem of the reference's
+    multi-phase integration test (tests/integration/test_multiphase.py:25-74; expected objective 0.4472136 =
+    2 / sqrt(20) for every phase count)."""
+    x, v, f = sym.symbols("x v f")
+    MAX_T, MAX_V, MAX_F = 1.0, 10.0, 20.0
+    prob = ProblemSpec(f"{num_phases}-phase sliding mass")
+    for i in range(num_phases):
+        x0, x1 = i / num_phases, (i + 1) / num_phases
+        ph = prob.new_phase("ABCDEFGH"[i])
+        ph.state_variables = [x, v]
+        ph.control_variables = [f]
+        ph.state_equations = [v, f]
+        ph.bounds.initial_time = [0, MAX_T] if i else 0.0
+        ph.bounds.final_time = [0, MAX_T]
+        ph.bounds.initial_state_constraints = {x: x0, v: [0, MAX_V] if i else 0}
+        ph.bounds.state_variables = [[x0, x1], [0, MAX_V]]
+        ph.bounds.final_state_constraints = {x: x1, v: [0, MAX_V] if (i + 1) != num_phases else 0}
+        ph.bounds.control_variables = [[-MAX_F, MAX_F]]
+        ph.guess.time = np.array([x0 * MAX_T, x1 * MAX_T])
+        ph.guess.state_variables = np.array([[x0, x1], [0.0, 0.0]])
+        ph.guess.control_variables = np.array([[0.0, 0.0]])
+        _mesh(ph, K, order)
+    if num_phases >= 2:
+        cons = []
+        for p1, p2 in zip(prob.phases[:-1], prob.phases[1:]):
+            cons.append(p1.final_state_variables[1] - p2.initial_state_variables[1])
+            cons.append(p1.final_time_variable - p2.initial_time_variable)
+        prob.endpoint_constraints = cons
+        prob.bounds.endpoint_constraints = [0] * len(cons)
+    prob.objective_function = prob.phases[-1].final_time_variable
+    return prob
+
+
 REGISTRY = {
     "brachistochrone": brachistochrone,
     "hypersensitive": hypersensitive,
@@ -342,4 +377,5 @@ REGISTRY = {
     "delta_iii": delta_iii,
     "double_pendulum": double_pendulum,
     "two_phase_transfer": two_phase_transfer,
+    "sliding_mass": sliding_mass,
 }

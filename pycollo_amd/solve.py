@@ -1,0 +1,65 @@
+"""The outer solve loop: mesh iteration -> NLP solve -> ph mesh-error estimate -> next mesh.
+
+SURVEY.md section 8f rows N1-N3 put together, i.e. what ``OptimalControlProblem.solve()`` does around the hot
+path (pycollo/optimal_control_problem.py:497-541: ``_solve_iteration`` in a loop until the mesh tolerance is met
+or ``max_mesh_iterations`` is reached; each pass = ``Iteration.solve`` (pycollo/iteration.py:474-526) followed by
+``PattersonRaoMeshRefinement`` (pycollo/mesh_refinement.py:61-392)).  Every NLP callback, the guess interpolation,
+the constraint-scaling row norms and the mesh-error estimate run on the GPU; the NLP solver is the interior-point
+stand-in of ``pycollo_amd.ipm`` (IPOPT is not installed in this image).
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .iteration import MeshIteration
+from .refinement import MESH_TOLERANCE, mesh_error, next_phase_mesh
+
+
+@dataclass
+class OcpResult:
+    objective: float
+    mesh_tolerance_met: bool
+    mesh_iterations: int
+    iterations: list = field(default_factory=list)   # per mesh iteration: dict(K, N, objective, status, nlp_iterations, max_rel_err)
+    final: MeshIteration | None = None
+
+
+def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float = MESH_TOLERANCE, device: int = 0,
+              nlp_tol: float = 1e-8, nlp_max_iter: int = 1000, verbose: int = 0) -> OcpResult:
+    """Solve ``problem`` (a :class:`pycollo_amd.problem.ProblemSpec`) on its initial mesh, refine, repeat."""
+    prob = copy.deepcopy(problem)
+    prev = None
+    log = []
+    it = None
+    met = False
+    for k in range(max_mesh_iterations):
+        it = MeshIteration(prob, device=device, prev=prev)
+        res = it.solve_with_ipm(max_iter=nlp_max_iter, tol=nlp_tol, verbose=max(0, verbose - 1))
+        errs = mesh_error(it.engine, it.x_tilde)
+        worst = max(float(np.max(rel)) for rel, _ in errs)
+        log.append({"K": [int(m.K) for m in it.meshes], "N": [int(pl.N) for pl in it.layout.phases],
+                    "objective": float(it.objective), "status": res.status, "nlp_iterations": int(res.iterations),
+                    "max_rel_err": worst, "seconds": float(res.seconds), "evaluations": dict(res.evaluations)})
+        if verbose:
+            print(f"mesh iteration {k + 1}: K={log[-1]['K']} N={log[-1]['N']} J={it.objective:.10g} "
+                  f"[{res.status}, {res.iterations} NLP iterations, {res.seconds:.2f} s] max rel. mesh error {worst:.3e}", flush=True)
+        if not res.success:
+            break
+        done_all = True
+        new_meshes = []
+        for mesh, (rel, _) in zip(it.meshes, errs):
+            sizes, nodes, done = next_phase_mesh(mesh.sizes, mesh.n, rel, mesh_tol=mesh_tolerance)
+            done_all = done_all and done
+            new_meshes.append((sizes, nodes))
+        if done_all:
+            met = True
+            break
+        prev = it.solution()
+        for ph, (sizes, nodes) in zip(prob.phases, new_meshes):
+            ph.mesh.number_mesh_sections = len(nodes)
+            ph.mesh.mesh_section_sizes = sizes
+            ph.mesh.number_mesh_section_nodes = nodes
+    return OcpResult(objective=float(it.objective), mesh_tolerance_met=met, mesh_iterations=len(log), iterations=log, final=it)

@@ -1,0 +1,48 @@
+"""End-to-end solve() on the GPU path: mesh iteration -> interior-point NLP solve
+through the cyipopt-protocol callbacks -> GPU mesh-error estimate -> refinement, checked against the objectives the
+reference's integration tests assert (tests/integration/test_brachistochrone.py:157-167,
+test_hypersensitive_problem.py:127-137, test_multiphase.py:22,78-84) with the reference's own tolerances."""
+import numpy as np
+import pytest
+
+from pycollo_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def test_brachistochrone_solution(built):
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.brachistochrone())
+    GPOPS_II_SOLUTION = 0.82434
+    assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-4, atol=0.0)
+    assert res.mesh_tolerance_met is True
+    np.testing.assert_allclose(res.objective, 0.8243386694458454, rtol=1e-9)     # tests/unit/test_iteration.py:305-318
+
+
+def test_hypersensitive_solution(built):
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.hypersensitive())
+    GPOPS_II_SOLUTION = 3.36206
+    assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-5, atol=0.0)
+    assert res.mesh_tolerance_met is True
+    assert res.mesh_iterations <= 10                                             # settings.max_mesh_iterations default
+
+
+@pytest.mark.parametrize("num_phases", [1, 2, 3, 4])
+def test_multiphase(built, num_phases):
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.sliding_mass(num_phases))
+    EXPECTED_SOLUTION = 0.4472136
+    assert np.isclose(res.objective, EXPECTED_SOLUTION)
+    assert res.mesh_tolerance_met is True
+
+
+def test_callback_counts_are_reported(built):
+    """The solver goes through PycolloGpuProblem only: every evaluation is a GPU callback and is counted."""
+    from pycollo_amd.iteration import MeshIteration
+    it = MeshIteration(problems.cart_pole(K=20, order=4))
+    res = it.solve_with_ipm()
+    assert res.success, res.status
+    ev = res.evaluations
+    assert ev["hessian"] >= res.iterations and ev["jacobian"] >= res.iterations and ev["objective"] >= res.iterations
+    assert res.inf_pr < 1e-8

@@ -1,0 +1,79 @@
+"""The interior-point stand-in for IPOPT (pycollo_amd/ipm.py) on small analytic NLPs, through the cyipopt
+``problem_obj`` protocol it shares with PycolloGpuProblem.  No GPU: plain NumPy problem objects."""
+import numpy as np
+
+from pycollo_amd.ipm import InteriorPointSolver, solve_nlp
+
+
+class HS071:
+    """Hock-Schittkowski 71 (IPOPT's own tutorial problem): f* = 17.0140173."""
+    n, m = 4, 2
+
+    def objective(self, x):
+        return x[0] * x[3] * (x[0] + x[1] + x[2]) + x[2]
+
+    def gradient(self, x):
+        return np.array([x[3] * (2 * x[0] + x[1] + x[2]), x[0] * x[3], x[0] * x[3] + 1.0, x[0] * (x[0] + x[1] + x[2])])
+
+    def constraints(self, x):
+        return np.array([np.prod(x), np.dot(x, x)])
+
+    def jacobianstructure(self):
+        return np.repeat([0, 1], 4), np.tile(np.arange(4), 2)
+
+    def jacobian(self, x):
+        return np.concatenate([np.prod(x) / x, 2 * x])
+
+    def hessianstructure(self):
+        return np.tril_indices(4)
+
+    def hessian(self, x, lam, s):
+        H = s * np.array([[2 * x[3], 0, 0, 0], [x[3], 0, 0, 0], [x[3], 0, 0, 0], [2 * x[0] + x[1] + x[2], x[0], x[0], 0]], float)
+        H += lam[0] * np.array([[0, 0, 0, 0], [x[2] * x[3], 0, 0, 0], [x[1] * x[3], x[0] * x[3], 0, 0], [x[1] * x[2], x[0] * x[2], x[0] * x[1], 0]], float)
+        H += lam[1] * 2 * np.eye(4)
+        return H[np.tril_indices(4)]
+
+
+def test_hs071():
+    p = HS071()
+    res = solve_nlp(p, np.array([1.0, 5.0, 5.0, 1.0]), np.ones(4), 5 * np.ones(4), np.array([25.0, 40.0]), np.array([2e19, 40.0]))
+    assert res.success, res.status
+    np.testing.assert_allclose(res.objective, 17.0140173, rtol=1e-7)
+    np.testing.assert_allclose(res.x, [1.0, 4.74299963, 3.82114998, 1.37940829], rtol=1e-6)
+    assert res.inf_pr < 1e-8
+
+
+class Rosenbrock:
+    """Unconstrained in c (m = 0) with one fixed variable and one active bound."""
+    n, m = 3, 0
+
+    def objective(self, x):
+        return 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2 + (x[2] - 3.0) ** 2
+
+    def gradient(self, x):
+        return np.array([-400 * x[0] * (x[1] - x[0] ** 2) - 2 * (1 - x[0]), 200 * (x[1] - x[0] ** 2), 2 * (x[2] - 3.0)])
+
+    def constraints(self, x):
+        return np.zeros(0)
+
+    def jacobianstructure(self):
+        return np.zeros(0, int), np.zeros(0, int)
+
+    def jacobian(self, x):
+        return np.zeros(0)
+
+    def hessianstructure(self):
+        return np.array([0, 1, 1, 2]), np.array([0, 0, 1, 2])
+
+    def hessian(self, x, lam, s):
+        return s * np.array([1200 * x[0] ** 2 - 400 * x[1] + 2, -400 * x[0], 200.0, 2.0])
+
+
+def test_bounds_and_fixed_variables():
+    p = Rosenbrock()
+    s = InteriorPointSolver(p, 3, 0, [-2, -2, 1.0], [0.5, 2, 1.0], [], [])
+    res = s.solve(np.array([-1.0, 1.0, 1.0]))
+    assert res.success, res.status
+    assert res.x[2] == 1.0                                  # fixed variable untouched
+    np.testing.assert_allclose(res.x[:2], [0.5, 0.25], atol=1e-6)   # x0 at its upper bound
+    np.testing.assert_allclose(res.objective, 0.25 + 4.0, atol=1e-6)

@@ -1,0 +1,10 @@
+"""Development aid: the outer solve loop (pycollo_amd.solve.solve_ocp) on a registered problem."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pycollo_amd import problems
+from pycollo_amd.solve import solve_ocp
+name = sys.argv[1] if len(sys.argv) > 1 else "brachistochrone"
+kw = eval(sys.argv[2]) if len(sys.argv) > 2 else {}
+t0 = time.time()
+res = solve_ocp(problems.REGISTRY[name](**kw), verbose=1, max_mesh_iterations=int(os.environ.get("MAX_MESH", "10")))
+print(f"{name}: objective {res.objective:.10g}, mesh tolerance met: {res.mesh_tolerance_met}, {res.mesh_iterations} mesh iterations, {time.time() - t0:.1f} s")
