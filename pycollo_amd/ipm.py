@@ -216,6 +216,8 @@ class InteriorPointSolver:
         k_eps, k_mu, th_mu, s_max, g_th, g_phi, eta = 10.0, 0.2, 1.5, 100.0, 1e-5, 1e-8, 1e-4
         accept_count = 0
         it = 0
+        last_alpha = last_amax = 0.0
+        last_tag = ""
         inf_pr = inf_du = np.inf
 
         def errors(mu_):
@@ -236,7 +238,8 @@ class InteriorPointSolver:
             e0, inf_pr, inf_du = errors(0.0)
             hist.append((it, f, inf_pr, inf_du, mu))
             if self.verbose:
-                print(f"{it:4d}  f {f: .8e}  inf_pr {inf_pr:.2e}  inf_du {inf_du:.2e}  lg(mu) {np.log10(mu):5.1f}  dw {dw_last:.1e}")
+                print(f"{it:4d}  f {f: .8e}  inf_pr {inf_pr:.2e}  inf_du {inf_du:.2e}  lg(mu) {np.log10(mu):5.1f}  dw {dw_last:.1e}"
+                      f"  alpha {last_alpha:.2e} (max {last_amax:.2e}){last_tag}")
             if e0 <= self.tol:
                 status = "optimal"
                 break
@@ -335,6 +338,7 @@ class InteriorPointSolver:
                     status = "restoration_failed"
                     break
                 v, c, J, f = vr, cr_, Jr, ft
+                last_alpha, last_amax, last_tag = 0.0, a_max, " R"
                 g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
                 # multipliers after restoration: least squares, as at the start
                 try:
@@ -345,6 +349,7 @@ class InteriorPointSolver:
                 except RuntimeError:
                     lam = np.zeros(m)
                 continue
+            last_alpha, last_amax, last_tag = alpha, a_max, ""
             v = v + alpha * dv
             lam = lam + alpha * dlam
             zl = zl + a_z * dzl
