@@ -265,6 +265,11 @@ __device__ __forceinline__ void lds_barrier() {
 // Cooperative, fully coalesced copy of a staged CSR run from LDS to HBM: 16 B per lane and instruction (1 KiB per
 // wave instruction).  A run starts wherever the CSR layout puts it (8-byte granularity), so lane 0 peels one
 // element when that makes the destination 16-byte aligned; the LDS side is then read as two 8-byte halves.
+#ifdef PC_NT_STORES   // experiment: streaming (non-temporal) stores for the CSR runs
+#define PC_RUN_STORE(p, v) __builtin_nontemporal_store((pc_d2_a16)(v), (p))
+#else
+#define PC_RUN_STORE(p, v) (*(p) = (v))
+#endif
 typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef double pc_d2_a16 __attribute__((ext_vector_type(2), aligned(16)));
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
@@ -285,11 +290,11 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + q * TB));
 #pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)) = a[q];
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)), a[q]);
   }
   for (; e < pairs; e += TB) {
     const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
-    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
+    PC_RUN_STORE(reinterpret_cast<pc_d2_a16*>(dst + 2 * e), a0);
   }
   if ((len & 1) && tid == TB - 1) dst[len - 1] = src[len - 1];
 }

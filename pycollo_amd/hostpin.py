@@ -23,9 +23,9 @@ def _current_cpu() -> int:
 def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int]]:
     """Pin this process to one allowed CPU; returns (cpu, previous affinity mask).
 
-    One rank: the core the thread is running on.  Several ranks on a node: cores spread evenly over the first
-    half of the allowed list (the physical cores on an SMT host), in rank order, which follows the usual
-    GPU-to-NUMA-node order."""
+    One rank: the core the thread is running on.  Several ranks on a node: a slice of up to 8 cores each, spread
+    evenly over the first half of the allowed list (the physical cores on an SMT host) in rank order, which
+    follows the usual GPU-to-NUMA-node order."""
     if not hasattr(os, "sched_setaffinity"):
         return -1, set()
     allowed = sorted(os.sched_getaffinity(0))
@@ -33,11 +33,15 @@ def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int
         cpu = _current_cpu()
         if cpu not in allowed:
             cpu = allowed[0]
-    else:
-        stride = max(1, len(allowed) // (2 * world))
-        cpu = allowed[(local_rank * stride) % len(allowed)]
-    os.sched_setaffinity(0, {cpu})
-    return cpu, set(allowed)
+        os.sched_setaffinity(0, {cpu})
+        return cpu, set(allowed)
+    # several ranks: each gets its own slice of cores rather than one core -- the collective library's helper
+    # threads inherit the mask too and must not queue behind the launching thread
+    stride = max(1, len(allowed) // (2 * world))
+    lo = (local_rank * stride) % len(allowed)
+    mine = set(allowed[lo:lo + min(stride, 8)])
+    os.sched_setaffinity(0, mine)
+    return allowed[lo], set(allowed)
 
 
 def restore_affinity(mask: set[int]) -> None:
