@@ -200,12 +200,15 @@ def main():
         # this process); only quoted when the workload is the one those passes profiled
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
+            with open(latest) as f:
                 pmc = json.load(f)
-            key = f"{args.problem}_K{K_total}_n{args.order}_{args.sections * (args.order - 1) + 1}_nodes"
-            if world == 1 and key in pmc:
-                traffic = pmc[key]["pc_bulk_p0"]["hbm_bytes_per_launch"]
-        except OSError:
+            for entry in pmc.values():
+                if world == 1 and isinstance(entry, dict) and entry.get("workload") == workload:
+                    traffic = sum(k.get("hbm_bytes_per_launch", 0) for name, k in entry["kernels"].items()
+                                  if name.startswith("pc_bulk")) or None
+        except (OSError, IndexError):
             pass
         roofline = {"bound": "hbm", "kernel": "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
