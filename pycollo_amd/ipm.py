@@ -79,32 +79,34 @@ class InteriorPointSolver:
         # constant part of the constraint Jacobian w.r.t. the slacks
         self.Js = sp.csr_matrix((-np.ones(self.ns), (self.ineq, np.arange(self.ns))), shape=(self.m, self.ns))
         self.rhs_c = np.where(self.eq, self.cl, 0.0)
+        self.sf = 1.0                       # IPOPT's gradient-based NLP scaling (set in solve())
+        self.sc = np.ones(self.m)
         self.counts = {"objective": 0, "gradient": 0, "constraints": 0, "jacobian": 0, "hessian": 0, "factorisations": 0}
 
     # ---- callbacks --------------------------------------------------------------------------------
     def _f(self, x):
         self.counts["objective"] += 1
-        return float(self.p.objective(x))
+        return self.sf * float(self.p.objective(x))
 
     def _g(self, x):
         self.counts["gradient"] += 1
-        return np.asarray(self.p.gradient(x), float)
+        return self.sf * np.asarray(self.p.gradient(x), float)
 
     def _c(self, v):
         self.counts["constraints"] += 1
-        c = np.asarray(self.p.constraints(v[:self.n]), float) - self.rhs_c
+        c = self.sc * (np.asarray(self.p.constraints(v[:self.n]), float) - self.rhs_c)
         if self.ns:
-            c[self.ineq] -= v[self.n:]
+            c[self.ineq] -= v[self.n:]      # slacks live in the scaled constraint's units
         return c
 
     def _J(self, x):
         self.counts["jacobian"] += 1
-        Jx = sp.csr_matrix((np.asarray(self.p.jacobian(x), float), (self.jr, self.jc)), shape=(self.m, self.n))
+        Jx = sp.csr_matrix((np.asarray(self.p.jacobian(x), float) * self.sc[self.jr], (self.jr, self.jc)), shape=(self.m, self.n))
         return sp.hstack([Jx, self.Js], format="csr") if self.ns else Jx
 
     def _W(self, x, lam):
         self.counts["hessian"] += 1
-        vals = np.asarray(self.p.hessian(x, lam, 1.0), float)
+        vals = np.asarray(self.p.hessian(x, self.sc * lam, self.sf), float)
         W = sp.coo_matrix((vals, (self.hr, self.hc)), shape=(self.nv, self.nv))
         Wt = sp.coo_matrix((vals[self.hoff], (self.hc[self.hoff], self.hr[self.hoff])), shape=(self.nv, self.nv))
         return (W + Wt).tocsr()
@@ -154,27 +156,50 @@ class InteriorPointSolver:
         base = (W + sp.diags(Sigma))[fr][:, fr]
         J = J[:, fr]
         r1 = r1[fr]
+        rhs = np.concatenate([r1, r2])
         for attempt in range(40):
-            K = sp.bmat([[base + dw * sp.identity(nv), J.T], [J, -dc * sp.identity(m) if dc > 0 else None]], format="csc")
+            # The (2,2) block always carries a tiny -dc I: the matrix is then quasi-definite whenever the (1,1) block
+            # is positive definite, a symmetric-mode LU that pivots on the diagonal exists, and the signs of U's
+            # diagonal are the inertia (Sylvester) -- which is what IPOPT's regularisation is driven by
+            # (n positive, m negative eigenvalues).  SuperLU with diag_pivot_thresh = 0 is that factorisation as
+            # long as it reports the same row and column permutation.
+            dc_eff = max(dc, 1e-9)
+            K = sp.bmat([[base + dw * sp.identity(nv), J.T], [J, -dc_eff * sp.identity(m)]], format="csc")
             self.counts["factorisations"] += 1
-            ok = True
+            good = False
             try:
                 with np.errstate(all="ignore"):
-                    lu = spla.splu(K)
-                    sol = lu.solve(np.concatenate([r1, r2]))
-                if not np.all(np.isfinite(sol)):
-                    ok = False
+                    lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+                    d = lu.U.diagonal()
+                    sym = np.array_equal(lu.perm_r, lu.perm_c)
+                    npos, nneg = int(np.sum(d > 0)), int(np.sum(d < 0))
+                    if sym and npos == nv and nneg == m:
+                        # refine against the system actually wanted (dc, not dc_eff): the tiny (2,2) shift only
+                        # makes the factorisation exist, it must not limit the accuracy of the step
+                        K0 = K if dc_eff == dc else sp.bmat([[base + dw * sp.identity(nv), J.T],
+                                                             [J, -dc * sp.identity(m) if dc > 0 else None]], format="csc")
+                        sol = lu.solve(rhs)
+                        res = rhs - K0 @ sol
+                        for _ in range(3):
+                            trial = sol + lu.solve(res)
+                            res_t = rhs - K0 @ trial
+                            if not np.all(np.isfinite(trial)) or np.linalg.norm(res_t) >= 0.5 * np.linalg.norm(res):
+                                break          # (nearly) singular unshifted system: keep the regularised step
+                            sol, res = trial, res_t
+                        good = bool(np.all(np.isfinite(sol)))
+                    elif not sym:
+                        # off-diagonal pivots were needed: fall back to the curvature test on the step
+                        sol = lu.solve(rhs)
+                        if np.all(np.isfinite(sol)):
+                            dv = sol[:nv]
+                            good = bool(dv @ (base @ dv) + dw * (dv @ dv) >= 1e-11 * (dv @ dv))
             except RuntimeError:
-                ok = False
-                dc = 1e-8 if dc == 0.0 else dc   # singular: rank-deficient Jacobian
-            if ok:
-                dv, dlam = sol[:nv], sol[nv:]
-                curv = dv @ (base @ dv) + dw * (dv @ dv)
-                if curv >= 1e-11 * (dv @ dv) or dw >= 1e20:
-                    full = np.zeros(self.nv)
-                    full[fr] = dv
-                    return full, dlam, dw
-            # wrong curvature (or singular): raise the primal regularisation, IPOPT's delta_w schedule
+                dc = 1e-8 if dc == 0.0 else dc * 10.0
+            if good or dw >= 1e20:
+                full = np.zeros(self.nv)
+                full[fr] = sol[:nv]
+                return full, sol[nv:], dw
+            # wrong inertia / curvature (or singular): raise the primal regularisation, IPOPT's delta_w schedule
             if dw == 0.0:
                 dw = 1e-4 if dw_last == 0.0 else max(1e-20, dw_last / 3.0)
             else:
@@ -188,9 +213,27 @@ class InteriorPointSolver:
         t_start = time.perf_counter()
         n, nv, m = self.n, self.nv, self.m
         x0 = np.asarray(x0, float)
+        # gradient-based scaling at the starting point, IPOPT's default nlp_scaling_method (the reference leaves it
+        # on, pycollo/backend.py:1704-1710): objective and every constraint row are scaled down so that no
+        # gradient entry exceeds nlp_scaling_max_gradient = 100
+        self.sf, self.sc = 1.0, np.ones(m)
+        x0c = np.clip(x0, np.where(self.lb > -INF, self.lb, x0), np.where(self.ub < INF, self.ub, x0))
+        g0 = np.asarray(self.p.gradient(x0c), float)
+        gmax = float(np.max(np.abs(g0))) if n else 0.0
+        if gmax > 100.0:
+            self.sf = max(100.0 / gmax, 1e-8)
+        if m:
+            jv = np.abs(np.asarray(self.p.jacobian(x0c), float))
+            rowmax = np.zeros(m)
+            np.maximum.at(rowmax, self.jr, jv)
+            big = rowmax > 100.0
+            self.sc[big] = np.maximum(100.0 / rowmax[big], 1e-8)
+        if self.ns:
+            self.vl[n:] = np.where(self.cl[self.ineq] > -INF, self.sc[self.ineq] * self.cl[self.ineq], self.cl[self.ineq])
+            self.vu[n:] = np.where(self.cu[self.ineq] < INF, self.sc[self.ineq] * self.cu[self.ineq], self.cu[self.ineq])
         v = np.concatenate([x0, np.zeros(self.ns)])
         if self.ns:
-            v[n:] = np.asarray(self.p.constraints(x0), float)[self.ineq]
+            v[n:] = (self.sc * np.asarray(self.p.constraints(x0), float))[self.ineq]
         v = self._push_interior(v)
         v[self.fixed] = self.vl[self.fixed]
         mu = self.mu_init
@@ -362,7 +405,7 @@ class InteriorPointSolver:
             f, c = ft, ct
             g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
             J = self._J(v[:n])
-        return IpmResult(x=v[:n].copy(), lam=lam.copy(), objective=f, status=status, iterations=it, inf_pr=inf_pr,
+        return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
                          inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=dict(self.counts), history=hist)
 
 

@@ -1,7 +1,8 @@
 """End-to-end solve() on the GPU path: mesh iteration -> interior-point NLP solve
 through the cyipopt-protocol callbacks -> GPU mesh-error estimate -> refinement, checked against the objectives the
 reference's integration tests assert (tests/integration/test_brachistochrone.py:157-167,
-test_hypersensitive_problem.py:127-137, test_multiphase.py:22,78-84) with the reference's own tolerances."""
+test_hypersensitive_problem.py:127-137, test_space_shuttle_reentry_trajectory.py:238-256, test_multiphase.py:22,78-84)
+with the reference's own tolerances."""
 import numpy as np
 import pytest
 
@@ -26,6 +27,16 @@ def test_hypersensitive_solution(built):
     assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-5, atol=0.0)
     assert res.mesh_tolerance_met is True
     assert res.mesh_iterations <= 10                                             # settings.max_mesh_iterations default
+
+
+def test_space_shuttle_solution(built):
+    """BASELINE config 4's model end to end (5 states + altitude-rate... 6 needed states, 2 controls, Betts ex. 6.1)."""
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.shuttle())
+    GPOPS_II_SOLUTION, SOS_SOLUTION = -0.59628, -0.59588
+    assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-3, atol=0.0)
+    assert np.isclose(res.objective, SOS_SOLUTION, rtol=1e-3, atol=0.0)
+    assert res.mesh_tolerance_met is True
 
 
 @pytest.mark.parametrize("num_phases", [1, 2, 3, 4])
