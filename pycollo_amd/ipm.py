@@ -166,7 +166,7 @@ class InteriorPointSolver:
             dc_eff = max(dc, 1e-9)
             K = sp.bmat([[base + dw * sp.identity(nv), J.T], [J, -dc_eff * sp.identity(m)]], format="csc")
             self.counts["factorisations"] += 1
-            good = False
+            good, sol = False, None
             try:
                 with np.errstate(all="ignore"):
                     lu = spla.splu(K, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
@@ -195,7 +195,7 @@ class InteriorPointSolver:
                             good = bool(dv @ (base @ dv) + dw * (dv @ dv) >= 1e-11 * (dv @ dv))
             except RuntimeError:
                 dc = 1e-8 if dc == 0.0 else dc * 10.0
-            if good or dw >= 1e20:
+            if good or (dw >= 1e20 and sol is not None and np.all(np.isfinite(sol))):
                 full = np.zeros(self.nv)
                 full[fr] = sol[:nv]
                 return full, sol[nv:], dw

@@ -212,6 +212,13 @@ def delta_iii(K: int = 10, order: int = 4) -> ProblemSpec:
         ph.bounds.path_constraints = [[0, 0], [0, "inf"]]
         ph.bounds.initial_state_constraints = {m: m_a}
         ph.bounds.final_state_constraints = {m: m_b}
+        # guess: at rest on the pad, mass linear, constant steering (delta_iii_launch_vehicle.py:273-281; the
+        # example's later phases reuse phase B's time span in their guess, here each phase gets its own)
+        vy0 = omega_val * R_E_val * np.cos(psi_L_val)
+        ph.guess.time = np.array([ta, tb])
+        ph.guess.state_variables = np.array([[R_E_val * np.cos(psi_L_val)] * 2, [0.0, 0.0], [R_E_val * np.sin(psi_L_val)] * 2,
+                                             [0.0, 0.0], [vy0, vy0], [0.0, 0.0], [m_a, m_b]], dtype=float)
+        ph.guess.control_variables = np.array([[0.9, 0.9], [0.05, 0.05], [0.45, 0.45]])
         _mesh(ph, K, order)
         phases.append(ph)
     A = phases[0]
