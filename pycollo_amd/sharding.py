@@ -125,8 +125,7 @@ class SegmentExchange:
     """pack -> all_gather_into_tensor -> unpack on one combined buffer.
 
     On GPU tensors over RCCL the pack and the unpack are one launch each of the library's run-copy kernel
-    (``pc_copy_runs``): a rank's share is a handful of contiguous runs, so no index arrays are read; the pack
-    writes straight into this rank's slot of the receive buffer and the all-gather runs in place.  On CPU
+    (``pc_copy_runs``): a rank's share is a handful of contiguous runs, so no index arrays are read.  On CPU
     tensors (gloo, the tests) and in the several-ranks-on-one-GPU rehearsal the same moves are torch index ops."""
 
     def __init__(self, plan: ShardPlan, rank: int, device, group=None):
@@ -137,7 +136,7 @@ class SegmentExchange:
         self.maxlen = ml = max(plan.maxlen, 1)
         self.idx_me = torch.from_numpy(plan.index[rank]).to(device)
         self.recv = torch.zeros(self.world * ml, dtype=torch.float64, device=device)
-        self.send = self.recv[rank * ml:(rank + 1) * ml]       # in-place all-gather: my slot of the receive buffer
+        self.send = torch.zeros(ml, dtype=torch.float64, device=device)
         src, dst = [], []
         for r in range(self.world):
             if r == rank:
@@ -151,7 +150,7 @@ class SegmentExchange:
             from .engine import load_library
             self.lib = load_library()
             chunk = int(self.lib.pc_run_chunk())
-            runs, o = [], rank * ml
+            runs, o = [], 0
             for a, b in plan.segments[rank]:
                 runs.append((a, o, b - a))
                 o += b - a
@@ -179,7 +178,7 @@ class SegmentExchange:
         n = self.idx_me.numel()
         rehearsal = buf.is_cuda and dist.get_backend(self.group) == "gloo"
         if buf.is_cuda:
-            self._copy_runs(buf, self.recv, self.pack_tab)
+            self._copy_runs(buf, self.send, self.pack_tab)
         elif n:
             torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
         if rehearsal:

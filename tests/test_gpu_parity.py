@@ -315,8 +315,8 @@ def test_sharded_ranks_reassemble_bitwise(built, name, kw, world):
 @pytest.mark.parametrize("name,kw,world", [("shuttle", dict(K=300, order=5), 3), ("delta_iii", dict(K=40, order=4), 2)])
 def test_exchange_run_copy_tables(built, name, kw, world):
     """The GPU pack / unpack of SegmentExchange (pc_copy_runs over run tables) against the index form of the same
-    plan: every rank packs its runs into its slot, the slots are copied between the ranks' receive buffers (what
-    the in-place all-gather does), every rank unpacks -- all ranks must hold the same complete buffer."""
+    plan: every rank packs its runs into its send buffer, the buffers are copied into the ranks' receive buffers
+    (what the all-gather does), every rank unpacks -- all ranks must hold the same complete buffer."""
     import torch
     from pycollo_amd.sharding import SegmentExchange, ShardPlan
     prob = problems.REGISTRY[name](**kw)
@@ -336,12 +336,12 @@ def test_exchange_run_copy_tables(built, name, kw, world):
         bufs.append(b)
         exs.append(SegmentExchange(plan, r, dev))
     for r in range(world):
-        exs[r]._copy_runs(bufs[r], exs[r].recv, exs[r].pack_tab)
+        exs[r]._copy_runs(bufs[r], exs[r].send, exs[r].pack_tab)
     torch.cuda.synchronize()
     ml = exs[0].maxlen
     for r in range(world):                        # the all-gather, by hand
         for q in range(world):
-            exs[r].recv[q * ml:(q + 1) * ml] = exs[q].recv[q * ml:(q + 1) * ml]
+            exs[r].recv[q * ml:(q + 1) * ml] = exs[q].send
     for r in range(world):
         exs[r]._copy_runs(exs[r].recv, bufs[r], exs[r].unpack_tab)
     torch.cuda.synchronize()
