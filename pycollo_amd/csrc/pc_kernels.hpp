@@ -439,9 +439,27 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // does this replica produce any Hessian output (and hence need the adjoint node weights)?
   const bool hess_replica = W == 1 || (((W == 2 ? DEAL2.hmask : DEAL4.hmask) >> w) & 1u);
 #define PC_ITEM(i) std::integral_constant<int, (i)>{}
-  auto stage_sync = [&]() {
-    if (W == 1) lds_barrier();
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: LDS ops of a wave complete in order
+  // Synchronisation by who shares the data.  LDS operations of ONE wave complete in program order, so a wave that
+  // hands data to itself through LDS (a one-wave workgroup, or a replica's private staging region) needs no wait
+  // and no barrier at all -- only the compiler must not reorder the accesses (PC_WAVE_FENCE emits nothing).
+  // `one_wave`: the workgroup is a single wave.  `wave_private`: additionally true for replicas (W > 1), for data
+  // every replica writes in full for itself (node values) or keeps to itself (staging).
+#ifndef PC_WAVE_FENCE
+#define PC_WAVE_FENCE() asm volatile("" ::: "memory")
+#endif
+  const bool one_wave = (TB == 64);
+  const bool wave_private = one_wave || W > 1;
+  auto stage_sync = [&]() {       // staging buffer of this tile / replica
+    if (wave_private) PC_WAVE_FENCE();
+    else lds_barrier();
+  };
+  auto block_sync = [&]() {       // data of the whole workgroup (tables staged cooperatively, the overlay hand-over)
+    if (one_wave) PC_WAVE_FENCE();
+    else lds_barrier();
+  };
+  auto node_sync = [&]() {        // per-node values: every replica wrote all of them itself
+    if (wave_private) PC_WAVE_FENCE();
+    else lds_barrier();
   };
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
@@ -565,7 +583,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
   if (!uni) {
-    __syncthreads();
+    block_sync();
     for (int ls = tid; ls < nsec; ls += TB) {
       const int sb = s_s[ls], se = s_s[ls + 1];
       for (int nd = sb + 1; nd <= se; ++nd) {
@@ -575,7 +593,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
     if (tid == 0 && n0 == 0) s_kr[0] = -1;
   }
-  __syncthreads();
+  block_sync();
   STAMP(1);
   if (A.dbg_stage == 2) { if (active && v[0] == 1.2345e300) A.c[0] = v[0]; return; }
 
@@ -734,7 +752,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       });
     });
   }
-  __syncthreads();
+  node_sync();
   STAMP(3);
   if (A.dbg_stage == 3) { if (active && F[0] == 1.2345e300) A.c[0] = F[0]; return; }
 
@@ -757,7 +775,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TN + sk] - v[a]) + stretch * accf[a]);
     });
   }
-  lds_barrier();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
+  block_sync();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
   STAMP(4);
   if (A.dbg_stage == 4) return;
 
@@ -1028,7 +1046,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
   if constexpr (NRED > 0 && !FUSED) {
-    lds_barrier();
+    block_sync();
     if (tid < NRED) {
       const int nw = (TB + 63) >> 6;
       double s = 0.0;
