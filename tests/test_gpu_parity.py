@@ -91,6 +91,20 @@ def test_waves_per_tile_replicas(built, tab, monkeypatch, name, kw):
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,order,K", [("hypersensitive", 20, 7), ("hypersensitive", 13, 11), ("cart_pole", 20, 5),
+                                          ("brachistochrone", 2, 9), ("shuttle", 11, 1)])
+def test_extreme_orders(built, tab, name, order, K):
+    """The largest supported section order (20 nodes, pycollo/quadrature.py order range), orders past the
+    coefficient-hoisting limit, the smallest one (2 nodes: every node is a section boundary) and a single section;
+    both the order-specialised and the any-mesh kernel."""
+    for specialise in (True, False):
+        prob = problems.REGISTRY[name](K=K, order=order)
+        eng = _engine(prob, threads_per_block=64, specialise=specialise)
+        ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+        _check_all(eng, ora, seed=order + K)
+        eng.close()
+
+
 def test_known_answers_brachistochrone(built, known_answers):
     """tests/unit/test_iteration.py:305-318, 339-354, 371-385 evaluated by the HIP path."""
     eng = _engine(problems.brachistochrone())
