@@ -24,7 +24,7 @@ from .scaling import constraint_scaling, objective_scaling
 
 
 class MeshIteration:
-    def __init__(self, problem, *, device: int = 0, meshes=None, prev=None, threads_per_block: int = 0):
+    def __init__(self, problem, *, device: int = 0, meshes=None, prev=None, threads_per_block: int = 0, number: int = 1):
         """``prev`` = (tau per phase, y per phase, u per phase, q per phase, t per phase, s) in *unscaled*
         variables -- the previous iteration's solution; default: the problem's user guess."""
         self.problem = problem
@@ -38,8 +38,13 @@ class MeshIteration:
         V, r = self.layout.base_variable_scaling()
         self.V, self.r = self.layout.expand_x(V), self.layout.expand_x(r)
         self.guess_x_tilde = (self.guess_x - self.r) / self.V                    # scaling.py:172-174
-        # first-iteration scaling: w = 1, W from the Jacobian row norms at the guess (scaling.py:271-275)
+        # first mesh iteration: w = 1, W from the Jacobian row norms at the guess (scaling.py:271-275); later ones
+        # (default update_scaling = False -> _generate_from_base, scaling.py:277-281): w = 1 / ||grad J|| as well
+        self.number = int(number)
         self.w = 1.0
+        self.engine.set_scaling(V, r, np.ones(self.layout.num_ocp_c), 1.0)
+        if self.number > 1:
+            self.w = objective_scaling(self.engine, self.guess_x_tilde)
         self.W_ocp = constraint_scaling(self.engine, self.guess_x_tilde)
         self.engine.set_scaling(V, r, self.W_ocp, self.w)
         self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u = self._bounds()

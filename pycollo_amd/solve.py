@@ -36,7 +36,7 @@ def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float =
     it = None
     met = False
     for k in range(max_mesh_iterations):
-        it = MeshIteration(prob, device=device, prev=prev)
+        it = MeshIteration(prob, device=device, prev=prev, number=k + 1)
         res = it.solve_with_ipm(max_iter=nlp_max_iter, tol=nlp_tol, verbose=max(0, verbose - 1))
         errs = mesh_error(it.engine, it.x_tilde)
         worst = max(float(np.max(rel)) for rel, _ in errs)
