@@ -376,6 +376,41 @@ def sliding_mass(num_phases: int = 2, K: int = 10, order: int = 4) -> ProblemSpe
     return prob
 
 
+def free_flying_robot(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Sakawa free-flying robot, 6 states, 4 one-sided thruster controls, 2 path inequality rows, fuel integral;
+    the problem of the reference's integration test (tests/integration/test_free_flying_robot.py:20-186; expected
+    objective 7.9101902 (GPOPS-II) / 7.910154646 (SOS), mesh tolerance 1e-5, at most 15 mesh iterations)."""
+    r_x, r_y, theta, v_x, v_y, omega = sym.symbols("r_x r_y theta v_x v_y omega")
+    uxp, uxn, uyp, uyn = sym.symbols("u_x_pos u_x_neg u_y_pos u_y_neg")
+    T_x, T_y, I_xx, I_yy = sym.symbols("T_x T_y I_xx I_yy")
+    prob = ProblemSpec("Free-Flying Robot")
+    ph = prob.new_phase("A")
+    ph.state_variables = [r_x, r_y, theta, v_x, v_y, omega]
+    ph.control_variables = [uxp, uxn, uyp, uyn]
+    ph.state_equations = {r_x: v_x, r_y: v_y, theta: omega,
+                          v_x: (T_x + T_y) * sym.cos(theta), v_y: (T_x + T_y) * sym.sin(theta),
+                          omega: I_xx * T_x - I_yy * T_y}
+    ph.integrand_functions = [uxp + uxn + uyp + uyn]
+    ph.path_constraints = [uxp + uxn, uyp + uyn]
+    prob.objective_function = ph.integral_variables[0]
+    prob.auxiliary_data = {I_xx: 0.2, I_yy: 0.2, T_x: uxp - uxn, T_y: uyp - uyn}
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = 12.0
+    ph.bounds.state_variables = {r_x: [-10, 10], r_y: [-10, 10], theta: [-np.pi, np.pi], v_x: [-2, 2], v_y: [-2, 2],
+                                 omega: [-1, 1]}
+    ph.bounds.initial_state_constraints = {r_x: -10, r_y: -10, theta: np.pi / 2, v_x: 0, v_y: 0, omega: 0}
+    ph.bounds.final_state_constraints = {r_x: 0, r_y: 0, theta: 0, v_x: 0, v_y: 0, omega: 0}
+    ph.bounds.control_variables = [[0, 1000]] * 4
+    ph.bounds.integral_variables = [[0, 100]]
+    ph.bounds.path_constraints = [[-1000, 1], [-1000, 1]]
+    ph.guess.time = np.array([0.0, 12.0])
+    ph.guess.state_variables = np.array([[-10, 0], [-10, 0], [np.pi / 2, 0], [0, 0], [0, 0], [0, 0]], dtype=float)
+    ph.guess.control_variables = np.zeros((4, 2))
+    ph.guess.integral_variables = np.array([0.0])
+    _mesh(ph, K, order)
+    return prob
+
+
 REGISTRY = {
     "brachistochrone": brachistochrone,
     "hypersensitive": hypersensitive,
@@ -385,4 +420,5 @@ REGISTRY = {
     "double_pendulum": double_pendulum,
     "two_phase_transfer": two_phase_transfer,
     "sliding_mass": sliding_mass,
+    "free_flying_robot": free_flying_robot,
 }

@@ -6,5 +6,6 @@ from pycollo_amd.solve import solve_ocp
 name = sys.argv[1] if len(sys.argv) > 1 else "brachistochrone"
 kw = eval(sys.argv[2]) if len(sys.argv) > 2 else {}
 t0 = time.time()
-res = solve_ocp(problems.REGISTRY[name](**kw), verbose=1, max_mesh_iterations=int(os.environ.get("MAX_MESH", "10")))
+res = solve_ocp(problems.REGISTRY[name](**kw), verbose=1, max_mesh_iterations=int(os.environ.get("MAX_MESH", "10")),
+                mesh_tolerance=float(os.environ.get("MESH_TOL", "1e-7")))
 print(f"{name}: objective {res.objective:.10g}, mesh tolerance met: {res.mesh_tolerance_met}, {res.mesh_iterations} mesh iterations, {time.time() - t0:.1f} s")
