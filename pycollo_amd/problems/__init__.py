@@ -411,6 +411,39 @@ def free_flying_robot(K: int = 10, order: int = 4) -> ProblemSpec:
     return prob
 
 
+def tumour_anti_angiogenesis(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Ledzewicz-Schaettler tumour anti-angiogenesis: 2 states, 1 control, 1 integral (total drug) with an upper
+    bound, free final time, Mayer objective p(tF); log and fractional-power dynamics.  The problem of the reference's
+    integration test (tests/integration/test_tumour_anti_angiogenesis.py:20-111; expected objective 7571.66986
+    (GPOPS-II) / 7571.6831 (SOS), rtol 1e-5)."""
+    p_, q_, u_ = sym.symbols("p q u")
+    xi, b, d, G, mu = sym.symbols("xi b d G mu")
+    b_v, mu_v, d_v, a_v, A_v = 5.85, 0.02, 0.00873, 75.0, 15.0
+    p_max = ((b_v - mu_v) / d_v) ** 1.5
+    p_min = 0.1
+    p_t0, q_t0 = p_max / 2, p_max / 4
+    prob = ProblemSpec("Tumour Anti-Angiogenesis")
+    ph = prob.new_phase("A")
+    ph.state_variables = [p_, q_]
+    ph.control_variables = [u_]
+    ph.state_equations = {p_: -xi * p_ * sym.log(p_ / q_), q_: q_ * (b - (mu + d * p_ ** (2 / 3) + G * u_))}
+    ph.integrand_functions = [u_]
+    prob.objective_function = ph.final_state_variables[0]
+    prob.auxiliary_data = {xi: 0.084, b: b_v, d: d_v, G: 0.15, mu: mu_v}
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = [0.1, 5.0]
+    ph.bounds.state_variables = {p_: [p_min, p_max], q_: [p_min, p_max]}
+    ph.bounds.control_variables = [[0.0, a_v]]
+    ph.bounds.integral_variables = [[0.0, A_v]]
+    ph.bounds.initial_state_constraints = {p_: p_t0, q_: q_t0}
+    ph.guess.time = np.array([0.0, 1.0])
+    ph.guess.state_variables = np.array([[p_t0, p_max], [q_t0, p_max]])
+    ph.guess.control_variables = np.array([[a_v, a_v]])
+    ph.guess.integral_variables = np.array([7.5])
+    _mesh(ph, K, order)
+    return prob
+
+
 REGISTRY = {
     "brachistochrone": brachistochrone,
     "hypersensitive": hypersensitive,
@@ -421,4 +454,5 @@ REGISTRY = {
     "two_phase_transfer": two_phase_transfer,
     "sliding_mass": sliding_mass,
     "free_flying_robot": free_flying_robot,
+    "tumour_anti_angiogenesis": tumour_anti_angiogenesis,
 }
