@@ -444,6 +444,65 @@ def tumour_anti_angiogenesis(K: int = 10, order: int = 4) -> ProblemSpec:
     return prob
 
 
+def space_station(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Betts' space-station attitude control: 9 states (angular velocity, Euler-Rodrigues parameters, control-moment-
+    gyro momentum), 3 torque controls, momentum-magnitude path row, control-effort integral, six nonlinear endpoint
+    rows (zero angular and attitude acceleration at tF).  The problem of the reference's integration test
+    (tests/integration/test_space_station_attitute_control.py:24-285; expected objective 3.58675 (GPOPS-II) /
+    3.58688 (SOS), rtol 1e-4)."""
+    wx, wy, wz, rx, ry, rz, hx, hy, hz = sym.symbols("omega_x omega_y omega_z r_x r_y r_z h_x h_y h_z")
+    ux, uy, uz = sym.symbols("u_x u_y u_z")
+    Jm = sym.Matrix([[2.80701911616e7, 4.822509936e5, -1.71675094448e7],
+                     [4.822509936e5, 9.5144639344e7, 6.02604448e4],
+                     [-1.71675094448e7, 6.02604448e4, 7.6594401336e7]])
+    Jinv = Jm.inv()
+    w_orb = 0.06511 * np.pi / 180
+    h_max = 10000.0
+
+    def skew(vv):
+        return sym.Matrix([[0, -vv[2], vv[1]], [vv[2], 0, -vv[0]], [-vv[1], vv[0], 0]])
+
+    def rates(om, r, h, u):
+        I3 = sym.eye(3)
+        rs = skew(r)
+        C = I3 + (2 / (1 + r.dot(r))) * (rs * rs - rs)
+        tau_gg = 3 * w_orb**2 * skew(C[:, 2]) * (Jm * C[:, 2])
+        dom = Jinv * (tau_gg - skew(om) * (Jm * om + h) - u)
+        om0 = -w_orb * C[:, 1]
+        dr = sym.Rational(1, 2) * (r * r.T + I3 + rs) * (om - om0)
+        return dom, dr
+
+    prob = ProblemSpec("Space Station Attitude Control")
+    ph = prob.new_phase("A")
+    ph.state_variables = [wx, wy, wz, rx, ry, rz, hx, hy, hz]
+    ph.control_variables = [ux, uy, uz]
+    dom, dr = rates(sym.Matrix([wx, wy, wz]), sym.Matrix([rx, ry, rz]), sym.Matrix([hx, hy, hz]), sym.Matrix([ux, uy, uz]))
+    ph.state_equations = [dom[0], dom[1], dom[2], dr[0], dr[1], dr[2], ux, uy, uz]
+    ph.path_constraints = [hx**2 + hy**2 + hz**2]
+    ph.integrand_functions = [1e-6 * (ux**2 + uy**2 + uz**2)]
+    prob.objective_function = ph.integral_variables[0]
+    yF = ph.final_state_variables
+    domF, drF = rates(sym.Matrix(yF[0:3]), sym.Matrix(yF[3:6]), sym.Matrix(yF[6:9]), sym.zeros(3, 1))
+    prob.endpoint_constraints = [domF[0], domF[1], domF[2], drF[0], drF[1], drF[2]]
+    prob.bounds.endpoint_constraints = [0] * 6
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = 1800.0
+    ph.bounds.state_variables = [[-2e-3, 2e-3]] * 3 + [[-1, 1]] * 3 + [[-15000, 15000]] * 3
+    y0 = [-9.5380685844896e-6, -1.1363312657036e-3, 5.3472801108427e-6, 2.9963689649816e-3, 1.5334477761054e-1,
+          3.8359805613992e-3, 5000.0, 5000.0, 5000.0]
+    ph.bounds.initial_state_constraints = dict(zip(ph.state_variables, y0))
+    ph.bounds.final_state_constraints = {hx: 0, hy: 0, hz: 0}
+    ph.bounds.control_variables = [[-150, 150]] * 3
+    ph.bounds.integral_variables = [[0, 10]]
+    ph.bounds.path_constraints = [[0, h_max**2]]
+    ph.guess.time = np.array([0.0, 1800.0])
+    ph.guess.state_variables = np.array([[v, v] for v in y0])
+    ph.guess.control_variables = np.zeros((3, 2))
+    ph.guess.integral_variables = np.array([10.0])
+    _mesh(ph, K, order)
+    return prob
+
+
 REGISTRY = {
     "brachistochrone": brachistochrone,
     "hypersensitive": hypersensitive,
@@ -455,4 +514,5 @@ REGISTRY = {
     "sliding_mass": sliding_mass,
     "free_flying_robot": free_flying_robot,
     "tumour_anti_angiogenesis": tumour_anti_angiogenesis,
+    "space_station": space_station,
 }

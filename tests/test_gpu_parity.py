@@ -53,7 +53,7 @@ def _check_all(eng, ora, seed=1, xlo=-0.45, xhi=0.45):
 CASES = [("brachistochrone", {}), ("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=500, order=4)),
          ("shuttle", dict(K=60, order=5)), ("double_pendulum", {}), ("two_phase_transfer", {}),
          ("delta_iii", dict(K=9, order=4)), ("free_flying_robot", dict(K=33, order=5)), ("sliding_mass", dict(num_phases=3, K=7, order=4)),
-         ("tumour_anti_angiogenesis", dict(K=21, order=6))]
+         ("tumour_anti_angiogenesis", dict(K=21, order=6)), ("space_station", dict(K=12, order=4))]
 
 
 @pytest.mark.parametrize("tpb", [64, 256])

@@ -1,7 +1,8 @@
 """End-to-end solve() on the GPU path: mesh iteration -> interior-point NLP solve
 through the cyipopt-protocol callbacks -> GPU mesh-error estimate -> refinement, checked against the objectives the
 reference's integration tests assert (tests/integration/test_brachistochrone.py:157-167,
-test_hypersensitive_problem.py:127-137, test_space_shuttle_reentry_trajectory.py:238-256, test_multiphase.py:22,78-84)
+test_hypersensitive_problem.py:127-137, test_space_shuttle_reentry_trajectory.py:238-256, test_multiphase.py:22,78-84,
+test_free_flying_robot.py, test_space_station_attitute_control.py, test_tumour_anti_angiogenesis.py)
 with the reference's own tolerances."""
 import numpy as np
 import pytest
@@ -47,6 +48,16 @@ def test_free_flying_robot_solution(built):
     res = solve_ocp(problems.free_flying_robot(), mesh_tolerance=1e-5, max_mesh_iterations=15)
     assert np.isclose(res.objective, 7.9101902, rtol=5e-4, atol=0.0)
     assert np.isclose(res.objective, 7.910154646, rtol=5e-4, atol=0.0)
+    assert res.mesh_tolerance_met is True
+
+
+def test_space_station_solution(built):
+    """tests/integration/test_space_station_attitute_control.py:286-305: nine states, nonlinear endpoint rows."""
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.space_station())
+    GPOPS_II_SOLUTION, SOS_SOLUTION = 3.58675, 3.58688
+    assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-4, atol=0.0)
+    assert np.isclose(res.objective, SOS_SOLUTION, rtol=1e-4, atol=0.0)
     assert res.mesh_tolerance_met is True
 
 
