@@ -131,6 +131,16 @@ def _phase_struct(pm: PhaseModel) -> str:
              "    (void)v; (void)mult; (void)F; (void)Jv; (void)Hv;"]
     lines += body
     lines += ["  }"]
+    # the same outputs in two passes (values and first partials / second partials): heavy models run them one after
+    # the other so that the first and second partials are never live together (pc::bulk, SPLIT)
+    cdecl = [f"    constexpr double {k} = {float(val)!r};" for k, val in pm.consts]
+    fj = [(f"F[{i}]", e) for i, e in enumerate(pm.f + pm.p + pm.g)] + [(f"Jv[{i}]", e) for i, (_, _, e) in enumerate(pm.jac)]
+    lines += ["  __device__ static __forceinline__ void eval_fj(const double* __restrict__ v, double* __restrict__ F,",
+              "      double* __restrict__ Jv) {", "    (void)v; (void)F; (void)Jv;"]
+    lines += cdecl + _emit_block(v_in, fj, "w") + ["  }"]
+    lines += ["  __device__ static __forceinline__ void eval_h(const double* __restrict__ v, const double* __restrict__ mult,",
+              "      double* __restrict__ Hv) {", "    (void)v; (void)mult; (void)Hv;"]
+    lines += cdecl + _emit_block(inputs, [(f"Hv[{i}]", e) for i, (_, _, e) in enumerate(pm.hess)], "w") + ["  }"]
     # state equations only (ph mesh-error estimate, mesh_refinement.py:199-201)
     fbody = [f"    constexpr double {k} = {float(val)!r};" for k, val in pm.consts]
     fbody += _emit_block(v_in, [(f"F[{i}]", e) for i, e in enumerate(pm.f)], "w")

@@ -735,13 +735,23 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   STAMP(2);
   // ---- model evaluation -----------------------------------------------------------------------
+  // The heaviest models evaluate in two passes -- values and first partials here, second partials after the
+  // Jacobian has been written -- so that the two derivative sets are never live together.  It pays only where
+  // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
+  // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
+  // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
+#ifndef PC_SPLIT_MIN
+#define PC_SPLIT_MIN 90
+#endif
+  constexpr bool SPLIT = !FUSED && (NJ + NH >= PC_SPLIT_MIN);
+  double mult[NFN > 0 ? NFN : 1];
   if (active) {
-    double mult[NFN > 0 ? NFN : 1];
     static_for<0, NFN>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
       mult[r] = (r >= NY && r < NY + NP) ? mu[r] : stretch * mu[r];
     });
-    M::eval(v, mult, F, Jv, Hv);
+    if constexpr (SPLIT) M::eval_fj(v, F, Jv);
+    else M::eval(v, mult, F, Jv, Hv);
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       s_f[a * TN + t] = F[a];
@@ -830,8 +840,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   STAMP(5);
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
-  if (wantH && hess_replica) {
-    const bool edge0 = (node == 0), edgeN = (node == N - 1);
+  const bool edge0 = (node == 0), edgeN = (node == N - 1);
+  auto hess_second = [&]() {     // everything built from the second partials
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
     static_for<0, NZ>([&](auto rv_) {
       constexpr int rv = decltype(rv_)::value;
@@ -881,6 +891,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           red[St::R_SS + l * (l + 1) / 2 + l2] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
         }
       });
+    }
+  };
+  auto hess_tstrips = [&]() {    // built from the adjoint weights and the first partials
+    if (owns) {
       // time coupling through stretch: d/dt~_j of stretch * (mu . dF/dv), f and g rows only
       if constexpr (NT > 0) {
         static_for<0, NV>([&](auto c_) {
@@ -905,6 +919,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         });
       }
     }
+  };
+  if (wantH && hess_replica) {
+    if constexpr (!SPLIT) hess_second();
+    hess_tstrips();
   }
 
   // ---- per-tile partial sums (fixed order: lanes -> waves -> tile): every wave deposits its sums here.  In the
@@ -912,6 +930,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   //      (partials, edge Hessian entries) is out before the bulky c~/G~ runs, so the store drain below waits for a
   //      handful of stores only
   bool is_last = false;
+  auto deposit_partials = [&]() {
   if constexpr (NRED > 0) {
     static_for<0, NRED>([&](auto r_) {   // replicas hold copies: the owner of the sum's item contributes
       constexpr int r = decltype(r_)::value;
@@ -932,6 +951,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       }
     }
   }
+  };
+  if constexpr (!SPLIT) deposit_partials();
   if constexpr (FUSED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (payload is sc1)
     __syncthreads();
@@ -1044,6 +1065,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
 
+  if constexpr (SPLIT) {         // second pass: second partials, the Hessian runs built from them, then the sums
+    if (wantH && hess_replica) {
+      if (active) M::eval_h(v, mult, Hv);
+      hess_second();
+    }
+    deposit_partials();
+  }
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
   if constexpr (NRED > 0 && !FUSED) {
     block_sync();
