@@ -215,10 +215,10 @@ def generate_source(model: Model, orders=None) -> str:
     if len(model.phases) > 1:
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(PcMultiArgs m) {')
-        parts.append("  const int b = blockIdx.x;")
+        parts.append(f"  const int b = pc::xcd_major((int)blockIdx.x, m.first_block[{len(model.phases)}]);")
         for i, pm in enumerate(model.phases):
             cond = f"if (b < m.first_block[{i + 1}]) " if i + 1 < len(model.phases) else ""
-            parts.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(m.ph[{i}], nullptr, &m, m.first_block[{i}]); return; }}")
+            parts.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(m.ph[{i}], nullptr, &m, m.first_block[{i}], b); return; }}")
         parts.append("}")
     last = model.phases[-1].index
     parts.append("// last phase with the tail folded in: the last workgroup to arrive finishes the evaluation")

@@ -49,6 +49,9 @@ struct PcPhaseArgs {
   int32_t lds_out;        // doubles of the output staging buffer
   int32_t dbg_stage;      // 0 = normal; k > 0: diagnostic build of the timeline, return after stage k
   int32_t wpt;            // waves (replicas) per tile: 1, 2 or 4; > 1 only with 64-node tiles
+  int32_t block_threads;  // threads per workgroup of this launch (= blockDim.x, passed for the same reason as n_blocks)
+  int32_t n_blocks;       // workgroups of this launch (tile_end - tile_begin): the kernel must not read gridDim,
+                          // which lives in the dispatch packet in host memory
   int32_t qa_off[PC_MAX_ORDER + 1];
   int32_t qw_off[PC_MAX_ORDER + 1];
   // packed scaling doubles: Vz[NZ] rz[NZ] Vq[NQ] rq[NQ] Vt[2] rt[2] Vs[NS] rs[NS] Wd[NY] Wp[NP] Wi[NQ]
@@ -108,6 +111,7 @@ struct PcTailArgs {
   int64_t c_end_off;            // first endpoint row of c
   int64_t g_end_base;           // CSR offset of the first endpoint row of G
   int32_t n_tail_owned, flags;
+  int32_t block_threads, reserved;   // threads of the workgroup that runs the tail (blockDim.x would be a late scalar load)
   PcTailPhase ph[PC_MAX_PHASES];
 };
 

@@ -236,6 +236,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.g_end_base = Q.g_end_base;
   t.n_tail_owned = (int32_t)Q.tail_owned.size();
   t.flags = flags;
+  t.block_threads = 256;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
@@ -301,6 +302,8 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.n_tiles = D.n_tiles;
   a.flags = flags;
   a.tile_begin = D.tile_begin;
+  a.n_blocks = std::max(0, D.tile_end - D.tile_begin);
+  a.block_threads = h->TB * wpt;
   a.qa_total = (int32_t)h->qa.size();
   a.qw_total = (int32_t)h->qw.size();
   std::memcpy(a.qa_off, h->qa_off, sizeof(a.qa_off));
@@ -363,6 +366,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     if (D.tile_end <= D.tile_begin) continue;
     if (fuse && ip == last) {
       fill_tail_args(h, both.t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
+      both.t.block_threads = h->TB;   // the tail runs inside the bulk workgroup
       size_t sz = sizeof(both);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
       HIP_OK(hipModuleLaunchKernel(D.fn_fused, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
@@ -931,6 +935,7 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   t.c_end_off = Q.c_end_off;
   t.g_end_base = Q.g_end_base;
   t.flags = 0;
+  t.block_threads = 256;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     t.ph[ip].n_tiles = 0;
     t.ph[ip].partials = h->pd[ip]->partials.p;

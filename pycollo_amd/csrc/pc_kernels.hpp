@@ -313,7 +313,7 @@ struct BulkIn {
   unsigned* sync; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
-  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt;
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -362,11 +362,29 @@ __device__ __forceinline__ void store_agent(double* p, double v) {
 // is demoted from registers to scratch memory.
 #define PC_CE(expr) (std::integral_constant<int, (expr)>::value)
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.
+// Neighbouring tiles share a halo node on the read side and, on the write side, the cache line in which one tile's
+// CSR run ends and the next one's begins; mapping consecutive *tiles* to the same XCD keeps both in one L2
+// (the shared lines are merged before they are written back).  b -> position in an XCD-major order.
+#ifndef PC_XCD_SWIZZLE
+#define PC_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xcd_major(int b, int nb) {
+#if PC_XCD_SWIZZLE
+  constexpr int NX = 8;
+  const int q = nb / NX, r = nb % NX, x = b % NX, j = b / NX;
+  return x * q + (x < r ? x : r) + j;
+#else
+  (void)nb;
+  return b;
+#endif
+}
+
 // MA != null: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call
 // pointers and flags come from MA, the workgroup's tile from its index relative to the phase's first block.
 template <class M, int UN, class TAIL = void>
 __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr, const PcMultiArgs* MA = nullptr,
-                                     int first_block = 0) {
+                                     int first_block = 0, int block = -1) {
   constexpr bool FUSED = !std::is_void<TAIL>::value;
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
@@ -384,7 +402,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
   A.N = KA.N; A.K = KA.K; A.flags = MA ? MA->flags : KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
   A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
-  A.wpt = KA.wpt;
+  A.wpt = KA.wpt; A.n_blocks = KA.n_blocks; A.block_threads = KA.block_threads;
   static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
   static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
@@ -393,7 +411,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.tab); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
   PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
   PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
-  PC_PIN(A.dbg_stage); PC_PIN(A.wpt);
+  PC_PIN(A.dbg_stage); PC_PIN(A.wpt); PC_PIN(A.n_blocks); PC_PIN(A.block_threads);
   // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
   // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
   // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
@@ -411,7 +429,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // functions are cheap next to a SIMD that would otherwise idle) and produces a disjoint subset of the output
   // runs -- states, Hessian row blocks, path rows are dealt round-robin.  W > 1 only with TN = 64 (a replica is
   // exactly one wave, so its private staging region needs no workgroup barrier).
-  const int tid = threadIdx.x, TB = blockDim.x;
+  const int tid = threadIdx.x, TB = A.block_threads;   // (blockDim.x is a separate, late scalar load)
   const int W = A.wpt;                                        // 1, 2 or 4
   const int TN = W > 1 ? 64 : TB;
   const int w = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // wave-uniform: branches on it are scalar
@@ -464,7 +482,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
   const int N = A.N;
-  const int tile = (int)blockIdx.x - first_block + A.tile_begin;
+  // (a single-phase launch is swizzled here; pc_bulk_all swizzles before it picks the phase and passes `first_block`
+  //  relative to the swizzled index, together with that index)
+  const int blk = block >= 0 ? block : xcd_major((int)blockIdx.x, A.n_blocks);
+  const int tile = blk - first_block + A.tile_begin;
   if (A.dbg_stage == 1) return;
   // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of every tile
   // stamps s_memtime at the phase boundaries into a buffer of its own
@@ -958,7 +979,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     __syncthreads();
     __shared__ int s_last;
     if (tid == 0) {
-      const unsigned nblk = gridDim.x;
+      const unsigned nblk = (unsigned)A.n_blocks;   // (gridDim would be read from the dispatch packet in host memory)
       const unsigned nsh = nblk < PC_SYNC_SHARDS ? nblk : PC_SYNC_SHARDS;
       const unsigned sh = blockIdx.x % nsh;
       const unsigned members = nblk / nsh + (sh < nblk % nsh ? 1u : 0u);
@@ -1112,14 +1133,14 @@ __device__ __forceinline__ double* tail_acc() {
 __device__ __forceinline__ void tail_begin(const PcTailArgs& A) {
   double* acc = tail_acc();
   if (A.flags & PC_FLAG_H)
-    for (int i = threadIdx.x; i < A.n_tail_owned; i += blockDim.x) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) acc[i] = 0.0;
   lds_barrier();
 }
 __device__ __forceinline__ void tail_end(const PcTailArgs& A) {
   const double* acc = tail_acc();
   lds_barrier();
   if (A.flags & PC_FLAG_H)
-    for (int i = threadIdx.x; i < A.n_tail_owned; i += blockDim.x) A.H[A.tail_owned[i]] = acc[i];
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) A.H[A.tail_owned[i]] = acc[i];
 }
 
 // Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.
@@ -1131,7 +1152,7 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
     __shared__ double s_part[NRED * 4];
     __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = blockDim.x;  // 1 to 4 waves (64 .. 256 threads)
+    const int tid = threadIdx.x, TB = A.block_threads;  // 1 to 4 waves (64 .. 256 threads)
     // lane 0's own inputs are requested before the partial sums so that the two round trips overlap
     const double* sc = P.scal;
     const int N = P.N;
