@@ -326,17 +326,26 @@ struct BulkIn {
 #ifndef PC_PIN_BUDGET_FUSED
 #define PC_PIN_BUDGET_FUSED 0   // the fused build also carries the tail's scalars
 #endif
-template <class T>
-__device__ __forceinline__ void pin_one(T v) {
-  asm volatile("" ::"s"(v));
-}
+// One empty asm per value would do the forcing too, but every inline asm is a scheduling boundary: the loads
+// then come in several dependent batches (measured: 6 loads, wait, 2 loads, wait, 2 loads, wait ...).  Folding all
+// values into one word that a single asm consumes leaves the scheduler free to issue every load at once.
+struct PinAcc {
+  unsigned long long h = 0;
+  template <class T>
+  __device__ __forceinline__ void operator()(T* v) { h ^= (unsigned long long)reinterpret_cast<uintptr_t>(v); }
+  __device__ __forceinline__ void operator()(double v) { h ^= __builtin_bit_cast(unsigned long long, v); }
+  __device__ __forceinline__ void operator()(long long v) { h ^= (unsigned long long)v; }
+  __device__ __forceinline__ void operator()(long v) { h ^= (unsigned long long)v; }
+  __device__ __forceinline__ void operator()(int v) { h ^= (unsigned long long)(unsigned)v; }
+  __device__ __forceinline__ void done() const { asm volatile("" ::"s"(h)); }
+};
 template <class T, int N, int... I>
-__device__ __forceinline__ void pin_array_impl(const T (&a)[N], std::integer_sequence<int, I...>) {
-  (pin_one(a[I]), ...);
+__device__ __forceinline__ void pin_array_impl(PinAcc& p, const T (&a)[N], std::integer_sequence<int, I...>) {
+  (p(a[I]), ...);
 }
 template <int CNT, class T, int N>
-__device__ __forceinline__ void pin_array(const T (&a)[N]) {
-  pin_array_impl(a, std::make_integer_sequence<int, CNT>{});
+__device__ __forceinline__ void pin_array(PinAcc& p, const T (&a)[N]) {
+  pin_array_impl(p, a, std::make_integer_sequence<int, CNT>{});
 }
 
 // UN > 0: the phase's mesh has UN nodes in every section and the kernel is compiled for exactly that
@@ -406,12 +415,26 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
   static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
-  PC_PIN(A.x); PC_PIN(A.lam); PC_PIN(A.c); PC_PIN(A.G); PC_PIN(A.H); PC_PIN(A.tile_k0); PC_PIN(A.tile_n0);
-  PC_PIN(A.sec_s); PC_PIN(A.sec_h); PC_PIN(A.sec_E); PC_PIN(A.qa); PC_PIN(A.qw); PC_PIN(A.hslot0); PC_PIN(A.hslotN);
-  PC_PIN(A.partials); PC_PIN(A.dbg); PC_PIN(A.sync); PC_PIN(A.tab); PC_PIN(A.x_off); PC_PIN(A.s_off); PC_PIN(A.c_off); PC_PIN(A.c_path_off);
-  PC_PIN(A.c_int_off); PC_PIN(A.t_fixed[0]); PC_PIN(A.t_fixed[1]); PC_PIN(A.N); PC_PIN(A.K); PC_PIN(A.flags);
-  PC_PIN(A.qa_total); PC_PIN(A.qw_total); PC_PIN(A.tile_begin); PC_PIN(A.uni_n); PC_PIN(A.spt); PC_PIN(A.lds_out);
-  PC_PIN(A.dbg_stage); PC_PIN(A.wpt); PC_PIN(A.n_blocks); PC_PIN(A.block_threads);
+  // (only what this build of the kernel can use: everything pinned is live in SGPRs from here on, and the file has
+  //  ~100 of them -- an over-full pin list is loaded in several dependent batches and partly spilled to VGPR lanes)
+  PinAcc pin;
+  pin(A.x); pin(A.lam); pin(A.c); pin(A.G); pin(A.H); pin(A.sec_h); pin(A.qa); pin(A.qw);
+  pin(A.x_off); pin(A.c_off); pin(A.N); pin(A.K); pin(A.flags); pin(A.qa_total); pin(A.qw_total); pin(A.tile_begin);
+  pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.dbg_stage); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
+  if constexpr (NP > 0) pin(A.c_path_off);
+  if constexpr (NQ > 0) pin(A.c_int_off);
+  if constexpr (NS > 0) pin(A.s_off);
+  if constexpr (NRED > 0) pin(A.partials);
+  if constexpr (!M::T0_FREE) pin(A.t_fixed[0]);
+  if constexpr (!M::TF_FREE) pin(A.t_fixed[1]);
+  if constexpr (UN == 0) { pin(A.tile_k0); pin(A.tile_n0); pin(A.sec_s); pin(A.sec_E); }   // any-mesh tables
+  if constexpr (FUSED) pin(A.sync);
+  // (hslot0 / hslotN are left lazy: only the two edge tiles read them)
+#ifdef PC_PIN_ALL   // A/B switch: the earlier, over-full pin list
+  pin(A.tile_k0); pin(A.tile_n0); pin(A.sec_s); pin(A.sec_E); pin(A.hslot0); pin(A.hslotN); pin(A.partials); pin(A.dbg);
+  pin(A.sync); pin(A.tab); pin(A.s_off); pin(A.c_path_off); pin(A.c_int_off); pin(A.t_fixed[0]); pin(A.t_fixed[1]);
+  pin_array<St::NSCAL>(pin, A.scal); pin_array<3 * NZ + NS * NZ>(pin, A.hoff);
+#endif
   // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
   // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
   // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
@@ -419,10 +442,23 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   constexpr int NHO = 3 * NZ + NS * NZ;
   constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= (FUSED ? PC_PIN_BUDGET_FUSED : PC_PIN_BUDGET);
   if constexpr (PINNED) {
-    pin_array<St::NSCAL>(A.scal);
-    pin_array<NFN>(A.goff);
-    pin_array<NHO>(A.hoff);
+    // the scaling entries the bulk kernel reads: V, r of z, of the free times and of s; the row weights.  (V, r of
+    // the integral variables belong to the tail kernel.)
+    static_for<0, St::NSCAL>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      constexpr bool used = (i < St::O_VQ) || (i >= St::O_VT && i < St::O_VT + NT) || (i >= St::O_RT && i < St::O_RT + NT) ||
+                            (i >= St::O_VS);
+      if constexpr (used) pin(A.scal[i]);
+    });
+    pin_array<NFN>(pin, A.goff);
+    static_for<0, NHO>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      if constexpr (i < NZ || (NT > 0 && i < 3 * NZ) || i >= 3 * NZ) pin(A.hoff[i]);   // t strips only with free times
+    });
+  } else {
+    pin(A.tab);
   }
+  pin.done();
 
   extern __shared__ double smem[];
   // W replicas ("waves per tile") share one tile of TN nodes: every replica evaluates all TN nodes (the node
