@@ -417,48 +417,56 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
   // (only what this build of the kernel can use: everything pinned is live in SGPRs from here on, and the file has
   //  ~100 of them -- an over-full pin list is loaded in several dependent batches and partly spilled to VGPR lanes)
+  // Two groups.  The first is what the per-node loads and the table staging need (pointers, offsets, geometry);
+  // the second -- output pointers, scaling constants, run offsets -- is consumed by a second asm placed after those
+  // loads have been issued, so that its scalar-load round trip overlaps their latency instead of preceding it.
   PinAcc pin;
-  pin(A.x); pin(A.lam); pin(A.c); pin(A.G); pin(A.H); pin(A.sec_h); pin(A.qa); pin(A.qw);
+  pin(A.x); pin(A.lam); pin(A.sec_h); pin(A.qa); pin(A.qw);
   pin(A.x_off); pin(A.c_off); pin(A.N); pin(A.K); pin(A.flags); pin(A.qa_total); pin(A.qw_total); pin(A.tile_begin);
   pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.dbg_stage); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
   if constexpr (NP > 0) pin(A.c_path_off);
   if constexpr (NQ > 0) pin(A.c_int_off);
   if constexpr (NS > 0) pin(A.s_off);
-  if constexpr (NRED > 0) pin(A.partials);
-  if constexpr (!M::T0_FREE) pin(A.t_fixed[0]);
-  if constexpr (!M::TF_FREE) pin(A.t_fixed[1]);
   if constexpr (UN == 0) { pin(A.tile_k0); pin(A.tile_n0); pin(A.sec_s); pin(A.sec_E); }   // any-mesh tables
-  if constexpr (FUSED) pin(A.sync);
+  pin.done();
   // (hslot0 / hslotN are left lazy: only the two edge tiles read them)
-#ifdef PC_PIN_ALL   // A/B switch: the earlier, over-full pin list
-  pin(A.tile_k0); pin(A.tile_n0); pin(A.sec_s); pin(A.sec_E); pin(A.hslot0); pin(A.hslotN); pin(A.partials); pin(A.dbg);
-  pin(A.sync); pin(A.tab); pin(A.s_off); pin(A.c_path_off); pin(A.c_int_off); pin(A.t_fixed[0]); pin(A.t_fixed[1]);
-  pin_array<St::NSCAL>(pin, A.scal); pin_array<3 * NZ + NS * NZ>(pin, A.hoff);
-#endif
-  // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
-  // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
-  // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
-  // copy instead (uniform-address ds_read, staged with the quadrature tables).
   constexpr int NHO = 3 * NZ + NS * NZ;
   constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= (FUSED ? PC_PIN_BUDGET_FUSED : PC_PIN_BUDGET);
-  if constexpr (PINNED) {
-    // the scaling entries the bulk kernel reads: V, r of z, of the free times and of s; the row weights.  (V, r of
-    // the integral variables belong to the tail kernel.)
-    static_for<0, St::NSCAL>([&](auto i_) {
-      constexpr int i = decltype(i_)::value;
-      constexpr bool used = (i < St::O_VQ) || (i >= St::O_VT && i < St::O_VT + NT) || (i >= St::O_RT && i < St::O_RT + NT) ||
-                            (i >= St::O_VS);
-      if constexpr (used) pin(A.scal[i]);
-    });
-    pin_array<NFN>(pin, A.goff);
-    static_for<0, NHO>([&](auto i_) {
-      constexpr int i = decltype(i_)::value;
-      if constexpr (i < NZ || (NT > 0 && i < 3 * NZ) || i >= 3 * NZ) pin(A.hoff[i]);   // t strips only with free times
-    });
-  } else {
-    pin(A.tab);
-  }
-  pin.done();
+  auto pin_second_group = [&]() {
+    PinAcc pin2;
+    pin2(A.c); pin2(A.G); pin2(A.H);
+    if constexpr (NRED > 0) pin2(A.partials);
+    if constexpr (!M::T0_FREE) pin2(A.t_fixed[0]);
+    if constexpr (!M::TF_FREE) pin2(A.t_fixed[1]);
+    if constexpr (FUSED) pin2(A.sync);
+#ifdef PC_PIN_ALL   // A/B switch: the earlier, over-full pin list
+    pin2(A.hslot0); pin2(A.hslotN); pin2(A.dbg); pin2(A.sync); pin2(A.tab); pin2(A.s_off); pin2(A.c_path_off);
+    pin2(A.c_int_off); pin2(A.t_fixed[0]); pin2(A.t_fixed[1]);
+    pin_array<St::NSCAL>(pin2, A.scal); pin_array<3 * NZ + NS * NZ>(pin2, A.hoff);
+#endif
+    // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
+    // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
+    // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
+    // copy instead (uniform-address ds_read, staged with the quadrature tables).
+    if constexpr (PINNED) {
+      // the scaling entries the bulk kernel reads: V, r of z, of the free times and of s; the row weights.  (V, r
+      // of the integral variables belong to the tail kernel.)
+      static_for<0, St::NSCAL>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        constexpr bool used = (i < St::O_VQ) || (i >= St::O_VT && i < St::O_VT + NT) || (i >= St::O_RT && i < St::O_RT + NT) ||
+                              (i >= St::O_VS);
+        if constexpr (used) pin2(A.scal[i]);
+      });
+      pin_array<NFN>(pin2, A.goff);
+      static_for<0, NHO>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        if constexpr (i < NZ || (NT > 0 && i < 3 * NZ) || i >= 3 * NZ) pin2(A.hoff[i]);   // t strips only with free times
+      });
+    } else {
+      pin2(A.tab);
+    }
+    pin2.done();
+  };
 
   extern __shared__ double smem[];
   // W replicas ("waves per tile") share one tile of TN nodes: every replica evaluates all TN nodes (the node
@@ -616,6 +624,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       r_lam[2 * a + 1] = tid + TB < lam_cnt ? src[tid + TB] : 0.0;
     });
   }
+  pin_second_group();
   if (!uni) {
     for (int i = tid; i <= nsec; i += TB) {
       s_s[i] = A.sec_s[kp + i];

@@ -33,7 +33,9 @@ def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int
         cpu = _current_cpu()
         if cpu not in allowed:
             cpu = allowed[0]
-        os.sched_setaffinity(0, {cpu})
+        width = max(1, int(os.environ.get("PYCOLLO_AMD_PIN_WIDTH", "1")))   # experiment knob: cores in the slice
+        i = allowed.index(cpu)
+        os.sched_setaffinity(0, set(allowed[i:i + width]) or {cpu})
         return cpu, set(allowed)
     # several ranks: each gets its own slice of cores rather than one core -- the collective library's helper
     # threads inherit the mask too and must not queue behind the launching thread
