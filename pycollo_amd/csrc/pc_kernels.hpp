@@ -313,7 +313,7 @@ struct BulkIn {
   unsigned* sync; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
-  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads;
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads, qa0, qw0;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -412,6 +412,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   A.N = KA.N; A.K = KA.K; A.flags = MA ? MA->flags : KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
   A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
   A.wpt = KA.wpt; A.n_blocks = KA.n_blocks; A.block_threads = KA.block_threads;
+  A.qa0 = KA.qa_off[UN > 0 ? UN : 0]; A.qw0 = KA.qw_off[UN > 0 ? UN : 0];
   static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
   static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
   static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
@@ -424,6 +425,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   pin(A.x); pin(A.lam); pin(A.sec_h); pin(A.qa); pin(A.qw);
   pin(A.x_off); pin(A.c_off); pin(A.N); pin(A.K); pin(A.flags); pin(A.qa_total); pin(A.qw_total); pin(A.tile_begin);
   pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.dbg_stage); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
+  if constexpr (UN > 0) { pin(A.qa0); pin(A.qw0); }
   if constexpr (NP > 0) pin(A.c_path_off);
   if constexpr (NQ > 0) pin(A.c_int_off);
   if constexpr (NS > 0) pin(A.s_off);
@@ -480,7 +482,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
-  int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off
+  int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off (any-mesh kernels)
+  auto QAO = [&](int n) -> int { return UN > 0 ? A.qa0 : s_off[n]; };                       // start of A_n in s_qa
+  auto QWO = [&](int n) -> int { return UN > 0 ? A.qw0 : s_off[PC_MAX_ORDER + 1 + n]; };    // start of w_n in s_qw
   double* s_h = smem + lp.h;
   long long* s_E = reinterpret_cast<long long*>(smem + lp.E);
   int* s_s = reinterpret_cast<int*>(smem + lp.s);
@@ -604,7 +608,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 
   // ---- staging: every table's first chunk is loaded into registers before anything is written to LDS,
   //      so the global-load latencies overlap instead of queueing behind one loop after another ----------
-  const int r_off = tid < 2 * (PC_MAX_ORDER + 1) ? reinterpret_cast<const int32_t*>(&KA.qa_off[0])[tid] : 0;   // qa_off, qw_off adjacent
+  // table offsets by order: a compile-time order needs just its own two (scalar kernel arguments, see QAO / QWO)
+  const int r_off = (UN == 0 && tid < 2 * (PC_MAX_ORDER + 1)) ? reinterpret_cast<const int32_t*>(&KA.qa_off[0])[tid] : 0;   // qa_off, qw_off adjacent
   const double r_qa = tid < A.qa_total ? A.qa[tid] : 0.0;
   const double r_qw = tid < A.qw_total ? A.qw[tid] : 0.0;
   const double r_h = tid < nsec ? A.sec_h[kp + tid] : 0.0;   // widths are data even on a uniform-order mesh
@@ -631,7 +636,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       s_E[i] = A.sec_E[kp + i];
     }
   }
-  if (tid < 2 * (PC_MAX_ORDER + 1)) s_off[tid] = r_off;
+  if (UN == 0 && tid < 2 * (PC_MAX_ORDER + 1)) s_off[tid] = r_off;
   if (tid < A.qa_total) s_qa[tid] = r_qa;
   if (tid < A.qw_total) s_qw[tid] = r_qw;
   if (tid < nsec) s_h[tid] = r_h;
@@ -714,11 +719,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     if (ls_r >= 0) {
       n_r = S_n(ls_r);
       pos_r = node - S_s(ls_r);
-      w_node = S_h(ls_r) * s_qw[s_off[PC_MAX_ORDER + 1 + n_r] + pos_r];
+      w_node = S_h(ls_r) * s_qw[QWO(n_r) + pos_r];
     }
     if (has_start) {
       n_s = S_n(ls_s);
-      w_node += S_h(ls_s) * s_qw[s_off[PC_MAX_ORDER + 1 + n_s]];
+      w_node += S_h(ls_s) * s_qw[QWO(n_s)];
     }
   }
 
@@ -735,7 +740,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
 #pragma unroll
     for (int j = 0; j < NC; ++j) cr[j] = cs[j] = 0.0;
     if (active) {
-      const double* At = s_qa + s_off[UN];
+      const double* At = s_qa + QAO(UN);
       if (ls_r >= 0) {
         const double h = S_h(ls_r);
 #pragma unroll
@@ -771,7 +776,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         }
       } else {
         if (ls_r >= 0) {
-          const double* At = s_qa + s_off[n_r];
+          const double* At = s_qa + QAO(n_r);
           const int base = S_s(ls_r) - lam0;
           double a2 = 0.0;
 #pragma unroll
@@ -779,7 +784,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           acc += S_h(ls_r) * a2;
         }
         if (has_start) {
-          const double* At = s_qa + s_off[n_s];
+          const double* At = s_qa + QAO(n_s);
           const int base = S_s(ls_s) - lam0;
           double a2 = 0.0;
 #pragma unroll
@@ -838,7 +843,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if (rowthr && (wantC || wantG)) {
     const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
     const double h = S_h(ls_r);
-    const double* Arow = s_qa + s_off[n] + (j - 1) * n;
+    const double* Arow = s_qa + QAO(n) + (j - 1) * n;
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       accf[a] = 0.0;
@@ -1078,7 +1083,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
         auto write_cols = [&](int ls, int pos, int n_in, const double* cc) {
           const int n = UN > 0 ? UN : n_in;
           const double h = HOIST ? 0.0 : S_h(ls);
-          const double* At = s_qa + (HOIST ? 0 : s_off[n]);
+          const double* At = s_qa + (HOIST ? 0 : QAO(n));
 #pragma unroll
           for (int j = 1; j < n; ++j) {
             const double coef = HOIST ? cc[j - 1] : h * At[(j - 1) * n + pos];
@@ -1113,7 +1118,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
             static_for<0, NS>([&](auto l_) {
               constexpr int l = decltype(l_)::value;
               if constexpr (PC_CE(St::dep(a, NZ + l))) {
-                const double* Arow = s_qa + s_off[n] + (j - 1) * n;
+                const double* Arow = s_qa + QAO(n) + (j - 1) * n;
                 double as = 0.0;
 #pragma unroll
                 for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
