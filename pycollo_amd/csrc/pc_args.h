@@ -77,6 +77,8 @@ struct PcMultiArgs {
   int32_t flags, n_phases;
   int32_t first_block[PC_MAX_PHASES + 1];
 };
+#define PC_MAX_POINT 96           // endpoint (point) variables: y(t0), y(tF), q, t of every phase, s
+#define PC_MAX_ENDPOINT_ROWS 32   // endpoint constraint rows
 #define PC_TAIL_OWNED_MAX 1024   // Hessian entries the tail accumulates in LDS
 #define PC_SYNC_SHARDS 64   // arrival counters of the fused tail, one 64-B line each, plus the top counter
 
@@ -113,6 +115,12 @@ struct PcTailArgs {
   int32_t n_tail_owned, flags;
   int32_t block_threads, reserved;   // threads of the workgroup that runs the tail (blockDim.x would be a late scalar load)
   PcTailPhase ph[PC_MAX_PHASES];
+  // the endpoint block's small tables by value: their loads join the argument fetch instead of forming a
+  // second dependent round trip through device memory (point_x / point_V / point_r / W_end hold the same data)
+  int64_t pt_x[PC_MAX_POINT];
+  double pt_V[PC_MAX_POINT];
+  double pt_r[PC_MAX_POINT];
+  double pt_W[PC_MAX_ENDPOINT_ROWS];
 };
 
 // Arguments of the ph mesh-error kernel (pycollo/mesh_refinement.py:63-240).

@@ -197,6 +197,7 @@ struct pc_handle {
   DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
   DevBuf<int32_t> d_pt_hlocal;
+  std::vector<double> h_pointV, h_pointr, h_Wend;   // host copies: travel by value in PcTailArgs
   DevBuf<unsigned> d_sync;   // arrival counters of the fused tail (zero between launches)
   bool allow_fuse = false;   // PYCOLLO_AMD_FUSE=1 folds the tail into the last bulk launch (experimental:
                              // measured no faster than two launches on MI355X)
@@ -211,6 +212,16 @@ struct pc_handle {
 };
 
 namespace {
+
+void fill_point_tables(pc_handle* h, PcTailArgs& t) {
+  auto& Q = h->Q;
+  for (size_t i = 0; i < Q.point_x.size(); ++i) {
+    t.pt_x[i] = Q.point_x[i];
+    t.pt_V[i] = h->h_pointV[i];
+    t.pt_r[i] = h->h_pointr[i];
+  }
+  for (size_t r = 0; r < h->h_Wend.size(); ++r) t.pt_W[r] = h->h_Wend[r];
+}
 
 void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double* d_lam, double* d_c, double* d_G,
                     double* d_H, double* d_fobj, double* d_grad, int flags, double sigma) {
@@ -229,6 +240,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.point_V = h->d_pointV.p;
   t.point_r = h->d_pointr.p;
   t.W_end = h->d_Wend.p;
+  fill_point_tables(h, t);
   t.tail_owned = h->d_tail_owned.p;
   t.pt_hslot = h->d_pt_hslot.p;
   t.pt_hlocal = h->d_pt_hlocal.p;
@@ -434,6 +446,9 @@ void upload_scaling(pc_handle* h) {
     h->d_pointV.upload(pv);
     h->d_pointr.upload(pr);
     h->d_Wend.upload(we);
+    h->h_pointV = pv;
+    h->h_pointr = pr;
+    h->h_Wend = we;
   }
   h->have_cG = false;
 }
@@ -552,6 +567,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->TB = TB;
     if (const char* env = std::getenv("PYCOLLO_AMD_DBG_STAGE")) h->dbg_stage = std::atoi(env);
     pcp::build_all(Q, TB);
+    if (Q.point_x.size() > PC_MAX_POINT || Q.n_b > PC_MAX_ENDPOINT_ROWS)
+      throw std::runtime_error("too many endpoint variables / endpoint constraints for the tail kernel's argument block");
     if (Q.tail_owned.size() > PC_TAIL_OWNED_MAX)
       throw std::runtime_error("too many Hessian entries owned by the tail kernel (static parameters / endpoint terms)");
     for (auto& P : Q.ph)
@@ -932,6 +949,7 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   t.point_V = h->d_pointV.p;
   t.point_r = h->d_pointr.p;
   t.W_end = h->d_Wend.p;
+  fill_point_tables(h, t);
   t.c_end_off = Q.c_end_off;
   t.g_end_base = Q.g_end_base;
   t.flags = 0;

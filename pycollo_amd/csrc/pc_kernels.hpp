@@ -1310,15 +1310,15 @@ __device__ __forceinline__ void tail_point_load(const PcTailArgs& A, PointIn<PT>
   if (threadIdx.x != 0) return;
   constexpr int NPV = PT::NPV, NB = PT::NB, NPH = PT::NPH;
   const bool wantH = A.flags & PC_FLAG_H;
-  static_for<0, NPV>([&](auto i_) { I.px[decltype(i_)::value] = A.point_x[decltype(i_)::value]; });
+  static_for<0, NPV>([&](auto i_) { I.px[decltype(i_)::value] = A.pt_x[decltype(i_)::value]; });
   static_for<0, NPV>([&](auto i_) {
     constexpr int i = decltype(i_)::value;
-    I.V[i] = A.point_V[i];
-    I.xb[i] = I.V[i] * A.x[I.px[i]] + A.point_r[i];
+    I.V[i] = A.pt_V[i];
+    I.xb[i] = I.V[i] * A.x[I.px[i]] + A.pt_r[i];
   });
   static_for<0, NB>([&](auto r_) {
     constexpr int r = decltype(r_)::value;
-    I.We[r] = A.W_end[r];
+    I.We[r] = A.pt_W[r];
     I.lb[r] = wantH ? A.lam[A.c_end_off + r] * I.We[r] : 0.0;
   });
   if (wantH)
