@@ -1,6 +1,6 @@
 """Quick GPU parity sweep (development aid; the real tests live in tests/)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.ref_numpy import OracleNlp
 from pycollo_amd import problems

@@ -1,6 +1,6 @@
 """Per-block error breakdown against the oracle (development aid)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle.ref_numpy import OracleNlp
 from pycollo_amd import problems
