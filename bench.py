@@ -107,8 +107,7 @@ def main():
         G = torch.empty(eng.nnz_jac, dtype=torch.float64, device=dev)
         H = torch.empty(eng.nnz_hess, dtype=torch.float64, device=dev)
 
-        def step():
-            eng.evaluate_all_device(x, 1.0, lam, c, G, H, stream)
+        step = eng.bind_device(x, lam, c, G, H, stream)   # evaluate_all_device with the addresses resolved once
 
         def bulk_only():
             eng.launch_bulk_only(x, lam, c, G, H, stream)

@@ -192,6 +192,11 @@ struct pc_handle {
   hipFunction_t bulk_all_fn = nullptr;   // multi-phase problems: every phase's bulk kernel in one launch
   DevBuf<char> d_phase_args;             // [n_phases] PcPhaseArgs read by pc_bulk_all
   bool args_dirty = true;                // scaling / tile range / partials buffer changed since the last upload
+  // host-side argument blocks, filled once per change of scaling / tile range / partials buffer; a call only
+  // patches the caller's pointers, the flags and sigma into them
+  std::vector<PcPhaseArgs> host_phase_args;
+  PcTailArgs host_tail_args;
+  bool host_args_dirty = true;
   int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
   std::vector<std::unique_ptr<PhaseDev>> pd;
   DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
@@ -370,14 +375,32 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
     bulk = false;
   }
+  if (h->host_args_dirty) {
+    h->host_phase_args.resize(Q.ph.size());
+    for (size_t ip = 0; ip < Q.ph.size(); ++ip)
+      fill_phase_args(h, ip, h->host_phase_args[ip], nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
+    fill_tail_args(h, h->host_tail_args, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
+    h->host_args_dirty = false;
+  }
+  auto patch_tail = [&](PcTailArgs& t) {
+    t.x = d_x; t.lam = d_lam; t.c = d_c; t.G = d_G; t.H = d_H;
+    t.fobj = d_fobj; t.grad = d_grad; t.flags = flags; t.sigma = sigma;
+    t.block_threads = 256;
+  };
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& D = *h->pd[ip];
-    Both both;
-    PcPhaseArgs& a = both.a;
-    fill_phase_args(h, ip, a, d_x, d_lam, d_c, d_G, d_H, flags, (fuse && ip == last) ? 1 : D.wpt);
     if (D.tile_end <= D.tile_begin) continue;
+    PcPhaseArgs& a = h->host_phase_args[ip];
+    const int wpt = (fuse && ip == last) ? 1 : D.wpt;
+    a.x = d_x; a.lam = d_lam; a.c = d_c; a.G = d_G; a.H = d_H;
+    a.flags = flags;
+    a.wpt = wpt;
+    a.block_threads = h->TB * wpt;
     if (fuse && ip == last) {
-      fill_tail_args(h, both.t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
+      Both both;
+      both.a = a;
+      both.t = h->host_tail_args;
+      patch_tail(both.t);
       both.t.block_threads = h->TB;   // the tail runs inside the bulk workgroup
       size_t sz = sizeof(both);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -389,8 +412,8 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
   }
   if (!tail || fuse) return;
-  PcTailArgs t;
-  fill_tail_args(h, t, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, flags, sigma);
+  PcTailArgs& t = h->host_tail_args;
+  patch_tail(t);
   size_t sz = sizeof(t);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
@@ -801,6 +824,7 @@ int pc_set_scaling(pc_handle* h, const double* V, const double* r, const double*
     upload_scaling(h);
     h->scaling_set = true;
     h->args_dirty = true;
+    h->host_args_dirty = true;
   });
 }
 
@@ -843,6 +867,7 @@ int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end) {
     D.tile_end = tile_end;
     h->have_cG = false;
     h->args_dirty = true;
+    h->host_args_dirty = true;
   });
 }
 
@@ -861,6 +886,7 @@ int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials) {
     if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
     h->pd[phase]->partials_ext = d_partials;
     h->args_dirty = true;
+    h->host_args_dirty = true;
   });
 }
 

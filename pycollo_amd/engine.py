@@ -365,6 +365,20 @@ class NlpEngine:
         self._check(self._lib.pc_eval_all_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
                                                  addr(d_G), addr(d_H), stream))
 
+    def bind_device(self, d_x, d_lam, d_c, d_G, d_H, stream=None):
+        """``f(obj_factor)`` = :meth:`evaluate_all_device` on fixed device buffers, with the addresses resolved once.
+        At 10 k nodes an evaluation is ~8 us; resolving five ``data_ptr()`` per call is a visible part of that."""
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        fn, h, err = self._lib.pc_eval_all_device, self._h, self._lib.pc_last_error
+        px, pl, pc, pG, pH = addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H)
+        keep = (d_x, d_lam, d_c, d_G, d_H)       # the buffers must outlive the callable
+
+        def call(obj_factor=1.0, _keep=keep):
+            if not fn(h, px, obj_factor, pl, pc, pG, pH, stream):
+                raise RuntimeError("pc_eval_all_device failed: " + err().decode())
+        return call
+
     def launch_bulk_only(self, d_x, d_lam, d_c, d_G, d_H, stream=None):
         """Profiling aid: only the bulk kernels of :meth:`evaluate_all_device`."""
         def addr(t):
