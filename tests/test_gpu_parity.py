@@ -106,6 +106,26 @@ def test_extreme_orders(built, tab, name, order, K):
         eng.close()
 
 
+def test_bound_device_call(built):
+    """NlpEngine.bind_device: the pre-resolved form of evaluate_all_device writes the same bits."""
+    import torch
+    prob = problems.cart_pole(K=200, order=4)
+    eng = _engine(prob)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(21)
+    x = torch.from_numpy(rng.uniform(-0.4, 0.4, eng.num_x)).to(dev)
+    lam = torch.from_numpy(rng.normal(size=eng.num_c)).to(dev)
+    out = [[torch.full((n,), float("nan"), dtype=torch.float64, device=dev) for n in (eng.num_c, eng.nnz_jac, eng.nnz_hess)]
+           for _ in range(2)]
+    s = torch.cuda.Stream(device=dev)
+    eng.evaluate_all_device(x, 0.7, lam, *out[0], s.cuda_stream)
+    eng.bind_device(x, lam, *out[1], s.cuda_stream)(0.7)
+    s.synchronize()
+    for a, b in zip(*out):
+        assert torch.equal(a, b) and not torch.isnan(a).any()
+    eng.close()
+
+
 def test_known_answers_brachistochrone(built, known_answers):
     """tests/unit/test_iteration.py:305-318, 339-354, 371-385 evaluated by the HIP path."""
     eng = _engine(problems.brachistochrone())
