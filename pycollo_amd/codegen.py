@@ -197,9 +197,10 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("}  // namespace gen\n")
     parts.append("namespace gen {")
     parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase, then the endpoint block")
+    parts.append("  template <bool SERIAL = false>")
     parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a) {")
     parts.append("    pc::PointIn<Point> pin;")
-    parts.append("    pc::tail_point_load<Point>(a, pin);")
+    parts.append("    pc::tail_point_load<Point, SERIAL>(a, pin);")
     parts.append("    pc::tail_begin(a);")
     for pm in model.phases:
         parts.append(f"    pc::tail_phase<Phase{pm.index}>(a, {pm.index});")
@@ -228,7 +229,7 @@ def generate_source(model: Model, orders=None) -> str:
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
                      f'{{ pc::mesh_error<gen::Phase{pm.index}>(a); }}')
-    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run(a); }')
+    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run<false>(a); }')
     parts.append("")
     return "\n".join(parts)
 

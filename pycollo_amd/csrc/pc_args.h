@@ -113,7 +113,7 @@ struct PcTailArgs {
   int64_t c_end_off;            // first endpoint row of c
   int64_t g_end_base;           // CSR offset of the first endpoint row of G
   int32_t n_tail_owned, flags;
-  int32_t block_threads, reserved;   // threads of the workgroup that runs the tail (blockDim.x would be a late scalar load)
+  int32_t block_threads, reserved;   // threads of the workgroup that runs the tail (blockDim.x would be a late scalar load) (blockDim.x would be a late scalar load)
   PcTailPhase ph[PC_MAX_PHASES];
   // the endpoint block's small tables by value: their loads join the argument fetch instead of forming a
   // second dependent round trip through device memory (point_x / point_V / point_r / W_end hold the same data)

@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   STAMP(8);
   if constexpr (FUSED) {
     if (is_last) {
-      TAIL::run(*TA);
+      TAIL::template run<true>(*TA);
       STAMP(10);
     }
   }
@@ -1296,37 +1296,36 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
   }
 }
 
-// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  The inputs are fetched
-// by tail_point_load ahead of the phases' sums (their round trips overlap), the block itself runs after them.
+// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  One lane evaluates the
+// block, but its inputs -- the point variables scattered over x~, the endpoint multipliers, the edge-node Hessian
+// entries the endpoint terms are added to -- are fetched by as many lanes as there are values, all at once, into
+// LDS (tail_point_load, ahead of the phases' sums).  Fetched by the evaluating lane alone they were scalar loads
+// issued a register-file-full at a time: ~9 us of an 11 us tail for Delta III's 56 point variables.
 template <class PT>
 struct PointIn {
-  double xb[PT::NPV > 0 ? PT::NPV : 1], V[PT::NPV > 0 ? PT::NPV : 1], lb[PT::NB > 0 ? PT::NB : 1], We[PT::NB > 0 ? PT::NB : 1];
-  int64_t px[PT::NPV > 0 ? PT::NPV : 1];
-  int64_t hs[PT::NPH > 0 ? PT::NPH : 1];
-  int32_t hl[PT::NPH > 0 ? PT::NPH : 1];
+  double* xb;   // [NPV] unscaled point variables
+  double* lb;   // [NB] scaled endpoint multipliers
+  double* hold; // [NPH] current value of the H entry an endpoint term lands on (edge-node entries only)
 };
-template <class PT>
+template <class PT, bool SERIAL = false>
 __device__ __forceinline__ void tail_point_load(const PcTailArgs& A, PointIn<PT>& I) {
-  if (threadIdx.x != 0) return;
   constexpr int NPV = PT::NPV, NB = PT::NB, NPH = PT::NPH;
+  __shared__ double s_xb[NPV > 0 ? NPV : 1];
+  __shared__ double s_lb[NB > 0 ? NB : 1];
+  __shared__ double s_hold[NPH > 0 ? NPH : 1];
+  I.xb = s_xb;
+  I.lb = s_lb;
+  I.hold = s_hold;
   const bool wantH = A.flags & PC_FLAG_H;
-  static_for<0, NPV>([&](auto i_) { I.px[decltype(i_)::value] = A.pt_x[decltype(i_)::value]; });
-  static_for<0, NPV>([&](auto i_) {
-    constexpr int i = decltype(i_)::value;
-    I.V[i] = A.pt_V[i];
-    I.xb[i] = I.V[i] * A.x[I.px[i]] + A.pt_r[i];
-  });
-  static_for<0, NB>([&](auto r_) {
-    constexpr int r = decltype(r_)::value;
-    I.We[r] = A.pt_W[r];
-    I.lb[r] = wantH ? A.lam[A.c_end_off + r] * I.We[r] : 0.0;
-  });
+  // SERIAL (the fused bulk kernel): the loads stay on one lane.  With the lane-parallel form compiled into that
+  // kernel, unrelated Hessian entries of the double-pendulum model came out wrong (cause not found; the fused build is
+  // an experiment and keeps the form it was validated with).
+  const int tid = SERIAL ? (threadIdx.x == 0 ? 0 : (1 << 20)) : (int)threadIdx.x, TB = SERIAL ? 1 : A.block_threads;
+  for (int i = tid; i < NPV; i += TB) s_xb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
+  for (int r = tid; r < NB; r += TB) s_lb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
   if (wantH)
-    static_for<0, NPH>([&](auto e_) {
-      constexpr int e = decltype(e_)::value;
-      I.hs[e] = A.pt_hslot[e];
-      I.hl[e] = A.pt_hlocal[e];
-    });
+    for (int e = tid; e < NPH; e += TB) s_hold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
+  // (the workgroup barrier of tail_begin, which follows, publishes the three arrays)
 }
 template <class PT>
 __device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT>& I) {
@@ -1334,32 +1333,36 @@ __device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT
   constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
   const double sigma = A.sigma, wJ = A.wJ;
   const bool wantH = A.flags & PC_FLAG_H;
+  double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
+  static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = I.xb[decltype(i_)::value]; });
+  static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = I.lb[decltype(r_)::value]; });
   double Jval, gJ[NGJ > 0 ? NGJ : 1], b[NB > 0 ? NB : 1], jb[NBJ > 0 ? NBJ : 1], hb[NPH > 0 ? NPH : 1];
-  PT::eval(I.xb, sigma * wJ, I.lb, Jval, gJ, b, jb, hb);
+  PT::eval(xb, sigma * wJ, lb, Jval, gJ, b, jb, hb);
   if (A.fobj) A.fobj[0] = wJ * Jval;
   if (A.grad) {
     static_for<0, NGJ>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      A.grad[I.px[PT::gc(e)]] = wJ * gJ[e] * I.V[PT::gc(e)];
+      A.grad[A.pt_x[PT::gc(e)]] = wJ * gJ[e] * A.pt_V[PT::gc(e)];
     });
   }
   if (A.flags & PC_FLAG_C)
     static_for<0, NB>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
-      A.c[A.c_end_off + r] = I.We[r] * b[r];
+      A.c[A.c_end_off + r] = A.pt_W[r] * b[r];
     });
   if (A.flags & PC_FLAG_G)
     static_for<0, NBJ>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      A.G[A.g_end_base + e] = I.We[PT::br(e)] * jb[e] * I.V[PT::bc(e)];
+      A.G[A.g_end_base + e] = A.pt_W[PT::br(e)] * jb[e] * A.pt_V[PT::bc(e)];
     });
   if (wantH) {
     double* hacc = tail_acc();
     static_for<0, NPH>([&](auto e_) {
       constexpr int e = decltype(e_)::value;
-      const double val = hb[e] * I.V[PT::phr(e)] * I.V[PT::phc(e)];
-      if (I.hl[e] >= 0) hacc[I.hl[e]] += val;
-      else A.H[I.hs[e]] += val;   // an edge-node entry the bulk kernels wrote: add the endpoint term to it
+      const double val = hb[e] * A.pt_V[PT::phr(e)] * A.pt_V[PT::phc(e)];
+      const int hl = A.pt_hlocal[e];
+      if (hl >= 0) hacc[hl] += val;
+      else A.H[A.pt_hslot[e]] = I.hold[e] + val;   // an edge-node entry the bulk kernels wrote, plus the endpoint term
     });
   }
 }
