@@ -150,6 +150,9 @@ def _phase_struct(pm: PhaseModel) -> str:
     return "\n".join(lines)
 
 
+POINT_PARTS = 4   # the endpoint block is cut into this many parts, one per wave of the tail workgroup (PC_TAIL_THREADS / 64)
+
+
 def _point_struct(pt: PointModel) -> str:
     xb_in = {pv.symbol: sym.Symbol(f"xb[{i}]") for i, pv in enumerate(pt.vars)}
     inputs = dict(xb_in)
@@ -160,20 +163,41 @@ def _point_struct(pt: PointModel) -> str:
     outs += [(f"b[{i}]", e) for i, e in enumerate(pt.b)]
     outs += [(f"jb[{i}]", e) for i, (_, _, e) in enumerate(pt.b_jac)]
     outs += [(f"hb[{i}]", e) for i, (_, _, e) in enumerate(pt.hess)]
-    body = [f"    constexpr double {k} = {float(val)!r};" for k, val in pt.consts]
-    body += _emit_block(inputs, outs, "w")
+    # deal the outputs to POINT_PARTS parts, heaviest first onto the lightest part (operation counts before CSE);
+    # the objective value and gradient stay together in part 0's list so that part 0 always exists
+    cost = [max(1, int(sym.count_ops(sym.sympify(e)))) for _, e in outs]
+    part = [0] * len(outs)
+    load = [0] * POINT_PARTS
+    n_obj = 1 + len(pt.J_grad)
+    load[0] = sum(cost[:n_obj])
+    for i in sorted(range(n_obj, len(outs)), key=lambda i: -cost[i]):
+        g = min(range(POINT_PARTS), key=lambda g: load[g])
+        part[i] = g
+        load[g] += cost[i]
+    consts = [f"    constexpr double {k} = {float(val)!r};" for k, val in pt.consts]
+    o_b, o_jb, o_hb = n_obj, n_obj + len(pt.b), n_obj + len(pt.b) + len(pt.b_jac)
     lines = ["struct Point {",
              f"  static constexpr int NPV = {len(pt.vars)}, NB = {len(pt.b)}, NGJ = {len(pt.J_grad)}, "
-             f"NBJ = {len(pt.b_jac)}, NPH = {len(pt.hess)};",
+             f"NBJ = {len(pt.b_jac)}, NPH = {len(pt.hess)}, NPARTS = {POINT_PARTS};",
              _constexpr_table("gc", [c for c, _ in pt.J_grad]),
              _constexpr_table("br", [r for r, _, _ in pt.b_jac]),
              _constexpr_table("bc", [c for _, c, _ in pt.b_jac]),
              _constexpr_table("phr", [r for r, _, _ in pt.hess]),
              _constexpr_table("phc", [c for _, c, _ in pt.hess]),
-             "  __device__ static __forceinline__ void eval(const double* __restrict__ xb, double sw, const double* __restrict__ lb,",
-             "      double& Jval, double* __restrict__ gJ, double* __restrict__ b, double* __restrict__ jb, double* __restrict__ hb) {",
-             "    (void)xb; (void)sw; (void)lb; (void)gJ; (void)b; (void)jb; (void)hb;"]
-    lines += body
+             "  // which part evaluates an endpoint row / Jacobian entry / Hessian entry (the objective is part 0's)",
+             _constexpr_table("part_b", part[o_b:o_jb]),
+             _constexpr_table("part_jb", part[o_jb:o_hb]),
+             _constexpr_table("part_hb", part[o_hb:])]
+    sig = ("(const double* __restrict__ xb, double sw, const double* __restrict__ lb,\n"
+           "      double& Jval, double* __restrict__ gJ, double* __restrict__ b, double* __restrict__ jb, double* __restrict__ hb) {")
+    void = "    (void)xb; (void)sw; (void)lb; (void)Jval; (void)gJ; (void)b; (void)jb; (void)hb;"
+    lines += ["  __device__ static __forceinline__ void eval" + sig, void] + consts + _emit_block(inputs, outs, "w") + ["  }"]
+    for g in range(POINT_PARTS):
+        mine = [o for o, pg in zip(outs, part) if pg == g]
+        lines += [f"  __device__ static __forceinline__ void eval_part{g}" + sig, void] + consts + _emit_block(inputs, mine, "w") + ["  }"]
+    lines += ["  template <int G> __device__ static __forceinline__ void eval_part" + sig]
+    for g in range(POINT_PARTS):
+        lines.append(f"    if constexpr (G == {g}) eval_part{g}(xb, sw, lb, Jval, gJ, b, jb, hb);")
     lines += ["  }", "};", ""]
     return "\n".join(lines)
 
@@ -229,7 +253,7 @@ def generate_source(model: Model, orders=None) -> str:
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
                      f'{{ pc::mesh_error<gen::Phase{pm.index}>(a); }}')
-    parts.append('extern "C" __global__ void __launch_bounds__(256) pc_tail(PcTailArgs a) { gen::Tail::run<false>(a); }')
+    parts.append('extern "C" __global__ void __launch_bounds__(PC_TAIL_THREADS) pc_tail(PcTailArgs a) { gen::Tail::run<false>(a); }')
     parts.append("")
     return "\n".join(parts)
 

@@ -253,7 +253,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.g_end_base = Q.g_end_base;
   t.n_tail_owned = (int32_t)Q.tail_owned.size();
   t.flags = flags;
-  t.block_threads = 256;
+  t.block_threads = PC_TAIL_THREADS;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
@@ -385,7 +385,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   auto patch_tail = [&](PcTailArgs& t) {
     t.x = d_x; t.lam = d_lam; t.c = d_c; t.G = d_G; t.H = d_H;
     t.fobj = d_fobj; t.grad = d_grad; t.flags = flags; t.sigma = sigma;
-    t.block_threads = 256;
+    t.block_threads = PC_TAIL_THREADS;
   };
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& D = *h->pd[ip];
@@ -416,7 +416,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   patch_tail(t);
   size_t sz = sizeof(t);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
+  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, st, nullptr, cfg));
 }
 
 void upload_scaling(pc_handle* h) {
@@ -979,7 +979,7 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   t.c_end_off = Q.c_end_off;
   t.g_end_base = Q.g_end_base;
   t.flags = 0;
-  t.block_threads = 256;
+  t.block_threads = PC_TAIL_THREADS;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     t.ph[ip].n_tiles = 0;
     t.ph[ip].partials = h->pd[ip]->partials.p;
@@ -991,7 +991,7 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   }
   size_t sz = sizeof(t);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, 256, 1, 1, 0, h->stream, nullptr, cfg));
+  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, h->stream, nullptr, cfg));
   HIP_OK(hipMemcpyAsync(h->h_fobj.p, h->d_fobj.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (want_grad)
     HIP_OK(hipMemcpyAsync(h->h_grad.p, h->d_grad.p, Q.num_x * sizeof(double), hipMemcpyDeviceToHost, h->stream));

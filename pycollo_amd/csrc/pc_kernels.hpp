@@ -1199,10 +1199,10 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
   using St = S<M>;
   constexpr int NZ = St::NZ, NQ = St::NQ, NP = St::NP, NY = St::NY, NS = St::NS, NT = St::NT, NRED = St::NRED;
   if constexpr (NRED > 0) {
-    __shared__ double s_part[NRED * 4];
+    __shared__ double s_part[NRED * 16];
     __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = A.block_threads;  // 1 to 4 waves (64 .. 256 threads)
+    const int tid = threadIdx.x, TB = A.block_threads;  // 1 to 16 waves
     // lane 0's own inputs are requested before the partial sums so that the two round trips overlap
     const double* sc = P.scal;
     const int N = P.N;
@@ -1232,15 +1232,15 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
     static_for<0, NRED>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
       const double w = wave_sum(acc[r]);
-      if ((tid & 63) == 0) s_part[r * 4 + (tid >> 6)] = w;
+      if ((tid & 63) == 0) s_part[r * 16 + (tid >> 6)] = w;
     });
     lds_barrier();
     if (tid == 0) {
       const int nw = (TB + 63) >> 6;
       static_for<0, NRED>([&](auto r_) {
         constexpr int r = decltype(r_)::value;
-        double tot = s_part[r * 4];
-        for (int w = 1; w < nw; ++w) tot += s_part[r * 4 + w];
+        double tot = s_part[r * 16];
+        for (int w = 1; w < nw; ++w) tot += s_part[r * 16 + w];
         s_sum[r] = tot;
       });
       double* hacc = tail_acc();
@@ -1301,70 +1301,108 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
 // entries the endpoint terms are added to -- are fetched by as many lanes as there are values, all at once, into
 // LDS (tail_point_load, ahead of the phases' sums).  Fetched by the evaluating lane alone they were scalar loads
 // issued a register-file-full at a time: ~9 us of an 11 us tail for Delta III's 56 point variables.
+// A small block (few inputs) keeps the earlier form: lane 0 fetches its inputs with scalar loads into registers
+// and evaluates every part itself -- the LDS round trip of the wide form costs such a block ~0.4 us.
 template <class PT>
 struct PointIn {
+  static constexpr bool SMALL = (PT::NPV + PT::NB + PT::NPH) <= 16;
   double* xb;   // [NPV] unscaled point variables
   double* lb;   // [NB] scaled endpoint multipliers
   double* hold; // [NPH] current value of the H entry an endpoint term lands on (edge-node entries only)
+  double rxb[PT::NPV > 0 ? PT::NPV : 1], rlb[PT::NB > 0 ? PT::NB : 1], rhold[PT::NPH > 0 ? PT::NPH : 1];   // SMALL
 };
 template <class PT, bool SERIAL = false>
 __device__ __forceinline__ void tail_point_load(const PcTailArgs& A, PointIn<PT>& I) {
   constexpr int NPV = PT::NPV, NB = PT::NB, NPH = PT::NPH;
-  __shared__ double s_xb[NPV > 0 ? NPV : 1];
-  __shared__ double s_lb[NB > 0 ? NB : 1];
-  __shared__ double s_hold[NPH > 0 ? NPH : 1];
-  I.xb = s_xb;
-  I.lb = s_lb;
-  I.hold = s_hold;
   const bool wantH = A.flags & PC_FLAG_H;
-  // SERIAL (the fused bulk kernel): the loads stay on one lane.  With the lane-parallel form compiled into that
-  // kernel, unrelated Hessian entries of the double-pendulum model came out wrong (cause not found; the fused build is
-  // an experiment and keeps the form it was validated with).
-  const int tid = SERIAL ? (threadIdx.x == 0 ? 0 : (1 << 20)) : (int)threadIdx.x, TB = SERIAL ? 1 : A.block_threads;
-  for (int i = tid; i < NPV; i += TB) s_xb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
-  for (int r = tid; r < NB; r += TB) s_lb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
-  if (wantH)
-    for (int e = tid; e < NPH; e += TB) s_hold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
-  // (the workgroup barrier of tail_begin, which follows, publishes the three arrays)
-}
-template <class PT>
-__device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT>& I) {
-  if (threadIdx.x != 0) return;
-  constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
-  const double sigma = A.sigma, wJ = A.wJ;
-  const bool wantH = A.flags & PC_FLAG_H;
-  double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
-  static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = I.xb[decltype(i_)::value]; });
-  static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = I.lb[decltype(r_)::value]; });
-  double Jval, gJ[NGJ > 0 ? NGJ : 1], b[NB > 0 ? NB : 1], jb[NBJ > 0 ? NBJ : 1], hb[NPH > 0 ? NPH : 1];
-  PT::eval(xb, sigma * wJ, lb, Jval, gJ, b, jb, hb);
-  if (A.fobj) A.fobj[0] = wJ * Jval;
-  if (A.grad) {
-    static_for<0, NGJ>([&](auto e_) {
-      constexpr int e = decltype(e_)::value;
-      A.grad[A.pt_x[PT::gc(e)]] = wJ * gJ[e] * A.pt_V[PT::gc(e)];
+  if constexpr (PointIn<PT>::SMALL) {
+    I.xb = I.rxb;
+    I.lb = I.rlb;
+    I.hold = I.rhold;
+    if (threadIdx.x != 0) return;
+    static_for<0, NPV>([&](auto i_) {
+      constexpr int i = decltype(i_)::value;
+      I.rxb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
     });
-  }
-  if (A.flags & PC_FLAG_C)
     static_for<0, NB>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
-      A.c[A.c_end_off + r] = A.pt_W[r] * b[r];
+      I.rlb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
     });
-  if (A.flags & PC_FLAG_G)
-    static_for<0, NBJ>([&](auto e_) {
-      constexpr int e = decltype(e_)::value;
-      A.G[A.g_end_base + e] = A.pt_W[PT::br(e)] * jb[e] * A.pt_V[PT::bc(e)];
-    });
-  if (wantH) {
-    double* hacc = tail_acc();
-    static_for<0, NPH>([&](auto e_) {
-      constexpr int e = decltype(e_)::value;
-      const double val = hb[e] * A.pt_V[PT::phr(e)] * A.pt_V[PT::phc(e)];
-      const int hl = A.pt_hlocal[e];
-      if (hl >= 0) hacc[hl] += val;
-      else A.H[A.pt_hslot[e]] = I.hold[e] + val;   // an edge-node entry the bulk kernels wrote, plus the endpoint term
-    });
+    if (wantH)
+      static_for<0, NPH>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        I.rhold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
+      });
+  } else {
+    __shared__ double s_xb[NPV > 0 ? NPV : 1];
+    __shared__ double s_lb[NB > 0 ? NB : 1];
+    __shared__ double s_hold[NPH > 0 ? NPH : 1];
+    I.xb = s_xb;
+    I.lb = s_lb;
+    I.hold = s_hold;
+    // SERIAL (the fused bulk kernel): the loads stay on one lane.  With the lane-parallel form compiled into that
+    // kernel, unrelated Hessian entries of the double-pendulum model came out wrong (cause not found; the fused build
+    // is an experiment and keeps the form it was validated with).
+    const int tid = SERIAL ? (threadIdx.x == 0 ? 0 : (1 << 20)) : (int)threadIdx.x, TB = SERIAL ? 1 : A.block_threads;
+    for (int i = tid; i < NPV; i += TB) s_xb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
+    for (int r = tid; r < NB; r += TB) s_lb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
+    if (wantH)
+      for (int e = tid; e < NPH; e += TB) s_hold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
+    // (the workgroup barrier of tail_begin, which follows, publishes the three arrays)
   }
+}
+// The block is generated in PT::NPARTS parts of similar cost (codegen.py); lane 0 of wave w evaluates the parts
+// g with g % waves == w and stores what they produce, so a 256-thread tail runs four parts side by side.
+template <class PT>
+__device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT>& I) {
+  constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
+  constexpr bool SMALL = PointIn<PT>::SMALL;
+  // the phases' sums (lane 0 of wave 0) must be in the LDS accumulator before another wave adds to it
+  if constexpr (!SMALL) lds_barrier();
+  const int tid = threadIdx.x, wave = tid >> 6, nw = SMALL ? 1 : (A.block_threads + 63) >> 6;
+  if ((tid & 63) != 0 || (SMALL && tid != 0)) return;
+  const double sigma = A.sigma, wJ = A.wJ;
+  const bool wantH = A.flags & PC_FLAG_H;
+  static_for<0, PT::NPARTS>([&](auto g_) {
+    constexpr int g = decltype(g_)::value;
+    if (g % nw != wave) return;
+    double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
+    static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = I.xb[decltype(i_)::value]; });
+    static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = I.lb[decltype(r_)::value]; });
+    double Jval = 0.0, gJ[NGJ > 0 ? NGJ : 1], b[NB > 0 ? NB : 1], jb[NBJ > 0 ? NBJ : 1], hb[NPH > 0 ? NPH : 1];
+    PT::template eval_part<g>(xb, sigma * wJ, lb, Jval, gJ, b, jb, hb);
+    if constexpr (g == 0) {
+      if (A.fobj) A.fobj[0] = wJ * Jval;
+      if (A.grad) {
+        static_for<0, NGJ>([&](auto e_) {
+          constexpr int e = decltype(e_)::value;
+          A.grad[A.pt_x[PT::gc(e)]] = wJ * gJ[e] * A.pt_V[PT::gc(e)];
+        });
+      }
+    }
+    if (A.flags & PC_FLAG_C)
+      static_for<0, NB>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if constexpr (PT::part_b(r) == g) A.c[A.c_end_off + r] = A.pt_W[r] * b[r];
+      });
+    if (A.flags & PC_FLAG_G)
+      static_for<0, NBJ>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr (PT::part_jb(e) == g) A.G[A.g_end_base + e] = A.pt_W[PT::br(e)] * jb[e] * A.pt_V[PT::bc(e)];
+      });
+    if (wantH) {
+      double* hacc = tail_acc();
+      static_for<0, NPH>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr (PT::part_hb(e) == g) {
+          const double val = hb[e] * A.pt_V[PT::phr(e)] * A.pt_V[PT::phc(e)];
+          const int hl = A.pt_hlocal[e];
+          if (hl >= 0) hacc[hl] += val;
+          else A.H[A.pt_hslot[e]] = I.hold[e] + val;   // an edge-node entry the bulk kernels wrote, plus the endpoint term
+        }
+      });
+    }
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
