@@ -19,4 +19,5 @@ run cart_pole15k --problem cart_pole --sections 5000 --order 4 --steps 1000 --wa
 run shuttle60k --problem shuttle --sections 20000 --order 4 --steps 300 --warmup 30 &&
 run shuttle600k --problem shuttle --sections 200000 --order 4 --steps 50 --warmup 10 &&
 run delta_iii12k --problem delta_iii --sections 3125 --order 5 --steps 100 --warmup 10 &&
-run shuttle6k --problem shuttle --sections 2000 --order 4 --steps 1000 --warmup 100
+run shuttle6k --problem shuttle --sections 2000 --order 4 --steps 1000 --warmup 100 &&
+run space_station6k --problem space_station --sections 2000 --order 4 --steps 300 --warmup 30
