@@ -1023,11 +1023,18 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
   }
   };
-  if constexpr (!SPLIT) deposit_partials();
+  // PC_FUSED_EARLY: the fused build's first design -- arrive right after the Hessian phase so that the tail overlaps
+  // the last workgroup's own c~/G~ work; it makes every workgroup drain its stores in mid-life (~1 us each).  The
+  // default fused build arrives at the very end instead (the drain is the one a kernel end performs anyway).
+#ifndef PC_FUSED_EARLY
+#define PC_FUSED_EARLY 0
+#endif
+  constexpr bool EARLY = FUSED && PC_FUSED_EARLY;
+  __shared__ int s_last;
+  auto arrive = [&]() {
   if constexpr (FUSED) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (payload is sc1)
     __syncthreads();
-    __shared__ int s_last;
     if (tid == 0) {
       const unsigned nblk = (unsigned)A.n_blocks;   // (gridDim would be read from the dispatch packet in host memory)
       const unsigned nsh = nblk < PC_SYNC_SHARDS ? nblk : PC_SYNC_SHARDS;
@@ -1048,10 +1055,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     __syncthreads();
     is_last = s_last != 0;
     STAMP(9);
-    if (is_last) {   // ONE acquire; its latency overlaps this workgroup's own c~/G~ work below
+    if (is_last) {   // ONE acquire (early arrival: its latency overlaps this workgroup's own c~/G~ work below)
       if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if constexpr (!EARLY) __syncthreads();   // the other waves read only after the acquiring wave has passed it
     }
   }
+  };
+  if constexpr (!SPLIT && (!FUSED || EARLY)) deposit_partials();
+  if constexpr (EARLY) arrive();
   STAMP(6);
   if (A.dbg_stage == 5) return;
   // ---- Jacobian of the defect rows (compiled.py:305-334), one state at a time:
@@ -1153,9 +1164,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       A.partials[(int64_t)tile * NRED + tid] = s;
     }
   }
+  if constexpr (FUSED && !EARLY) {   // everything this workgroup writes is out: deposit the sums, arrive
+    deposit_partials();
+    arrive();
+  }
   STAMP(7);
   if (A.dbg_stage == 6) return;
-  if constexpr (FUSED) {
+  if constexpr (EARLY) {
     if (is_last) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
