@@ -62,6 +62,9 @@ def main():
     if not args.no_pin:
         from pycollo_amd.hostpin import pin_launch_thread
         pinned_cpu, full_mask = pin_launch_thread(local_rank, world)
+        if os.environ.get("PYCOLLO_AMD_SPIN_PROBE"):
+            from pycollo_amd.hostpin import spin_seconds
+            print(f"spin probe: cpu {pinned_cpu} {spin_seconds() * 1e3:.3f} ms", file=sys.stderr, flush=True)
 
     import torch
     import torch.distributed as dist
@@ -168,6 +171,18 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    colocated = []
+    if not args.no_pin:   # the runtime's completion thread next to the launching thread (pycollo_amd/hostpin.py)
+        from pycollo_amd.hostpin import colocate_runtime_threads
+
+        def burst():
+            for _ in range(max(200, min(3000, args.warmup))):
+                step()
+            torch.cuda.synchronize()
+        burst()
+        colocated = colocate_runtime_threads(burst)
+    extra["runtime_threads_colocated"] = len(colocated)
 
     for _ in range(args.warmup):
         step()

@@ -4,8 +4,9 @@ An evaluation at BASELINE.json's headline size is two ~3 us kernel launches for 
 host side is on the critical path.  Left to the scheduler on the 256-CPU host of an MI355X box, the launching
 thread and the runtime's helper threads migrate between cores and the launch cost drifts between ~3.2 and
 ~5.8 us per launch from one process to the next (measured: 90k / 121k evals/s unpinned against 125-128k on any
-single core, tools/ab_affinity.sh).  Pinning must happen before the first HIP call so that the runtime's own
-threads inherit the mask.
+single core, tools/ab_affinity.sh).  Pinning happens before the first HIP call so that the threads the runtime
+creates inherit the mask -- except the one that matters most: the runtime's completion thread gets its affinity
+reset to every CPU by the runtime itself, and ``colocate_runtime_threads`` moves it next to the launcher afterwards.
 """
 from __future__ import annotations
 
@@ -18,6 +19,20 @@ def _current_cpu() -> int:
         return int(ctypes.CDLL(None).sched_getcpu())
     except (OSError, AttributeError):
         return -1
+
+
+def spin_seconds(reps: int = 3, n: int = 100_000) -> float:
+    """Best-of-``reps`` time of a fixed interpreter loop on the current core: a busy SMT sibling or a clocked-down
+    core shows up here before any HIP call is made."""
+    import time
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        acc = 0
+        for i in range(n):
+            acc += i
+        best = min(best, time.perf_counter() - t0)
+    return best
 
 
 def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int]]:
@@ -44,6 +59,89 @@ def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int
     mine = set(allowed[lo:lo + min(stride, 8)])
     os.sched_setaffinity(0, mine)
     return allowed[lo], set(allowed)
+
+
+def _parse_cpulist(text: str) -> set[int]:
+    out: set[int] = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.update(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _l3_peers(cpu: int) -> set[int]:
+    """CPUs that share the last-level cache with ``cpu`` (one CCD on an EPYC host); empty if sysfs does not say."""
+    for idx in (3, 2):
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/cache/index{idx}/shared_cpu_list") as f:
+                return _parse_cpulist(f.read())
+        except (OSError, ValueError):
+            continue
+    return set()
+
+
+def _thread_run_ns() -> dict[int, int]:
+    """On-CPU time of every thread of this process, in ns (schedstat) or 10 ms ticks scaled to ns (stat)."""
+    out = {}
+    try:
+        tids = os.listdir("/proc/self/task")
+    except OSError:
+        return out
+    for t in tids:
+        try:
+            with open(f"/proc/self/task/{t}/schedstat") as f:
+                out[int(t)] = int(f.read().split()[0])
+        except (OSError, ValueError, IndexError):
+            try:
+                with open(f"/proc/self/task/{t}/stat") as f:
+                    st = f.read()
+                fld = st[st.rindex(")") + 2:].split()
+                out[int(t)] = (int(fld[11]) + int(fld[12])) * 10_000_000
+            except (OSError, ValueError, IndexError):
+                pass
+    return out
+
+
+def colocate_runtime_threads(burst, min_share: float = 0.03) -> list[int]:
+    """Move the HIP runtime's busy helper threads next to the launching thread; returns the thread ids moved.
+
+    The ROCm runtime keeps one thread that wakes on every kernel completion (it runs ~30 % of a core at 250 k
+    launches/s) and resets that thread's affinity to every CPU, so pinning the process before HIP initialises does
+    not place it.  Where the scheduler leaves it decides the launch cost: measured on the 2-socket MI355X host
+    (tools/core_sweep.py, tools/thread_probe.py) the headline loop runs at 128-131 k evals/s with the helper in the
+    launcher's L3 domain, 110-123 k on the same socket and 87-99 k across sockets -- the "slow mode" one process
+    in three used to land in.  ``burst`` is a callable that launches for a few tens of ms and synchronises; threads
+    other than the caller that are on a CPU for more than ``min_share`` of it are the ones moved."""
+    if not hasattr(os, "sched_setaffinity"):
+        return []
+    import threading
+    import time
+    me = threading.get_native_id()
+    mask = os.sched_getaffinity(0)
+    if len(mask) == 1:
+        cpu = next(iter(mask))
+        target = _l3_peers(cpu) - {cpu}
+    else:
+        target = set(mask)           # a rank's slice of cores: the helper shares it
+    if not target:
+        return []
+    before = _thread_run_ns()
+    t0 = time.perf_counter()
+    burst()
+    wall_ns = (time.perf_counter() - t0) * 1e9
+    after = _thread_run_ns()
+    moved = []
+    for tid, ns in after.items():
+        if tid == me or ns - before.get(tid, ns) < min_share * wall_ns:
+            continue
+        try:
+            os.sched_setaffinity(tid, target)
+            moved.append(tid)
+        except OSError:              # outside the cgroup's cpuset, or the thread has gone
+            pass
+    return moved
 
 
 def restore_affinity(mask: set[int]) -> None:
