@@ -180,6 +180,7 @@ struct pc_handle {
   pcp::Problem Q;
   int device = -1;
   int TB = 64;
+  int TC = 64;   // nodes a tile may hold (<= TB)
   bool scaling_set = false;
   double w_J = 1.0;
   // quadrature
@@ -588,8 +589,18 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       while (TB > 64 && !fits(TB)) TB /= 2;
     }
     h->TB = TB;
+    // Tile capacity in nodes (<= TB): a tile smaller than its workgroup leaves lanes idle but shortens every
+    // wave's store phase and puts more waves on the chip -- what a problem with far fewer tiles than SIMDs wants.
+    int TC = TB, max_nk = 2;
+    for (auto& P : Q.ph)
+      for (int k = 0; k < P.K; ++k) max_nk = std::max(max_nk, P.n_k[k]);
+    if (const char* env = std::getenv("PYCOLLO_AMD_TILE_NODES")) {
+      const int v = std::atoi(env);
+      if (v >= max_nk && v <= TB) TC = v;
+    }
+    h->TC = TC;
     if (const char* env = std::getenv("PYCOLLO_AMD_DBG_STAGE")) h->dbg_stage = std::atoi(env);
-    pcp::build_all(Q, TB);
+    pcp::build_all(Q, TC);
     if (Q.point_x.size() > PC_MAX_POINT || Q.n_b > PC_MAX_ENDPOINT_ROWS)
       throw std::runtime_error("too many endpoint variables / endpoint constraints for the tail kernel's argument block");
     if (Q.tail_owned.size() > PC_TAIL_OWNED_MAX)
@@ -619,7 +630,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       bool same = true;
       for (int k = 0; k < P.K; ++k) same = same && P.n_k[k] == P.n_k[0];
       D.uni_n = same ? P.n_k[0] : 0;
-      D.spt = same ? (TB - 1) / (P.n_k[0] - 1) : 0;
+      D.spt = same ? (TC - 1) / (P.n_k[0] - 1) : 0;
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, Q.n_s, TB);
