@@ -277,6 +277,12 @@ def _occupancy_attr() -> str:
     return f"__attribute__((amdgpu_waves_per_eu({w},{w}))) " if w > 0 else ""
 
 
+def _fp_contract() -> str:
+    """Experiment knob PYCOLLO_AMD_FP_CONTRACT: 'off' (default, see build_code_object) or 'fast'."""
+    v = os.environ.get("PYCOLLO_AMD_FP_CONTRACT", "off").strip().lower()
+    return v if v in ("off", "fast", "on") else "off"
+
+
 def _kernels_stamp() -> str:
     h = hashlib.sha256()
     for fn in ("pc_kernels.hpp", "pc_args.h"):
@@ -302,6 +308,8 @@ def _orders_tag(model: Model, orders) -> str:
 
 def code_object_path(model: Model, orders=None) -> str:
     occ = f"_w{_waves_per_eu()}" if _waves_per_eu() > 0 else ""
+    if _fp_contract() != "off":
+        occ += "_fc" + _fp_contract()
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
@@ -324,7 +332,7 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
         f.write(generate_source(model, orders))
     # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
     # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", "-ffp-contract=off",
+    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
            f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

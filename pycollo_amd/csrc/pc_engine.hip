@@ -736,7 +736,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.hsum_slot.upload(P.hsum_slot);
       D.hsum_local.upload(P.hsum_local);
       D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
-      if (h->dbg_stage == 9) D.dbg.alloc((size_t)16 * D.n_tiles);
+      if (h->dbg_stage == 9) D.dbg.alloc((size_t)64 * D.n_tiles);   // 4 waves x 16 stamps per tile
     }
     h->d_sync.upload(std::vector<unsigned>((PC_SYNC_SHARDS + 1) * 16, 0u));
     if (const char* env = std::getenv("PYCOLLO_AMD_FUSE")) h->allow_fuse = std::atoi(env) != 0;
@@ -1046,7 +1046,7 @@ int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles) {
     auto& D = *h->pd.at(phase);
     if (!D.dbg.p) throw std::runtime_error("no stamps: create the handle with PYCOLLO_AMD_DBG_STAGE=9");
     HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(out, D.dbg.p, sizeof(long long) * 16 * std::min(n_tiles, D.n_tiles), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(out, D.dbg.p, sizeof(long long) * 64 * std::min(n_tiles, D.n_tiles), hipMemcpyDeviceToHost));
   });
 }
 

@@ -46,6 +46,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------------------------
 // compile-time structure derived from the model's non-zero lists
 // ---------------------------------------------------------------------------------------------
+// threshold of the two-pass build (see pc::bulk)
+#ifndef PC_SPLIT_MIN
+#define PC_SPLIT_MIN 90
+#endif
+
 template <class M>
 struct S {
   static constexpr int NY = M::NY, NU = M::NU, NZ = M::NY + M::NU, NQ = M::NQ, NP = M::NP, NS = M::NS;
@@ -535,14 +540,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   const int blk = block >= 0 ? block : xcd_major((int)blockIdx.x, A.n_blocks);
   const int tile = blk - first_block + A.tile_begin;
   if (A.dbg_stage == 1) return;
-  // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of every tile
-  // stamps s_memtime at the phase boundaries into a buffer of its own
-  const bool stamping = (A.dbg_stage == 9) && threadIdx.x == 0;
+  // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of each of a tile's
+  // (up to four) waves stamps s_memtime at the phase boundaries into a buffer of its own
+  const bool stamping = (A.dbg_stage == 9) && (threadIdx.x & 63) == 0;
   auto STAMP = [&](int k) {
     if (stamping) {
       unsigned long long tm;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
-      A.dbg[(int64_t)tile * 16 + k] = (long long)tm;
+      A.dbg[((int64_t)tile * 4 + (threadIdx.x >> 6)) * 16 + k] = (long long)tm;
     }
   };
   STAMP(0);
@@ -811,9 +816,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
   // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
   // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
-#ifndef PC_SPLIT_MIN
-#define PC_SPLIT_MIN 90
-#endif
   constexpr bool SPLIT = !FUSED && (NJ + NH >= PC_SPLIT_MIN);
   double mult[NFN > 0 ? NFN : 1];
   if (active) {
@@ -1155,6 +1157,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     deposit_partials();
   }
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
+  STAMP(11);
   if constexpr (NRED > 0 && !FUSED) {
     block_sync();
     if (tid < NRED) {

@@ -24,18 +24,26 @@ s = torch.cuda.Stream(device=dev)
 for _ in range(200):
     eng.evaluate_all_device(x, 1.0, lam, c, G, H, s.cuda_stream)
 torch.cuda.synchronize()
-nt = eng.info["n_tiles_total"]
-out = np.zeros((nt, 16), dtype=np.int64)
+nt = eng.info["n_tiles_total"] if len(prob.phases) == 1 else None
 eng._lib.pc_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-assert eng._lib.pc_debug_stamps(eng._h, 0, out.ctypes.data, nt)
-d = np.diff(out[:, :9], axis=1)
-names = ["loads+staging+sync", "geometry+mu", "eval+LDS f+sync", "defect c", "path+integral", "hessian+partials", "defect G", "end"]
-print(f"{name} K={K} n={order} TB={tpb}: tiles {nt}; cycles per phase (median over tiles; each stamp costs ~250-500 cycles itself)")
-for i, nm in enumerate(names):
-    print(f"  {nm:22s} {np.median(d[:, i]):8.0f}   (min {d[:, i].min():6d}, max {d[:, i].max():6d})")
-print(f"  total                  {np.median(out[:, 8] - out[:, 0]):8.0f} cycles = {np.median(out[:, 8] - out[:, 0]) / 100:.2f} us at 100 MHz stamp clock")
-if out[:, 9].max() > 0:
-    print(f"  fused: hessian+partials+drain+arrival (stamp5->9) median {np.median(out[:, 9] - out[:, 5]):.0f} max {(out[:, 9] - out[:, 5]).max()}")
-    lastb = int(np.argmax(out[:, 10]))
-    print(f"  fused: last workgroup = tile {lastb}: start->arrival {out[lastb, 9] - out[lastb, 0]}, arrival->own work done {out[lastb, 8] - out[lastb, 9]}, tail {out[lastb, 10] - out[lastb, 8]} cycles")
-    print(f"  fused: whole kernel (first start -> tail end) {out[lastb, 10] - out[:, 0].min()} cycles; first start -> last non-tail end {out[:, 8].max() - out[:, 0].min()}")
+names = ["loads+staging+sync", "geometry+mu", "eval+LDS f+sync", "defect c", "path+integral", "hessian+partials", "defect G (+2nd pass)", "meet+end"]
+for ip in range(len(prob.phases)):
+    ntp = nt if nt is not None else 4096
+    raw = np.zeros((ntp, 4, 16), dtype=np.int64)
+    try:
+        assert eng._lib.pc_debug_stamps(eng._h, ip, raw.ctypes.data, ntp)
+    except AssertionError:
+        print("no stamps for phase", ip); continue
+    raw = raw[raw[:, 0, 0] > 0]
+    print(f"{name} K={K} n={order} TB={tpb} W={eng.info['waves_per_tile']} phase {ip}: {len(raw)} tiles; s_memtime ticks (shader clock, ~2.1-2.4 GHz) per stage, median over tiles, per wave of the tile")
+    for w in range(4):
+        o = raw[:, w, :]
+        o = o[o[:, 0] > 0]
+        if not len(o):
+            continue
+        seq = np.stack([o[:, 0], o[:, 1], o[:, 2], o[:, 3], o[:, 4], o[:, 5], o[:, 6], o[:, 11], o[:, 7]], axis=1)
+        d = np.diff(seq, axis=1)
+        print(f"  wave {w}: " + " | ".join(f"{nm} {np.median(d[:, i]):.0f}" for i, nm in enumerate(names)) + f" | total {np.median(seq[:, -1] - seq[:, 0]):.0f} ticks")
+    t0 = raw[:, :, 0][raw[:, :, 0] > 0].min()
+    en = raw[:, :, 7].max() - t0
+    print(f"  first start -> last end: {en} ticks")
