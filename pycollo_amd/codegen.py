@@ -235,8 +235,13 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("}  // namespace gen\n")
     occ = _occupancy_attr()
     for pm in model.phases:
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(PcPhaseArgs a) '
-                     f'{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a); }}')
+        # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(const double* x, '
+                     'const double* lam, long long x_off, long long c_off, int N, int K, int tile_begin, int spt, '
+                     'int n_blocks, int flags_wpt, PcPhaseArgs a) {')
+        parts.append('  const PcLead ld{x, lam, x_off, c_off, N, K, tile_begin, spt, n_blocks, flags_wpt};')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, nullptr, nullptr, 0, -1, &ld);')
+        parts.append('}')
     if len(model.phases) > 1:
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(PcMultiArgs m) {')
@@ -283,6 +288,15 @@ def _fp_contract() -> str:
     return v if v in ("off", "fast", "on") else "off"
 
 
+def _preload_count() -> int:
+    """Leading kernel arguments the command processor preloads into SGPRs (pc_bulk_p<i>: the ten of PcLead = 14
+    dwords, all the user SGPRs there are next to the kernarg pointer).  PYCOLLO_AMD_PRELOAD=0 turns it off."""
+    try:
+        return max(0, int(os.environ.get("PYCOLLO_AMD_PRELOAD", "10")))
+    except ValueError:
+        return 10
+
+
 def _kernels_stamp() -> str:
     h = hashlib.sha256()
     for fn in ("pc_kernels.hpp", "pc_args.h"):
@@ -310,6 +324,8 @@ def code_object_path(model: Model, orders=None) -> str:
     occ = f"_w{_waves_per_eu()}" if _waves_per_eu() > 0 else ""
     if _fp_contract() != "off":
         occ += "_fc" + _fp_contract()
+    if _preload_count() != 10:
+        occ += f"_pl{_preload_count()}"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
@@ -333,6 +349,7 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
     # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
     cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
+           "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}",
            f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -61,6 +61,22 @@ struct PcPhaseArgs {
   int64_t hoff[PC_MAX_HOFF];  // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
 };
 
+// The first 14 dwords of pc_bulk_p<i>'s argument block, passed as leading scalar kernel parameters: the command
+// processor preloads them into SGPRs with the dispatch (kernarg preload), so a wave can address its node loads
+// without waiting for a scalar load of the block first.  Copies of the PcPhaseArgs fields of the same name.
+struct PcLead {
+  const double* x;
+  const double* lam;
+  int64_t x_off, c_off;
+  int32_t N, K, tile_begin, spt, n_blocks;
+  int32_t flags_wpt;   // flags | wpt << 8
+};
+// what the host hands to pc_bulk_p<i>: (lead scalars..., PcPhaseArgs a)
+struct PcBulkArgs {
+  PcLead lead;
+  PcPhaseArgs a;
+};
+
 #define PC_MAX_PHASES 8
 
 // One launch for the bulk kernels of every phase of a multi-phase problem (`pc_bulk_all`): workgroup b belongs to

@@ -195,7 +195,7 @@ struct pc_handle {
   bool args_dirty = true;                // scaling / tile range / partials buffer changed since the last upload
   // host-side argument blocks, filled once per change of scaling / tile range / partials buffer; a call only
   // patches the caller's pointers, the flags and sigma into them
-  std::vector<PcPhaseArgs> host_phase_args;
+  std::vector<PcBulkArgs> host_bulk_args;   // per phase: lead scalars + argument block, kept filled between calls
   PcTailArgs host_tail_args;
   bool host_args_dirty = true;
   int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
@@ -377,9 +377,9 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     bulk = false;
   }
   if (h->host_args_dirty) {
-    h->host_phase_args.resize(Q.ph.size());
+    h->host_bulk_args.resize(Q.ph.size());
     for (size_t ip = 0; ip < Q.ph.size(); ++ip)
-      fill_phase_args(h, ip, h->host_phase_args[ip], nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
+      fill_phase_args(h, ip, h->host_bulk_args[ip].a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
     fill_tail_args(h, h->host_tail_args, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
     h->host_args_dirty = false;
   }
@@ -391,7 +391,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& D = *h->pd[ip];
     if (D.tile_end <= D.tile_begin) continue;
-    PcPhaseArgs& a = h->host_phase_args[ip];
+    PcPhaseArgs& a = h->host_bulk_args[ip].a;
     const int wpt = (fuse && ip == last) ? 1 : D.wpt;
     a.x = d_x; a.lam = d_lam; a.c = d_c; a.G = d_G; a.H = d_H;
     a.flags = flags;
@@ -407,8 +407,11 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
       HIP_OK(hipModuleLaunchKernel(D.fn_fused, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
     } else {
-      size_t sz = sizeof(a);
-      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      // (lead scalars..., PcPhaseArgs): the lead is what the command processor preloads into SGPRs (pc_args.h)
+      PcBulkArgs& ba = h->host_bulk_args[ip];
+      ba.lead = PcLead{a.x, a.lam, a.x_off, a.c_off, a.N, a.K, a.tile_begin, a.spt, a.n_blocks, a.flags | (a.wpt << 8)};
+      size_t sz = sizeof(ba);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ba, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
       HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB * D.wpt, 1, 1, D.lds_bytes, st, nullptr, cfg));
     }
   }

@@ -398,29 +398,91 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 // pointers and flags come from MA, the workgroup's tile from its index relative to the phase's first block.
 template <class M, int UN, class TAIL = void>
 __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr, const PcMultiArgs* MA = nullptr,
-                                     int first_block = 0, int block = -1) {
+                                     int first_block = 0, int block = -1, const PcLead* LD = nullptr) {
   constexpr bool FUSED = !std::is_void<TAIL>::value;
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
   BulkIn<St> A;
-  if (MA) {
-    A.x = MA->x; A.lam = MA->lam; A.c = MA->c; A.G = MA->G; A.H = MA->H;
+  // part 1: what the node loads are addressed with.  pc_bulk_p<i> gets these as leading scalar arguments, which the
+  // command processor preloads into SGPRs (LD); the other launches read them from their argument block like the rest.
+  if (LD) {
+    A.x = LD->x; A.lam = LD->lam; A.x_off = LD->x_off; A.c_off = LD->c_off; A.N = LD->N; A.K = LD->K;
+    A.tile_begin = LD->tile_begin; A.spt = LD->spt; A.n_blocks = LD->n_blocks;
+    A.flags = LD->flags_wpt & 0xff; A.wpt = LD->flags_wpt >> 8;
   } else {
-    A.x = KA.x; A.lam = KA.lam; A.c = KA.c; A.G = KA.G; A.H = KA.H;
+    A.x = MA ? MA->x : KA.x; A.lam = MA ? MA->lam : KA.lam; A.x_off = KA.x_off; A.c_off = KA.c_off; A.N = KA.N; A.K = KA.K;
+    A.tile_begin = KA.tile_begin; A.spt = KA.spt; A.n_blocks = KA.n_blocks;
+    A.flags = MA ? MA->flags : KA.flags; A.wpt = KA.wpt;
   }
-  A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; A.sec_h = KA.sec_h; A.sec_E = KA.sec_E;
-  A.qa = KA.qa; A.qw = KA.qw; A.hslot0 = KA.hslot0; A.hslotN = KA.hslotN; A.partials = KA.partials; A.dbg = KA.dbg;
-  A.sync = KA.sync; A.tab = KA.tab;
-  A.x_off = KA.x_off; A.s_off = KA.s_off; A.c_off = KA.c_off; A.c_path_off = KA.c_path_off; A.c_int_off = KA.c_int_off;
-  A.t_fixed[0] = KA.t_fixed[0]; A.t_fixed[1] = KA.t_fixed[1];
-  A.N = KA.N; A.K = KA.K; A.flags = MA ? MA->flags : KA.flags; A.qa_total = KA.qa_total; A.qw_total = KA.qw_total;
-  A.tile_begin = KA.tile_begin; A.uni_n = KA.uni_n; A.spt = KA.spt; A.lds_out = KA.lds_out; A.dbg_stage = KA.dbg_stage;
-  A.wpt = KA.wpt; A.n_blocks = KA.n_blocks; A.block_threads = KA.block_threads;
-  A.qa0 = KA.qa_off[UN > 0 ? UN : 0]; A.qw0 = KA.qw_off[UN > 0 ? UN : 0];
-  static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KA.scal[decltype(i_)::value]; });
-  static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KA.goff[decltype(i_)::value]; });
-  static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KA.hoff[decltype(i_)::value]; });
+  if constexpr (UN == 0) { A.uni_n = KA.uni_n; A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; }
+  // ---- this workgroup's tile and this lane's node, then the node loads, before anything else: with the lead
+  //      scalars preloaded (pc_bulk_p<i>) their addresses need no scalar load, so the longest latency of the
+  //      prologue starts at the wave's first instructions and everything below overlaps it
+  const int N = A.N;
+  // (a single-phase launch is swizzled here; pc_bulk_all swizzles before it picks the phase and passes `first_block`
+  //  relative to the swizzled index, together with that index)
+  const int blk = block >= 0 ? block : xcd_major((int)blockIdx.x, A.n_blocks);
+  const int tile = blk - first_block + A.tile_begin;
+  // tile geometry: index arithmetic on a uniform mesh, two small tables otherwise
+  const int un = UN > 0 ? UN : A.uni_n;
+  const bool uni = UN > 0 || un > 0;
+  int k0, k1, n0, n1;
+  if (uni) {
+    k0 = tile * A.spt;
+    k1 = min(k0 + A.spt, A.K);
+    n0 = k0 * (un - 1);
+    n1 = k1 * (un - 1);
+  } else {
+    k0 = A.tile_k0[tile];
+    k1 = A.tile_k0[tile + 1];
+    n0 = A.tile_n0[tile];
+    n1 = A.tile_n0[tile + 1];
+  }
+  const int T = n1 - n0;                 // defect rows per state in this tile; nodes n0 .. n0+T
+  const int tid = threadIdx.x;
+  const int W = A.wpt;                                        // 1, 2 or 4
+  const int t = W > 1 ? (tid & 63) : tid;                     // node slot of this lane inside its replica
+  const bool active = t <= T;
+  const int node = n0 + t;
+  double v[NV > 0 ? NV : 1];
+  if (active) {
+    static_for<0, NZ>([&](auto b_) {
+      constexpr int b = decltype(b_)::value;
+      v[b] = A.x[A.x_off + (int64_t)b * N + node];
+    });
+  }
+  // part 2: everything else, fetched while the node loads are in flight.  With preloaded lead scalars the argument
+  // block is read through the kernarg segment pointer passed through an empty asm, so that the scalar loads below
+  // (and the wait their first use needs) depend on a point after the node loads and cannot be hoisted above them.
+  auto part2 = [&](const auto& KB) {
+    if (MA) {
+      A.c = MA->c; A.G = MA->G; A.H = MA->H;
+    } else {
+      A.c = KB.c; A.G = KB.G; A.H = KB.H;
+    }
+    if constexpr (UN > 0) { A.uni_n = KB.uni_n; A.tile_k0 = KB.tile_k0; A.tile_n0 = KB.tile_n0; }
+    A.sec_s = KB.sec_s; A.sec_h = KB.sec_h; A.sec_E = KB.sec_E;
+    A.qa = KB.qa; A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials; A.dbg = KB.dbg;
+    A.sync = KB.sync; A.tab = KB.tab;
+    A.s_off = KB.s_off; A.c_path_off = KB.c_path_off; A.c_int_off = KB.c_int_off;
+    A.t_fixed[0] = KB.t_fixed[0]; A.t_fixed[1] = KB.t_fixed[1];
+    A.qa_total = KB.qa_total; A.qw_total = KB.qw_total;
+    A.lds_out = KB.lds_out; A.dbg_stage = KB.dbg_stage;
+    A.block_threads = KB.block_threads;
+    A.qa0 = KB.qa_off[UN > 0 ? UN : 0]; A.qw0 = KB.qw_off[UN > 0 ? UN : 0];
+    static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KB.scal[decltype(i_)::value]; });
+    static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KB.goff[decltype(i_)::value]; });
+    static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KB.hoff[decltype(i_)::value]; });
+  };
+  if (LD) {
+    typedef const __attribute__((address_space(4))) char* kseg_t;
+    kseg_t kseg = (kseg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kseg)::"memory");
+    part2(*(const __attribute__((address_space(4))) PcPhaseArgs*)(kseg + sizeof(PcLead)));
+  } else {
+    part2(KA);
+  }
   // (only what this build of the kernel can use: everything pinned is live in SGPRs from here on, and the file has
   //  ~100 of them -- an over-full pin list is loaded in several dependent batches and partly spilled to VGPR lanes)
   // Two groups.  The first is what the per-node loads and the table staging need (pointers, offsets, geometry);
@@ -480,8 +542,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // functions are cheap next to a SIMD that would otherwise idle) and produces a disjoint subset of the output
   // runs -- states, Hessian row blocks, path rows are dealt round-robin.  W > 1 only with TN = 64 (a replica is
   // exactly one wave, so its private staging region needs no workgroup barrier).
-  const int tid = threadIdx.x, TB = A.block_threads;   // (blockDim.x is a separate, late scalar load)
-  const int W = A.wpt;                                        // 1, 2 or 4
+  const int TB = A.block_threads;   // (blockDim.x is a separate, late scalar load)
   const int TN = W > 1 ? 64 : TB;
   const int w = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // wave-uniform: branches on it are scalar
   const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
@@ -534,11 +595,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   };
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
-  const int N = A.N;
-  // (a single-phase launch is swizzled here; pc_bulk_all swizzles before it picks the phase and passes `first_block`
-  //  relative to the swizzled index, together with that index)
-  const int blk = block >= 0 ? block : xcd_major((int)blockIdx.x, A.n_blocks);
-  const int tile = blk - first_block + A.tile_begin;
   if (A.dbg_stage == 1) return;
   // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of each of a tile's
   // (up to four) waves stamps s_memtime at the phase boundaries into a buffer of its own
@@ -552,28 +608,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   };
   STAMP(0);
 
-  // ---- tile geometry: index arithmetic on a uniform mesh, two small tables otherwise ----------------
-  const int un = UN > 0 ? UN : A.uni_n;
-  const bool uni = UN > 0 || un > 0;
-  int k0, k1, n0, n1;
-  if (uni) {
-    k0 = tile * A.spt;
-    k1 = min(k0 + A.spt, A.K);
-    n0 = k0 * (un - 1);
-    n1 = k1 * (un - 1);
-  } else {
-    k0 = A.tile_k0[tile];
-    k1 = A.tile_k0[tile + 1];
-    n0 = A.tile_n0[tile];
-    n1 = A.tile_n0[tile + 1];
-  }
   const bool has_prev = k0 > 0;
   const int kp = has_prev ? k0 - 1 : 0;  // first staged section
   const int nsec = k1 - kp;              // staged sections (previous one included)
   const bool last_tile = (k1 == A.K);
-  const int T = n1 - n0;                 // defect rows per state in this tile; nodes n0 .. n0+T
 
-  // ---- per-node loads are issued before any staging so that their latency overlaps it -------------
+  // ---- the rest of the per-node loads are issued before any staging so that their latency overlaps it ------
   // kernarg-resident (scalar registers) or the LDS copy, see PINNED above
   double* s_tab = smem + lp.tab;
   const double* sc;
@@ -588,18 +628,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     goff = reinterpret_cast<const int64_t*>(s_tab + St::NSCAL);
     hoff = goff + NFN;
   }
-  const int t = tid - w * TN;
-  const bool active = t <= T;
-  const int node = n0 + t;
   const bool owns = active && (t < T || last_tile);
-  double v[NV > 0 ? NV : 1], F[NFN > 0 ? NFN : 1], Jv[NJ > 0 ? NJ : 1], Hv[NH > 0 ? NH : 1], mu[NFN > 0 ? NFN : 1];
+  double F[NFN > 0 ? NFN : 1], Jv[NJ > 0 ? NJ : 1], Hv[NH > 0 ? NH : 1], mu[NFN > 0 ? NFN : 1];
   double red[NRED > 0 ? NRED : 1];
   static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });
   if (active) {
-    static_for<0, NZ>([&](auto b_) {
-      constexpr int b = decltype(b_)::value;
-      v[b] = A.x[A.x_off + (int64_t)b * N + node];
-    });
     static_for<0, NS>([&](auto l_) {
       constexpr int l = decltype(l_)::value;
       v[NZ + l] = A.x[A.s_off + l];
