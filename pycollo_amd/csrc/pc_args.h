@@ -141,6 +141,21 @@ struct PcTailArgs {
   double pt_W[PC_MAX_ENDPOINT_ROWS];
 };
 
+// The first 12 dwords of pc_tail's argument block, as leading scalar kernel parameters (preloaded into SGPRs like
+// PcLead): what the partial-sum loads and lane 0's loads of the FIRST phase are addressed with.  Copies of
+// PcTailArgs::x / flags / block_threads and of ph[0].{partials, scal, x_off, n_tiles, N}.
+struct PcTailLead {
+  const double* x;
+  const double* partials0;
+  const double* scal0;
+  int64_t x_off0;
+  int32_t n_tiles0, N0, flags, block_threads;
+};
+struct PcTailLaunch {   // what the host hands to pc_tail: (lead scalars..., PcTailArgs a)
+  PcTailLead lead;
+  PcTailArgs t;
+};
+
 // Arguments of the ph mesh-error kernel (pycollo/mesh_refinement.py:63-240).
 struct PcRefineArgs {
   const double* x;          // [num_x] scaled solution

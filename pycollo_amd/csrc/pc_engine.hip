@@ -196,7 +196,7 @@ struct pc_handle {
   // host-side argument blocks, filled once per change of scaling / tile range / partials buffer; a call only
   // patches the caller's pointers, the flags and sigma into them
   std::vector<PcBulkArgs> host_bulk_args;   // per phase: lead scalars + argument block, kept filled between calls
-  PcTailArgs host_tail_args;
+  PcTailLaunch host_tail_launch;   // lead scalars + argument block of pc_tail, kept filled between calls
   bool host_args_dirty = true;
   int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
   std::vector<std::unique_ptr<PhaseDev>> pd;
@@ -380,7 +380,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     h->host_bulk_args.resize(Q.ph.size());
     for (size_t ip = 0; ip < Q.ph.size(); ++ip)
       fill_phase_args(h, ip, h->host_bulk_args[ip].a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
-    fill_tail_args(h, h->host_tail_args, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
+    fill_tail_args(h, h->host_tail_launch.t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
     h->host_args_dirty = false;
   }
   auto patch_tail = [&](PcTailArgs& t) {
@@ -400,7 +400,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     if (fuse && ip == last) {
       Both both;
       both.a = a;
-      both.t = h->host_tail_args;
+      both.t = h->host_tail_launch.t;
       patch_tail(both.t);
       both.t.block_threads = h->TB;   // the tail runs inside the bulk workgroup
       size_t sz = sizeof(both);
@@ -416,10 +416,12 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
   }
   if (!tail || fuse) return;
-  PcTailArgs& t = h->host_tail_args;
+  PcTailLaunch& tl = h->host_tail_launch;
+  PcTailArgs& t = tl.t;
   patch_tail(t);
-  size_t sz = sizeof(t);
-  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  tl.lead = PcTailLead{t.x, t.ph[0].partials, t.ph[0].scal, t.ph[0].x_off, t.ph[0].n_tiles, t.ph[0].N, t.flags, t.block_threads};
+  size_t sz = sizeof(tl);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, st, nullptr, cfg));
 }
 
@@ -978,8 +980,9 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
   copy_x_in(h, x);
   if (want_grad) HIP_OK(hipMemsetAsync(h->d_grad.p, 0, Q.num_x * sizeof(double), h->stream));
   // flags = 0: the bulk kernels are skipped entirely, only the endpoint block runs
-  PcTailArgs t;
-  std::memset(&t, 0, sizeof(t));
+  PcTailLaunch tl;
+  std::memset(&tl, 0, sizeof(tl));
+  PcTailArgs& t = tl.t;
   t.x = h->d_x.p;
   t.fobj = h->d_fobj.p;
   t.grad = want_grad ? h->d_grad.p : nullptr;
@@ -1003,8 +1006,9 @@ static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
     t.ph[ip].t_fixed[0] = Q.ph[ip].t_fixed[0];
     t.ph[ip].t_fixed[1] = Q.ph[ip].t_fixed[1];
   }
-  size_t sz = sizeof(t);
-  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &t, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  tl.lead = PcTailLead{t.x, t.ph[0].partials, t.ph[0].scal, t.ph[0].x_off, t.ph[0].n_tiles, t.ph[0].N, t.flags, t.block_threads};
+  size_t sz = sizeof(tl);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, h->stream, nullptr, cfg));
   HIP_OK(hipMemcpyAsync(h->h_fobj.p, h->d_fobj.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (want_grad)

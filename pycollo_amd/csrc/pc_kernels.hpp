@@ -1244,42 +1244,64 @@ __device__ __forceinline__ void tail_end(const PcTailArgs& A) {
     for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) A.H[A.tail_owned[i]] = acc[i];
 }
 
-// Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.
+// Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.  In two steps, so
+// that the loads of the first phase can be issued at the very start of the kernel from preloaded scalars (PcTailLead).
 template <class M>
-__device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
+struct TailPhaseRegs {
   using St = S<M>;
-  constexpr int NZ = St::NZ, NQ = St::NQ, NP = St::NP, NY = St::NY, NS = St::NS, NT = St::NT, NRED = St::NRED;
+  double xt[2], vt[2], rt[2];
+  double xq[St::NQ > 0 ? St::NQ : 1], wi[St::NQ > 0 ? St::NQ : 1], vq[St::NQ > 0 ? St::NQ : 1], rq[St::NQ > 0 ? St::NQ : 1];
+  double vs[St::NS > 0 ? St::NS : 1], acc[St::NRED > 0 ? St::NRED : 1];
+};
+template <class M>
+__device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R, const PcTailLead* L = nullptr) {
+  using St = S<M>;
+  constexpr int NZ = St::NZ, NQ = St::NQ, NS = St::NS, NT = St::NT, NRED = St::NRED;
   if constexpr (NRED > 0) {
-    __shared__ double s_part[NRED * 16];
-    __shared__ double s_sum[NRED];
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = A.block_threads;  // 1 to 16 waves
+    const int tid = threadIdx.x, TB = L ? L->block_threads : A.block_threads;  // 1 to 16 waves
+    const double* xv = L ? L->x : A.x;
     // lane 0's own inputs are requested before the partial sums so that the two round trips overlap
-    const double* sc = P.scal;
-    const int N = P.N;
-    const int64_t q_off = P.x_off + (int64_t)NZ * N, t_off = q_off + NQ;
-    double xt[2] = {0.0, 0.0}, vt[2] = {0.0, 0.0}, rt[2] = {0.0, 0.0}, xq[NQ > 0 ? NQ : 1], wi[NQ > 0 ? NQ : 1];
-    double vq[NQ > 0 ? NQ : 1], rq[NQ > 0 ? NQ : 1], vs[NS > 0 ? NS : 1];
+    const double* sc = L ? L->scal0 : P.scal;
+    const int N = L ? L->N0 : P.N;
+    const int64_t q_off = (L ? L->x_off0 : P.x_off) + (int64_t)NZ * N, t_off = q_off + NQ;
+    double (&xt)[2] = R.xt, (&vt)[2] = R.vt, (&rt)[2] = R.rt;
+    auto& xq = R.xq; auto& wi = R.wi; auto& vq = R.vq; auto& rq = R.rq; auto& vs = R.vs; auto& acc = R.acc;
+    xt[0] = xt[1] = vt[0] = vt[1] = rt[0] = rt[1] = 0.0;
     if (tid == 0) {
       static_for<0, NT>([&](auto j_) {
         constexpr int j = decltype(j_)::value;
-        xt[j] = A.x[t_off + j];
+        xt[j] = xv[t_off + j];
         vt[j] = sc[St::O_VT + j];
         rt[j] = sc[St::O_RT + j];
       });
       static_for<0, NQ>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
-        xq[m] = A.x[q_off + m];
+        xq[m] = xv[q_off + m];
         wi[m] = sc[St::O_WI + m];
         vq[m] = sc[St::O_VQ + m];
         rq[m] = sc[St::O_RQ + m];
       });
       static_for<0, NS>([&](auto l_) { vs[decltype(l_)::value] = sc[St::O_VS + decltype(l_)::value]; });
     }
-    double acc[NRED];
     static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
-    for (int b = tid; b < P.n_tiles; b += TB)
-      static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += P.partials[(int64_t)b * NRED + decltype(r_)::value]; });
+    const double* part = L ? L->partials0 : P.partials;
+    const int nt = L ? L->n_tiles0 : P.n_tiles;
+    for (int b = tid; b < nt; b += TB)
+      static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += part[(int64_t)b * NRED + decltype(r_)::value]; });
+  }
+}
+template <class M>
+__device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R) {
+  using St = S<M>;
+  constexpr int NZ = St::NZ, NQ = St::NQ, NP = St::NP, NY = St::NY, NS = St::NS, NT = St::NT, NRED = St::NRED;
+  if constexpr (NRED > 0) {
+    __shared__ double s_part[NRED * 16];
+    __shared__ double s_sum[NRED];
+    const PcTailPhase& P = A.ph[ip];
+    const int tid = threadIdx.x, TB = A.block_threads;
+    double (&xt)[2] = R.xt, (&vt)[2] = R.vt, (&rt)[2] = R.rt;
+    auto& xq = R.xq; auto& wi = R.wi; auto& vq = R.vq; auto& rq = R.rq; auto& vs = R.vs; auto& acc = R.acc;
     static_for<0, NRED>([&](auto r_) {
       constexpr int r = decltype(r_)::value;
       const double w = wave_sum(acc[r]);
@@ -1345,6 +1367,12 @@ __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
       }
     }
   }
+}
+template <class M>
+__device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
+  TailPhaseRegs<M> R;
+  tail_phase_issue<M>(A, ip, R);
+  tail_phase_finish<M>(A, ip, R);
 }
 
 // Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  One lane evaluates the
