@@ -36,6 +36,22 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
     for k, v in entry["kernels"].items():
         if "FETCH_SIZE_KB" in v and "WRITE_SIZE_KB" in v:
             v["hbm_bytes_per_launch"] = int(round((2 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024))
+    # the same run's own bench line (HIP events inside the profiled process) and rocprof's durations split by loop:
+    # dispatches of the bulk-only loop (what bench.py's roofline times) against those inside evaluations
+    if bench:
+        entry["bench_under_profiler"] = {"avg_launch_us": bench["roofline"]["avg_launch_us"], "evals_per_s": bench["value"]}
+    tr = glob.glob(os.path.join(d, "stats", "**", "*_kernel_trace.csv"), recursive=True)
+    if tr:
+        kr = [r for r in csv.DictReader(open(tr[0])) if r["Kernel_Name"].startswith("pc_")]
+        kr.sort(key=lambda r: int(r["Start_Timestamp"]))
+        solo, pair = [], []
+        for i, r in enumerate(kr):
+            if r["Kernel_Name"].startswith("pc_bulk"):
+                nxt = kr[i + 1]["Kernel_Name"] if i + 1 < len(kr) else ""
+                (pair if nxt == "pc_tail" else solo).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        if solo and pair:
+            entry["rocprof_bulk_split"] = {"bulk_only_loop": {"calls": len(solo), "avg_ns": round(sum(solo) / len(solo), 1)},
+                                           "inside_evaluations": {"calls": len(pair), "avg_ns": round(sum(pair) / len(pair), 1)}}
     summary[name] = entry
 with open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w") as f:
     json.dump(summary, f, indent=1)
