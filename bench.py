@@ -181,7 +181,16 @@ def main():
                 step()
             torch.cuda.synchronize()
         burst()
-        colocated = colocate_runtime_threads(burst)
+        extra["pin_survived_hip_init"] = (world > 1) or os.sched_getaffinity(0) == {pinned_cpu}
+        if world == 1 and full_mask:   # one rank: also choose the launching core by measurement
+            from pycollo_amd.hostpin import tune_launch_core
+            best, timings = tune_launch_core(burst, full_mask)
+            if best >= 0:
+                extra["launch_thread_cpu"] = best
+                extra["launch_core_probe"] = [[c, round(t * 1e3, 3)] for c, t in timings]
+            colocated = [0]   # (moved inside tune_launch_core)
+        else:
+            colocated = colocate_runtime_threads(burst)
     extra["runtime_threads_colocated"] = len(colocated)
 
     for _ in range(args.warmup):

@@ -46,6 +46,9 @@ def pin_launch_thread(local_rank: int = 0, world: int = 1) -> tuple[int, set[int
     allowed = sorted(os.sched_getaffinity(0))
     if world <= 1:
         cpu = _current_cpu()
+        forced = os.environ.get("PYCOLLO_AMD_PIN_CPU", "")   # experiment knob: start on this core
+        if forced.isdigit() and int(forced) in allowed:
+            cpu = int(forced)
         if cpu not in allowed:
             cpu = allowed[0]
         width = max(1, int(os.environ.get("PYCOLLO_AMD_PIN_WIDTH", "1")))   # experiment knob: cores in the slice
@@ -142,6 +145,72 @@ def colocate_runtime_threads(burst, min_share: float = 0.03) -> list[int]:
         except OSError:              # outside the cgroup's cpuset, or the thread has gone
             pass
     return moved
+
+
+def tune_launch_core(burst, allowed: set[int], tries: int = 4) -> tuple[int, list[tuple[int, float]]]:
+    """Pick the launching core by measurement; returns (cpu chosen, [(cpu, seconds per burst), ...]).
+
+    Not every core launches equally fast on the shared 256-CPU host: two of sixteen processes that happened to start
+    on one particular CCD ran the headline loop at 87-93 k evals/s against 140-146 k everywhere else
+    (tools/core_probe.sh), with the runtime's completion thread correctly placed next to them.  ``burst`` (a few
+    thousand launches + a synchronise) is timed on the current core and on ``tries - 1`` cores spread over the other
+    L3 domains of ``allowed``, each time with the runtime's busy threads moved alongside; the fastest wins."""
+    if not hasattr(os, "sched_setaffinity") or not allowed:
+        return -1, []
+    import time
+    mask = os.sched_getaffinity(0)
+    if len(mask) == 1:
+        cur = next(iter(mask))
+    else:
+        # the pin made before HIP initialised did not survive (seen in about one process in eight on the MI355X
+        # host: the calling thread comes back from the runtime's start-up with its full mask) -- pin again
+        cur = _current_cpu()
+        if cur not in allowed:
+            cur = sorted(allowed)[0]
+        os.sched_setaffinity(0, {cur})
+    order = sorted(allowed)
+    cands = [cur]
+    if cur in order and tries > 1:
+        # spread over the machine; a candidate sharing a last-level cache with an earlier one is skipped, and the
+        # odd offset keeps the walk from landing on SMT siblings (cpu + n/2) of earlier candidates only
+        i0, step = order.index(cur), max(1, len(order) // tries) + 9
+        k = 1
+        while len(cands) < tries and k < 4 * tries:
+            c = order[(i0 + k * step) % len(order)]
+            if all(c not in (_l3_peers(x) or {x}) for x in cands):
+                cands.append(c)
+            k += 1
+    helpers = None
+    timings = []
+    for cpu in cands:
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except OSError:
+            continue
+        if helpers is None:
+            helpers = colocate_runtime_threads(burst)      # finds them (and runs a burst doing so)
+        else:
+            _confine(helpers, _l3_peers(cpu) - {cpu})
+        burst()                                            # settle on the new core
+        t0 = time.perf_counter()
+        burst()
+        timings.append((cpu, time.perf_counter() - t0))
+    if not timings:
+        return -1, []
+    best = min(timings, key=lambda t: t[1])[0]
+    os.sched_setaffinity(0, {best})
+    _confine(helpers or [], _l3_peers(best) - {best})
+    return best, timings
+
+
+def _confine(tids, target: set[int]) -> None:
+    if not target:
+        return
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, target)
+        except OSError:
+            pass
 
 
 def restore_affinity(mask: set[int]) -> None:

@@ -4,7 +4,7 @@ import os
 import pytest
 
 from pycollo_amd.hostpin import (_l3_peers, _parse_cpulist, colocate_runtime_threads, pin_launch_thread,
-                                 restore_affinity)
+                                 restore_affinity, tune_launch_core)
 
 pytestmark = pytest.mark.skipif(not hasattr(os, "sched_setaffinity"), reason="no affinity control on this platform")
 
@@ -66,4 +66,20 @@ def test_busy_helper_thread_is_moved_next_to_the_launcher():
         assert os.sched_getaffinity(0) == {cpu}
     finally:
         stop.set(); idle_go.set(); busy.join(); idle.join()
+        restore_affinity(full)
+
+
+def test_launch_core_is_chosen_among_the_probed_ones():
+    import time
+    full = os.sched_getaffinity(0)
+    try:
+        cpu, prev = pin_launch_thread()
+        best, timings = tune_launch_core(lambda: time.sleep(0.005), prev, tries=4)
+        assert best in prev and best in [c for c, _ in timings]
+        assert timings[0][0] == cpu                      # the current core is always a candidate
+        assert os.sched_getaffinity(0) == {best}
+        # candidates come from different last-level-cache domains
+        doms = [frozenset(_l3_peers(c) or {c}) for c, _ in timings]
+        assert len(set(doms)) == len(doms)
+    finally:
         restore_affinity(full)
