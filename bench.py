@@ -62,6 +62,7 @@ def main():
     if not args.no_pin:
         from pycollo_amd.hostpin import pin_launch_thread
         pinned_cpu, full_mask = pin_launch_thread(local_rank, world)
+        pinned_mask = os.sched_getaffinity(0)
         if os.environ.get("PYCOLLO_AMD_SPIN_PROBE"):
             from pycollo_amd.hostpin import spin_seconds
             print(f"spin probe: cpu {pinned_cpu} {spin_seconds() * 1e3:.3f} ms", file=sys.stderr, flush=True)
@@ -181,7 +182,9 @@ def main():
                 step()
             torch.cuda.synchronize()
         burst()
-        extra["pin_survived_hip_init"] = (world > 1) or os.sched_getaffinity(0) == {pinned_cpu}
+        extra["pin_survived_hip_init"] = os.sched_getaffinity(0) == pinned_mask
+        if world > 1 and not extra["pin_survived_hip_init"]:
+            os.sched_setaffinity(0, pinned_mask)   # this rank's slice again (HIP's start-up reset it)
         if world == 1 and full_mask:   # one rank: also choose the launching core by measurement
             from pycollo_amd.hostpin import tune_launch_core
             best, timings = tune_launch_core(burst, full_mask)
