@@ -241,10 +241,10 @@ def generate_source(model: Model, orders=None) -> str:
     occ = _occupancy_attr()
     for pm in model.phases:
         # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(const double* x, '
-                     'const double* lam, long long x_off, long long c_off, int N, int K, int tile_begin, int spt, '
-                     'int n_blocks, int flags_wpt, PcPhaseArgs a) {')
-        parts.append('  const PcLead ld{x, lam, x_off, c_off, N, K, tile_begin, spt, n_blocks, flags_wpt};')
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(const double* xz, '
+                     'const double* lamd, const double* qa, const double* sec_h, int N, int K, int tile_begin, '
+                     'int n_blocks, int wa, int wb, PcPhaseArgs a) {')
+        parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
         parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, nullptr, nullptr, 0, -1, &ld);')
         parts.append('}')
     if len(model.phases) > 1:

@@ -65,11 +65,13 @@ struct PcPhaseArgs {
 // processor preloads them into SGPRs with the dispatch (kernarg preload), so a wave can address its node loads
 // without waiting for a scalar load of the block first.  Copies of the PcPhaseArgs fields of the same name.
 struct PcLead {
-  const double* x;
-  const double* lam;
-  int64_t x_off, c_off;
-  int32_t N, K, tile_begin, spt, n_blocks;
-  int32_t flags_wpt;   // flags | wpt << 8
+  const double* xz;     // x + x_off: the phase's first node value
+  const double* lamd;   // lam + c_off: the phase's first defect multiplier (null without PC_FLAG_H)
+  const double* qa;     // packed A tables, the packed weight tables right behind them (qw == qa + qa_total)
+  const double* sec_h;  // section widths
+  int32_t N, K, tile_begin, n_blocks;
+  int32_t wa;           // flags | wpt << 8 | (block_threads / 64) << 12 | spt << 16
+  int32_t wb;           // uniform order n: qa_off[n] | (qa_total + qw_off[n]) << 16 (both relative to qa); else 0
 };
 // what the host hands to pc_bulk_p<i>: (lead scalars..., PcPhaseArgs a)
 struct PcBulkArgs {

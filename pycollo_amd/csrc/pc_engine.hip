@@ -200,7 +200,7 @@ struct pc_handle {
   bool host_args_dirty = true;
   int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
   std::vector<std::unique_ptr<PhaseDev>> pd;
-  DevBuf<double> d_qa, d_qw, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
+  DevBuf<double> d_qa, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
   DevBuf<int32_t> d_pt_hlocal;
   std::vector<double> h_pointV, h_pointr, h_Wend;   // host copies: travel by value in PcTailArgs
@@ -292,7 +292,7 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.sec_h = D.sec_h.p;
   a.sec_E = D.sec_E.p;
   a.qa = h->d_qa.p;
-  a.qw = h->d_qw.p;
+  a.qw = h->d_qa.p + h->qa.size();
   if (D.scal_host.size() > PC_MAX_SCAL) throw std::runtime_error("too many scaling constants for the kernel argument block");
   for (size_t i = 0; i < D.scal_host.size(); ++i) a.scal[i] = D.scal_host[i];
   for (size_t i = 0; i < P.goff.size(); ++i) a.goff[i] = P.goff[i];
@@ -409,7 +409,10 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     } else {
       // (lead scalars..., PcPhaseArgs): the lead is what the command processor preloads into SGPRs (pc_args.h)
       PcBulkArgs& ba = h->host_bulk_args[ip];
-      ba.lead = PcLead{a.x, a.lam, a.x_off, a.c_off, a.N, a.K, a.tile_begin, a.spt, a.n_blocks, a.flags | (a.wpt << 8)};
+      const int un = a.uni_n > 0 ? a.uni_n : 0;
+      ba.lead = PcLead{a.x + a.x_off, a.lam ? a.lam + a.c_off : nullptr, a.qa, a.sec_h, a.N, a.K, a.tile_begin, a.n_blocks,
+                       a.flags | (a.wpt << 8) | ((a.block_threads >> 6) << 12) | (a.spt << 16),
+                       un ? (a.qa_off[un] | ((a.qa_total + a.qw_off[un]) << 16)) : 0};
       size_t sz = sizeof(ba);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ba, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
       HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB * D.wpt, 1, 1, D.lds_bytes, st, nullptr, cfg));
@@ -717,8 +720,11 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         h->n_launches = 2;
       }
     }
-    h->d_qa.upload(h->qa);
-    h->d_qw.upload(h->qw);
+    {   // one buffer: the weight tables right behind the A tables (the kernels address both from `qa`)
+      std::vector<double> both(h->qa);
+      both.insert(both.end(), h->qw.begin(), h->qw.end());
+      h->d_qa.upload(both);
+    }
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       auto& P = Q.ph[ip];
       auto& D = *h->pd[ip];

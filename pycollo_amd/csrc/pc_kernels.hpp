@@ -313,12 +313,13 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 template <class St>
 struct BulkIn {
   const double* x; const double* lam; double* c; double* G; double* H;
+  const double* xz; const double* lamd;   // x + x_off, lam + c_off
   const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
   const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials; long long* dbg;
   unsigned* sync; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
-  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads, qa0, qw0;
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads, qa0, qw0, qwabs;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -407,15 +408,19 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // part 1: what the node loads are addressed with.  pc_bulk_p<i> gets these as leading scalar arguments, which the
   // command processor preloads into SGPRs (LD); the other launches read them from their argument block like the rest.
   if (LD) {
-    A.x = LD->x; A.lam = LD->lam; A.x_off = LD->x_off; A.c_off = LD->c_off; A.N = LD->N; A.K = LD->K;
-    A.tile_begin = LD->tile_begin; A.spt = LD->spt; A.n_blocks = LD->n_blocks;
-    A.flags = LD->flags_wpt & 0xff; A.wpt = LD->flags_wpt >> 8;
+    const int wa = LD->wa, wb = LD->wb;
+    A.xz = LD->xz; A.lamd = LD->lamd; A.qa = LD->qa; A.sec_h = LD->sec_h; A.N = LD->N; A.K = LD->K;
+    A.tile_begin = LD->tile_begin; A.n_blocks = LD->n_blocks;
+    A.flags = wa & 0xff; A.wpt = (wa >> 8) & 0xf; A.block_threads = ((wa >> 12) & 0xf) << 6; A.spt = wa >> 16;
+    A.qa0 = wb & 0xffff; A.qwabs = wb >> 16;
   } else {
     A.x = MA ? MA->x : KA.x; A.lam = MA ? MA->lam : KA.lam; A.x_off = KA.x_off; A.c_off = KA.c_off; A.N = KA.N; A.K = KA.K;
+    A.xz = A.x + A.x_off; A.lamd = A.lam + A.c_off; A.qa = KA.qa; A.sec_h = KA.sec_h;
     A.tile_begin = KA.tile_begin; A.spt = KA.spt; A.n_blocks = KA.n_blocks;
-    A.flags = MA ? MA->flags : KA.flags; A.wpt = KA.wpt;
+    A.flags = MA ? MA->flags : KA.flags; A.wpt = KA.wpt; A.block_threads = KA.block_threads;
+    A.qa0 = KA.qa_off[UN > 0 ? UN : 0]; A.qwabs = KA.qa_total + KA.qw_off[UN > 0 ? UN : 0];
   }
-  if constexpr (UN == 0) { A.uni_n = KA.uni_n; A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; }
+  if constexpr (UN == 0) { A.uni_n = KA.uni_n; A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; }
   // ---- this workgroup's tile and this lane's node, then the node loads, before anything else: with the lead
   //      scalars preloaded (pc_bulk_p<i>) their addresses need no scalar load, so the longest latency of the
   //      prologue starts at the wave's first instructions and everything below overlaps it
@@ -449,7 +454,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   if (active) {
     static_for<0, NZ>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
-      v[b] = A.x[A.x_off + (int64_t)b * N + node];
+      v[b] = A.xz[(int64_t)b * N + node];
     });
   }
   // part 2: everything else, fetched while the node loads are in flight.  With preloaded lead scalars the argument
@@ -461,16 +466,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     } else {
       A.c = KB.c; A.G = KB.G; A.H = KB.H;
     }
-    if constexpr (UN > 0) { A.uni_n = KB.uni_n; A.tile_k0 = KB.tile_k0; A.tile_n0 = KB.tile_n0; }
-    A.sec_s = KB.sec_s; A.sec_h = KB.sec_h; A.sec_E = KB.sec_E;
-    A.qa = KB.qa; A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials; A.dbg = KB.dbg;
+    if (LD) { A.x = KB.x; A.lam = KB.lam; A.x_off = KB.x_off; A.c_off = KB.c_off; }
+    if constexpr (UN > 0) { A.uni_n = KB.uni_n; A.tile_k0 = KB.tile_k0; A.tile_n0 = KB.tile_n0; A.sec_s = KB.sec_s; }
+    A.sec_E = KB.sec_E;
+    A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials; A.dbg = KB.dbg;
     A.sync = KB.sync; A.tab = KB.tab;
     A.s_off = KB.s_off; A.c_path_off = KB.c_path_off; A.c_int_off = KB.c_int_off;
     A.t_fixed[0] = KB.t_fixed[0]; A.t_fixed[1] = KB.t_fixed[1];
     A.qa_total = KB.qa_total; A.qw_total = KB.qw_total;
     A.lds_out = KB.lds_out; A.dbg_stage = KB.dbg_stage;
-    A.block_threads = KB.block_threads;
-    A.qa0 = KB.qa_off[UN > 0 ? UN : 0]; A.qw0 = KB.qw_off[UN > 0 ? UN : 0];
+    A.qw0 = KB.qw_off[UN > 0 ? UN : 0];
     static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KB.scal[decltype(i_)::value]; });
     static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KB.goff[decltype(i_)::value]; });
     static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KB.hoff[decltype(i_)::value]; });
@@ -483,6 +488,43 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   } else {
     part2(KA);
   }
+  // the multipliers of the defect rows, the section widths and (compile-time order) the order's A and weight tables:
+  // first chunks into registers.  Issued here -- behind the scalar loads of part 2, ahead of the wait for them -- when
+  // their addresses are preloaded scalars (pc_bulk_p<i>, compile-time order); otherwise after that wait, where the
+  // pointers have arrived anyway and fewer values are live across it (Delta III and the any-order kernels lose 2 %
+  // with the early form).
+  const bool wantH = A.flags & PC_FLAG_H;
+  const int TB = A.block_threads;   // (blockDim.x is a separate, late scalar load)
+  const bool has_prev = k0 > 0;
+  const int kp = has_prev ? k0 - 1 : 0;  // first staged section
+  const int nsec = k1 - kp;              // staged sections (previous one included)
+  constexpr int QA_N = UN > 0 ? (UN - 1) * UN : 0;   // a compile-time order stages just its own A_n and w_n, at the
+  double r_h = 0.0, r_qa = 0.0, r_qw = 0.0;          // start of the LDS table areas (QAO = QWO = 0)
+  double r_lam[2 * (NY > 0 ? NY : 1)];
+  int lam0 = 0, lam_cnt = 0;   // first staged defect row; rows staged (<= TB + PC_MAX_ORDER - 2: two chunks)
+  auto aux_loads = [&]() {
+    r_h = tid < nsec ? A.sec_h[kp + tid] : 0.0;   // widths are data even on a uniform-order mesh
+    if (uni) {
+      lam0 = kp * (un - 1);
+    } else {
+      lam0 = A.sec_s[kp];
+    }
+    lam_cnt = n1 - lam0;
+    if (wantH) {
+      static_for<0, NY>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        const double* src = A.lamd + (int64_t)a * (N - 1) + lam0;
+        r_lam[2 * a] = tid < lam_cnt ? src[tid] : 0.0;
+        r_lam[2 * a + 1] = tid + TB < lam_cnt ? src[tid + TB] : 0.0;
+      });
+    }
+    if constexpr (UN > 0) {
+      r_qa = tid < QA_N ? A.qa[A.qa0 + tid] : 0.0;
+      r_qw = tid < UN ? A.qa[A.qwabs + tid] : 0.0;
+    }
+  };
+  const bool early_aux = LD != nullptr && UN > 0;
+  if (early_aux) aux_loads();
   // (only what this build of the kernel can use: everything pinned is live in SGPRs from here on, and the file has
   //  ~100 of them -- an over-full pin list is loaded in several dependent batches and partly spilled to VGPR lanes)
   // Two groups.  The first is what the per-node loads and the table staging need (pointers, offsets, geometry);
@@ -492,7 +534,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   pin(A.x); pin(A.lam); pin(A.sec_h); pin(A.qa); pin(A.qw);
   pin(A.x_off); pin(A.c_off); pin(A.N); pin(A.K); pin(A.flags); pin(A.qa_total); pin(A.qw_total); pin(A.tile_begin);
   pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.dbg_stage); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
-  if constexpr (UN > 0) { pin(A.qa0); pin(A.qw0); }
+  if constexpr (UN > 0) { pin(A.qa0); pin(A.qwabs); }
   if constexpr (NP > 0) pin(A.c_path_off);
   if constexpr (NQ > 0) pin(A.c_int_off);
   if constexpr (NS > 0) pin(A.s_off);
@@ -542,15 +584,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   // functions are cheap next to a SIMD that would otherwise idle) and produces a disjoint subset of the output
   // runs -- states, Hessian row blocks, path rows are dealt round-robin.  W > 1 only with TN = 64 (a replica is
   // exactly one wave, so its private staging region needs no workgroup barrier).
-  const int TB = A.block_threads;   // (blockDim.x is a separate, late scalar load)
   const int TN = W > 1 ? 64 : TB;
   const int w = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // wave-uniform: branches on it are scalar
   const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
   int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off (any-mesh kernels)
-  auto QAO = [&](int n) -> int { return UN > 0 ? A.qa0 : s_off[n]; };                       // start of A_n in s_qa
-  auto QWO = [&](int n) -> int { return UN > 0 ? A.qw0 : s_off[PC_MAX_ORDER + 1 + n]; };    // start of w_n in s_qw
+  auto QAO = [&](int n) -> int { return UN > 0 ? 0 : s_off[n]; };                       // start of A_n in s_qa
+  auto QWO = [&](int n) -> int { return UN > 0 ? 0 : s_off[PC_MAX_ORDER + 1 + n]; };    // start of w_n in s_qw
   double* s_h = smem + lp.h;
   long long* s_E = reinterpret_cast<long long*>(smem + lp.E);
   int* s_s = reinterpret_cast<int*>(smem + lp.s);
@@ -594,7 +635,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     else lds_barrier();
   };
 
-  const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G, wantH = A.flags & PC_FLAG_H;
+  const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G;
   if (A.dbg_stage == 1) return;
   // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of each of a tile's
   // (up to four) waves stamps s_memtime at the phase boundaries into a buffer of its own
@@ -608,9 +649,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   };
   STAMP(0);
 
-  const bool has_prev = k0 > 0;
-  const int kp = has_prev ? k0 - 1 : 0;  // first staged section
-  const int nsec = k1 - kp;              // staged sections (previous one included)
   const bool last_tile = (k1 == A.K);
 
   // ---- the rest of the per-node loads are issued before any staging so that their latency overlaps it ------
@@ -648,24 +686,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   //      so the global-load latencies overlap instead of queueing behind one loop after another ----------
   // table offsets by order: a compile-time order needs just its own two (scalar kernel arguments, see QAO / QWO)
   const int r_off = (UN == 0 && tid < 2 * (PC_MAX_ORDER + 1)) ? reinterpret_cast<const int32_t*>(&KA.qa_off[0])[tid] : 0;   // qa_off, qw_off adjacent
-  const double r_qa = tid < A.qa_total ? A.qa[tid] : 0.0;
-  const double r_qw = tid < A.qw_total ? A.qw[tid] : 0.0;
-  const double r_h = tid < nsec ? A.sec_h[kp + tid] : 0.0;   // widths are data even on a uniform-order mesh
-  int lam0;  // first staged defect row
-  if (uni) {
-    lam0 = kp * (un - 1);
-  } else {
-    lam0 = A.sec_s[kp];
-  }
-  double r_lam[2 * (NY > 0 ? NY : 1)];
-  const int lam_cnt = n1 - lam0;   // <= TB + PC_MAX_ORDER - 2: two chunks
-  if (wantH) {
-    static_for<0, NY>([&](auto a_) {
-      constexpr int a = decltype(a_)::value;
-      const double* src = A.lam + A.c_off + (int64_t)a * (N - 1) + lam0;
-      r_lam[2 * a] = tid < lam_cnt ? src[tid] : 0.0;
-      r_lam[2 * a + 1] = tid + TB < lam_cnt ? src[tid + TB] : 0.0;
-    });
+  if (!early_aux) aux_loads();
+  if constexpr (UN == 0) {   // any order: the whole packed tables
+    r_qa = tid < A.qa_total ? A.qa[tid] : 0.0;
+    r_qw = tid < A.qw_total ? A.qw[tid] : 0.0;
   }
   pin_second_group();
   if (!uni) {
@@ -675,14 +699,23 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     }
   }
   if (UN == 0 && tid < 2 * (PC_MAX_ORDER + 1)) s_off[tid] = r_off;
-  if (tid < A.qa_total) s_qa[tid] = r_qa;
-  if (tid < A.qw_total) s_qw[tid] = r_qw;
+  if constexpr (UN > 0) {
+    if (tid < QA_N) s_qa[tid] = r_qa;
+    if (tid < UN) s_qw[tid] = r_qw;
+  } else {
+    if (tid < A.qa_total) s_qa[tid] = r_qa;
+    if (tid < A.qw_total) s_qw[tid] = r_qw;
+  }
   if (tid < nsec) s_h[tid] = r_h;
   if constexpr (!PINNED) {   // scal | goff | hoff, packed by the host in exactly this order
     for (int i = tid; i < St::NSCAL + NFN + NHO; i += TB) s_tab[i] = A.tab[i];
   }
-  for (int i = tid + TB; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
-  for (int i = tid + TB; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
+  if constexpr (UN > 0) {
+    for (int i = tid + TB; i < QA_N; i += TB) s_qa[i] = A.qa[A.qa0 + i];
+  } else {
+    for (int i = tid + TB; i < A.qa_total; i += TB) s_qa[i] = A.qa[i];
+    for (int i = tid + TB; i < A.qw_total; i += TB) s_qw[i] = A.qw[i];
+  }
   for (int i = tid + TB; i < nsec; i += TB) s_h[i] = A.sec_h[kp + i];
   if (wantH) {
     static_for<0, NY>([&](auto a_) {
