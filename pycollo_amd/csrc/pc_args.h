@@ -30,7 +30,7 @@ struct PcPhaseArgs {
   const double* sec_h;     // [K] section widths in tau
   const int64_t* sec_E;    // [K+1] prefix sum of (n_k-1)*n_k
   const double* qa;        // packed A tables of the orders in use
-  const double* qw;        // packed weight tables
+  const double* qw;        // packed weight tables; the host places them right behind the A tables (qw == qa + qa_total)
   const int64_t* hslot0;  // [NHZZ] slots of the node block at node 0
   const int64_t* hslotN;  // [NHZZ] slots of the node block at node N-1
   double* partials;       // [n_tiles][NRED] per-tile partial sums
