@@ -255,7 +255,7 @@ def main():
                                   if name.startswith("pc_bulk")) or None
         except (OSError, IndexError):
             pass
-        roofline = {"bound": "hbm", "kernel": "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(k_ms * 1e3, 3),
                     "method": f"{n_roof} bulk-kernel launches queued behind a blocker, between two HIP events on the launch stream"}
