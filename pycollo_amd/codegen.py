@@ -221,18 +221,18 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("}  // namespace gen\n")
     parts.append("namespace gen {")
     parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase, then the endpoint block")
-    parts.append("  template <bool SERIAL = false>")
+    parts.append("  template <bool SERIAL = false, bool BIG = false>")
     parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr) {")
     first = model.phases[0].index
     parts.append(f"    pc::TailPhaseRegs<Phase{first}> r0;   // the first phase's loads go out before anything else")
-    parts.append(f"    pc::tail_phase_issue<Phase{first}>(a, {first}, r0, ld);")
+    parts.append(f"    pc::tail_phase_issue<Phase{first}, BIG>(a, {first}, r0, ld);")
     parts.append("    __builtin_amdgcn_sched_barrier(0);")
     parts.append("    pc::PointIn<Point> pin;")
     parts.append("    pc::tail_point_load<Point, SERIAL>(a, pin);")
     parts.append("    pc::tail_begin(a);")
     parts.append(f"    pc::tail_phase_finish<Phase{first}>(a, {first}, r0);")
     for pm in model.phases[1:]:
-        parts.append(f"    pc::tail_phase<Phase{pm.index}>(a, {pm.index});")
+        parts.append(f"    pc::tail_phase<Phase{pm.index}, BIG>(a, {pm.index});")
     parts.append("    pc::tail_point<Point>(a, pin);")
     parts.append("    pc::tail_end(a);")
     parts.append("  }")
@@ -267,6 +267,12 @@ def generate_source(model: Model, orders=None) -> str:
                  'const double* scal0, long long x_off0, int n_tiles0, int N0, int flags, int block_threads, PcTailArgs a) {')
     parts.append('  const PcTailLead ld{x, partials0, scal0, x_off0, n_tiles0, N0, flags, block_threads};')
     parts.append('  gen::Tail::run<false>(a, &ld);')
+    parts.append('}')
+    parts.append('// the same for many tiles: several strides of partial sums in flight per lane')
+    parts.append('extern "C" __global__ void __launch_bounds__(PC_TAIL_THREADS) pc_tail_big(const double* x, const double* partials0, '
+                 'const double* scal0, long long x_off0, int n_tiles0, int N0, int flags, int block_threads, PcTailArgs a) {')
+    parts.append('  const PcTailLead ld{x, partials0, scal0, x_off0, n_tiles0, N0, flags, block_threads};')
+    parts.append('  gen::Tail::run<false, true>(a, &ld);')
     parts.append('}')
     parts.append("")
     return "\n".join(parts)

@@ -190,6 +190,7 @@ struct pc_handle {
   hipStream_t stream = nullptr;
   hipModule_t module = nullptr;
   hipFunction_t tail_fn = nullptr;
+  hipFunction_t tail_big_fn = nullptr;   // same kernel with the partial-sum loads of several strides in flight
   hipFunction_t bulk_all_fn = nullptr;   // multi-phase problems: every phase's bulk kernel in one launch
   DevBuf<char> d_phase_args;             // [n_phases] PcPhaseArgs read by pc_bulk_all
   bool args_dirty = true;                // scaling / tile range / partials buffer changed since the last upload
@@ -425,7 +426,11 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   tl.lead = PcTailLead{t.x, t.ph[0].partials, t.ph[0].scal, t.ph[0].x_off, t.ph[0].n_tiles, t.ph[0].N, t.flags, t.block_threads};
   size_t sz = sizeof(tl);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, st, nullptr, cfg));
+  // more than four strides of partial sums per lane in some phase: the build that overlaps their loads
+  int max_tiles = 0;
+  for (size_t ip = 0; ip < Q.ph.size(); ++ip) max_tiles = std::max(max_tiles, (int)t.ph[ip].n_tiles);
+  hipFunction_t fn = (h->tail_big_fn && max_tiles > 4 * PC_TAIL_THREADS) ? h->tail_big_fn : h->tail_fn;
+  HIP_OK(hipModuleLaunchKernel(fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, st, nullptr, cfg));
 }
 
 void upload_scaling(pc_handle* h) {
@@ -711,6 +716,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_OK(hipModuleLoad(&h->module, d->code_object));
     HIP_OK(hipModuleGetFunction(&h->tail_fn, h->module, d->tail_kernel));
+    if (hipModuleGetFunction(&h->tail_big_fn, h->module, (std::string(d->tail_kernel) + "_big").c_str()) != hipSuccess)
+      h->tail_big_fn = nullptr;
     if (Q.ph.size() > 1) {
       bool merge = true;
       if (const char* env = std::getenv("PYCOLLO_AMD_MERGE")) merge = std::atoi(env) != 0;

@@ -1286,7 +1286,7 @@ struct TailPhaseRegs {
   double xq[St::NQ > 0 ? St::NQ : 1], wi[St::NQ > 0 ? St::NQ : 1], vq[St::NQ > 0 ? St::NQ : 1], rq[St::NQ > 0 ? St::NQ : 1];
   double vs[St::NS > 0 ? St::NS : 1], acc[St::NRED > 0 ? St::NRED : 1];
 };
-template <class M>
+template <class M, bool BIG = false>
 __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R, const PcTailLead* L = nullptr) {
   using St = S<M>;
   constexpr int NZ = St::NZ, NQ = St::NQ, NS = St::NS, NT = St::NT, NRED = St::NRED;
@@ -1320,8 +1320,30 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
     static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
     const double* part = L ? L->partials0 : P.partials;
     const int nt = L ? L->n_tiles0 : P.n_tiles;
-    for (int b = tid; b < nt; b += TB)
-      static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += part[(int64_t)b * NRED + decltype(r_)::value]; });
+    // U strides of tiles are requested before the first is added, in the same order as a plain loop would add them
+    // (a wait per stride made the tail 6 us behind a 27 us bulk kernel at 4 k tiles, 58 us at 39 k)
+    constexpr int U = NRED <= 4 ? 8 : 4;
+    // (BIG: the build of the tail kernel the host picks for many tiles, pc_tail_big; the plain loop stays the code of
+    //  pc_tail, whose few strides leave nothing to overlap)
+    if constexpr (!BIG) {
+      for (int b = tid; b < nt; b += TB)
+        static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += part[(int64_t)b * NRED + decltype(r_)::value]; });
+    } else
+    for (int b0 = tid; b0 < nt; b0 += U * TB) {
+      double tmp[U][NRED];
+      static_for<0, U>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        const int b = b0 + u * TB;
+        static_for<0, NRED>([&](auto r_) {
+          constexpr int r = decltype(r_)::value;
+          tmp[u][r] = b < nt ? part[(int64_t)b * NRED + r] : 0.0;
+        });
+      });
+      static_for<0, U>([&](auto u_) {
+        constexpr int u = decltype(u_)::value;
+        if (b0 + u * TB < nt) static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += tmp[u][decltype(r_)::value]; });
+      });
+    }
   }
 }
 template <class M>
@@ -1401,10 +1423,10 @@ __device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, T
     }
   }
 }
-template <class M>
+template <class M, bool BIG = false>
 __device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
   TailPhaseRegs<M> R;
-  tail_phase_issue<M>(A, ip, R);
+  tail_phase_issue<M, BIG>(A, ip, R);
   tail_phase_finish<M>(A, ip, R);
 }
 

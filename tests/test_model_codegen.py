@@ -77,4 +77,4 @@ def test_generated_source_is_straight_line_fp64():
     src = codegen.generate_source(compile_model(problems.shuttle()))
     assert "pow(" not in src            # integer powers expanded to multiplications
     assert "float " not in src
-    assert src.count("__global__") == 4      # bulk, bulk with the tail folded in, mesh error, tail
+    assert src.count("__global__") == 5      # bulk, bulk with the tail folded in, mesh error, tail, tail for many tiles
