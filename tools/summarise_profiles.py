@@ -48,7 +48,7 @@ for d in sorted(glob.glob(os.path.join(src, "*/"))):
         for i, r in enumerate(kr):
             if r["Kernel_Name"].startswith("pc_bulk"):
                 nxt = kr[i + 1]["Kernel_Name"] if i + 1 < len(kr) else ""
-                (pair if nxt == "pc_tail" else solo).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                (pair if nxt.startswith("pc_tail") else solo).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         if solo and pair:
             entry["rocprof_bulk_split"] = {"bulk_only_loop": {"calls": len(solo), "avg_ns": round(sum(solo) / len(solo), 1)},
                                            "inside_evaluations": {"calls": len(pair), "avg_ns": round(sum(pair) / len(pair), 1)}}
