@@ -36,6 +36,47 @@ def cpu_baseline(K_sections: int, order: int, budget_s: float = 15.0):
         return {"value": None, "unit": "evals/s", "cores": 0, "kind": "port", "sample": f"unavailable: {exc}"}
 
 
+def host_leg(eng, x_np, lam_np, n_calls: int):
+    """SURVEY 8d leg (ii): the fused callback from HOST pointers -- x~, lambda in host memory, c~, G~, H~ delivered to
+    host memory, the call returning only when they are there -- timed call by call (median and p95 over >= 1000 calls
+    after 50 warm-up calls).  `inplace`: the caller reads / writes the library's pinned staging blocks
+    (pc_host_buffers), so no host memcpy on either side; `copying`: fresh pageable numpy arrays in and out, as the
+    reference's cyipopt object hands them over (pycollo/nlp.py:47-63).  Every data-movement mode is measured."""
+    import numpy as np
+    n_calls = max(1000, int(n_calls))
+    hx, hl, _, _, _ = eng.host_buffers()
+
+    def stats(fn):
+        for _ in range(50):
+            fn()
+        ts = np.empty(n_calls)
+        for i in range(n_calls):
+            t0 = time.perf_counter()
+            fn()
+            ts[i] = time.perf_counter() - t0
+        return float(np.median(ts) * 1e6), float(np.percentile(ts, 95) * 1e6)
+
+    names = {0: "dma_up_dma_down", 1: "kernel_reads_host_dma_down", 2: "dma_up_kernel_writes_host",
+             3: "kernel_reads_and_writes_host"}
+    by_mode = {}
+    for mode in (0, 1, 2, 3):
+        eng.set_host_mode(mode)
+        hx[:] = x_np
+        hl[:] = lam_np
+        med, p95 = stats(lambda: eng.evaluate_all_inplace(1.0))
+        cmed, cp95 = stats(lambda: eng.evaluate_all(x_np, 1.0, lam_np))
+        by_mode[names[mode]] = {"inplace_median_us": round(med, 2), "inplace_p95_us": round(p95, 2),
+                                "copying_median_us": round(cmed, 2), "copying_p95_us": round(cp95, 2)}
+    eng.set_host_mode(0)
+    best = min(by_mode, key=lambda k: by_mode[k]["inplace_median_us"])
+    b = by_mode[best]
+    return {"call": "pc_eval_all (host pointers in, host pointers out, synchronous)", "calls": n_calls, "mode": best,
+            "median_us": b["inplace_median_us"], "p95_us": b["inplace_p95_us"],
+            "evals_per_s": round(1e6 / b["inplace_median_us"], 1),
+            "copying_median_us": b["copying_median_us"], "copying_p95_us": b["copying_p95_us"],
+            "by_mode": by_mode}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +87,11 @@ def main():
     ap.add_argument("--problem", default="hypersensitive")
     ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--build-only", action="store_true",
+                    help="compile the code object this command needs and exit without touching the GPU (run this, "
+                         "unprofiled, before any rocprofv3 pass: no compiler may be spawned under the profiler)")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (pc_eval_all) timing leg")
+    ap.add_argument("--host-calls", type=int, default=2000, help="timed host-pointer calls per variant (>= 1000)")
     ap.add_argument("--no-pin", action="store_true", help="leave the launching thread to the scheduler")
     ap.add_argument("--ragged", action="store_true", help="ph-refined style mesh: random section sizes, orders 4..8")
     ap.add_argument("--generic", action="store_true", help="use the any-mesh kernels (no order specialisation)")
@@ -54,6 +100,15 @@ def main():
     args = ap.parse_args()
 
     import numpy as np
+    if args.build_only:
+        import __graft_entry__ as entry
+        from pycollo_amd import codegen, problems as _pr
+        from pycollo_amd.model import compile_model
+        entry.build_library()
+        pb = _pr.REGISTRY[args.problem](K=args.sections * max(1, args.gpus), order=args.order)
+        orders = tuple(0 for _ in pb.phases) if (args.ragged or args.generic) else tuple(args.order for _ in pb.phases)
+        print(codegen.build_code_object(compile_model(pb), orders))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,31 +274,31 @@ def main():
         # The launches are queued behind a blocker (an fp64 GEMM of ~15 ms on the same stream) so that the GPU
         # finds them back to back: at 5 us a kernel the host's launch rate (3.4-4.4 us a launch, bimodal between
         # runs) would otherwise leak into the figure.  e0/e1 are recorded on that stream, after the blocker.
-        n_roof = min(args.steps, 2000)
+        # its own launch counts, whatever --steps says: 5 batches of 2000 launches each, the median batch is reported
+        n_roof, n_batches = 2000, 5
         blk = torch.empty((8192, 8192), dtype=torch.float64, device=dev).normal_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        torch.mm(blk, blk)
-        e0.record()
-        for _ in range(n_roof):
-            bulk_only()
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / n_roof
+
+        def timed_batch(fn):
+            torch.cuda.synchronize()
+            torch.mm(blk, blk)
+            e0.record()
+            for _ in range(n_roof):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n_roof
+
+        k_batches = sorted(timed_batch(bulk_only) for _ in range(n_batches))
+        k_ms = k_batches[n_batches // 2]
         # the same for whole evaluations (bulk + tail): device time per evaluation with the host out of the picture
-        torch.cuda.synchronize()
-        torch.mm(blk, blk)
-        e0.record()
-        for _ in range(n_roof):
-            step()
-        e1.record()
-        torch.cuda.synchronize()
-        dev_step_ms = e0.elapsed_time(e1) / n_roof
+        d_batches = sorted(timed_batch(step) for _ in range(n_batches))
+        dev_step_ms = d_batches[n_batches // 2]
         del blk
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process); only quoted when the workload is the one those passes profiled
         traffic = None
+        traffic_source = None
         try:
             import glob
             latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))[-1]
@@ -253,12 +308,28 @@ def main():
                 if world == 1 and isinstance(entry, dict) and entry.get("workload") == workload:
                     traffic = sum(k.get("hbm_bytes_per_launch", 0) for name, k in entry["kernels"].items()
                                   if name.startswith("pc_bulk")) or None
+                    traffic_source = (f"profiles/{os.path.basename(latest)} (separate rocprofv3 --pmc passes over this "
+                                      f"workload; not measured by this run)")
         except (OSError, IndexError):
             pass
-        roofline = {"bound": "hbm", "kernel": "pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(k_ms * 1e3, 3),
-                    "method": f"{n_roof} bulk-kernel launches queued behind a blocker, between two HIP events on the launch stream"}
+        # One launch per evaluation (resident tail): the dominant kernel IS the evaluation, pc_bulk_p0_r / pc_bulk_all_r,
+        # and its launch time is the device time per step; the tile-only kernel is reported beside it.
+        one_launch = world == 1 and extra.get("launches_per_eval") == 1
+        kname = ("pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0") + ("_r" if one_launch else "")
+        dom_ms = dev_step_ms if one_launch else k_ms
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(dom_ms * 1e3, 3),
+                    "tiles_only_kernel_us": round(k_ms * 1e3, 3),
+                    "launch_us_batches": [round(b * 1e3, 3) for b in (d_batches if one_launch else k_batches)],
+                    "method": f"median of {n_batches} batches of {n_roof} launches, each batch queued behind a blocker, "
+                              f"between two HIP events on the launch stream"}
+
+    # ---- what a host-side caller (IPOPT) sees: pc_eval_all with host pointers in and out, one call at a time ----
+    host = None
+    if world == 1 and not args.no_host:
+        host = host_leg(eng, x.cpu().numpy(), lam.cpu().numpy(), args.host_calls)
 
     if rank == 0:
         out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",
@@ -268,6 +339,9 @@ def main():
                "config": {"workload": workload, **extra}}
         if roofline is not None:
             out["roofline"] = roofline
+        if host is not None:
+            out["host_ms_per_step"] = round(host["median_us"] * 1e-3, 6)
+            out["host"] = host
         if world == 1 and not args.no_cpu:
             if full_mask:
                 from pycollo_amd.hostpin import restore_affinity

@@ -113,7 +113,9 @@ int pc_hess_structure(const pc_handle* h, int32_t* iRow, int32_t* jCol);
  * vectors are per OCP variable / constraint (scaling.py:166-167,274) */
 int pc_set_scaling(pc_handle* h, const double* V_ocp, const double* r_ocp, const double* W_ocp, double w_J);
 
-/* replaces: nlp_f / IPOPTProblem.objective (backend.py:1713-1715, nlp.py:47-48) */
+/* new_x follows IPOPT's protocol (IpStdCInterface.h): 1 on the first callback at a point, 0 on the companion
+ * calls at the same x, which reuse what the first one launched (J, grad J, g and jac_g are produced together).
+ * replaces: nlp_f / IPOPTProblem.objective (backend.py:1713-1715, nlp.py:47-48) */
 int pc_eval_f(pc_handle* h, const double* x, int new_x, double* f);
 /* replaces: nlp_grad_f / IPOPTProblem.gradient (backend.py:1717-1720, nlp.py:50-51); dense n */
 int pc_eval_grad_f(pc_handle* h, const double* x, int new_x, double* grad);
@@ -127,6 +129,15 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
 /* fused g + jac_g + hess at one (x, sigma, lambda): the benchmarked call (host pointers) */
 int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* g,
                 double* jac, double* hess);
+/* The pinned staging blocks the host-pointer calls copy through.  A caller that writes x / lambda there and passes
+ * these same pointers to pc_eval_* (inputs and/or outputs) skips the corresponding host-side memcpy: the results are
+ * then read in place and stay valid until the next evaluation on the handle.  (The reference hands fresh numpy
+ * arrays to cyipopt, pycollo/nlp.py:47-63; this is the zero-copy form of that hand-over.) */
+int pc_host_buffers(pc_handle* h, double** x, double** lambda, double** g, double** jac, double** hess);
+/* How the host-pointer calls move data: bit 0 = the kernels read x / lambda straight from the pinned host block
+ * (no copy up), bit 1 = the kernels write their results straight into the pinned host block (no copy down).
+ * 0 = one DMA copy up, one down (default; PYCOLLO_AMD_HOST_MODE overrides at pc_create). */
+int pc_set_host_mode(pc_handle* h, int mode);
 /* same with every vector resident in device memory; asynchronous on `stream` (hipStream_t, NULL =
  * the handle's stream).  No host synchronisation is performed. */
 int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda,
@@ -148,8 +159,6 @@ int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nre
 int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials);
 int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
                           double* d_jac, double* d_hess, void* stream);
-/* diagnostic builds only (PYCOLLO_AMD_DBG_STAGE=9): per-tile s_memtime stamps of the last bulk launch */
-int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles);
 int pc_synchronize(pc_handle* h);
 
 /* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling

@@ -220,45 +220,75 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append(_point_struct(model.point))
     parts.append("}  // namespace gen\n")
     parts.append("namespace gen {")
-    parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase, then the endpoint block")
-    parts.append("  template <bool SERIAL = false, bool BIG = false>")
+    parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase and the endpoint block")
+    parts.append("  // RES: block 0 of a resident-tail bulk launch (values of other workgroups arrive as granules)")
+    parts.append("  template <bool RES = false, bool BIG = false>")
     parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr) {")
+    parts.append("    extern __shared__ double pc_tail_smem[];")
+    parts.append("    const pc::TailLds L = pc::tail_lds<Point>(a, pc_tail_smem);")
     first = model.phases[0].index
-    parts.append(f"    pc::TailPhaseRegs<Phase{first}> r0;   // the first phase's loads go out before anything else")
-    parts.append(f"    pc::tail_phase_issue<Phase{first}, BIG>(a, {first}, r0, ld);")
-    parts.append("    __builtin_amdgcn_sched_barrier(0);")
-    parts.append("    pc::PointIn<Point> pin;")
-    parts.append("    pc::tail_point_load<Point, SERIAL>(a, pin);")
-    parts.append("    pc::tail_begin(a);")
-    parts.append(f"    pc::tail_phase_finish<Phase{first}>(a, {first}, r0);")
+    parts.append("    if constexpr (RES) {")
+    parts.append("      pc::tail_point_load<Point, true>(a, L);")
+    parts.append("      pc::tail_begin(a, L);")
+    parts.append("      pc::tail_point_eval<Point>(a, L);   // the endpoint rows are out before the first tile's sums arrive")
+    for pm in model.phases:
+        parts.append(f"      pc::tail_phase<Phase{pm.index}, true>(a, {pm.index}, L);")
+    parts.append("      pc::tail_point_apply<Point, true>(a, L);")
+    parts.append("      pc::tail_end(a, L);")
+    parts.append("    } else {")
+    parts.append(f"      pc::TailPhaseRegs<Phase{first}> r0;   // the first phase's loads go out before anything else")
+    parts.append(f"      pc::tail_phase_issue<Phase{first}, false, BIG>(a, {first}, r0, ld);")
+    parts.append("      __builtin_amdgcn_sched_barrier(0);")
+    parts.append("      pc::tail_point_load<Point, false>(a, L);")
+    parts.append("      pc::tail_begin(a, L);")
+    parts.append("      pc::tail_point_eval<Point>(a, L);")
+    parts.append(f"      pc::tail_phase_finish<Phase{first}>(a, {first}, r0, L);")
     for pm in model.phases[1:]:
-        parts.append(f"    pc::tail_phase<Phase{pm.index}, BIG>(a, {pm.index});")
-    parts.append("    pc::tail_point<Point>(a, pin);")
-    parts.append("    pc::tail_end(a);")
+        parts.append(f"      pc::tail_phase<Phase{pm.index}, false, BIG>(a, {pm.index}, L);")
+    parts.append("      pc::tail_point_apply<Point, false>(a, L);")
+    parts.append("      pc::tail_end(a, L);")
+    parts.append("    }")
     parts.append("  }")
     parts.append("};")
     parts.append("}  // namespace gen\n")
     occ = _occupancy_attr()
+    lead_sig = ('const double* xz, const double* lamd, const double* qa, const double* sec_h, int N, int K, '
+                'int tile_begin, int n_blocks, int wa, int wb')
     for pm in model.phases:
         # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}(const double* xz, '
-                     'const double* lamd, const double* qa, const double* sec_h, int N, int K, int tile_begin, '
-                     'int n_blocks, int wa, int wb, PcPhaseArgs a) {')
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}({lead_sig}, PcPhaseArgs a) {{')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, nullptr, nullptr, 0, -1, &ld);')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, nullptr, 0, -1, &ld);')
         parts.append('}')
-    if len(model.phases) > 1:
+    if len(model.phases) == 1:
+        pm = model.phases[0]
+        parts.append("// resident-tail build: block 0 runs the tail beside the tiles, one launch per evaluation")
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
+        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t); return; }')
+        parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, nullptr, 0, pc::xcd_major((int)blockIdx.x - 1, n_blocks), &ld);')
+        parts.append('}')
+    else:
+        np_ = len(model.phases)
+
+        def all_body(res: bool):
+            out = []
+            blk = "(int)blockIdx.x - 1" if res else "(int)blockIdx.x"
+            out.append(f"  const int b = pc::xcd_major({blk}, m.first_block[{np_}]);")
+            for i, pm in enumerate(model.phases):
+                cond = f"if (b < m.first_block[{i + 1}]) " if i + 1 < np_ else ""
+                out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {'true' if res else 'false'}>"
+                           f"(m.ph[{i}], &m, m.first_block[{i}], b); return; }}")
+            return out
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(PcMultiArgs m) {')
-        parts.append(f"  const int b = pc::xcd_major((int)blockIdx.x, m.first_block[{len(model.phases)}]);")
-        for i, pm in enumerate(model.phases):
-            cond = f"if (b < m.first_block[{i + 1}]) " if i + 1 < len(model.phases) else ""
-            parts.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(m.ph[{i}], nullptr, &m, m.first_block[{i}], b); return; }}")
+        parts += all_body(False)
         parts.append("}")
-    last = model.phases[-1].index
-    parts.append("// last phase with the tail folded in: the last workgroup to arrive finishes the evaluation")
-    parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_bulk_p{last}_f(PcPhaseArgs a, PcTailArgs t) '
-                 f'{{ pc::bulk<gen::Phase{last}, {int(orders[last])}, gen::Tail>(a, &t); }}')
+        parts.append("// the same with the resident tail as block 0")
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(PcMultiArgs m, PcTailArgs t) {')
+        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t); return; }')
+        parts += all_body(True)
+        parts.append("}")
     parts.append("")
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
@@ -266,7 +296,7 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append('extern "C" __global__ void __launch_bounds__(PC_TAIL_THREADS) pc_tail(const double* x, const double* partials0, '
                  'const double* scal0, long long x_off0, int n_tiles0, int N0, int flags, int block_threads, PcTailArgs a) {')
     parts.append('  const PcTailLead ld{x, partials0, scal0, x_off0, n_tiles0, N0, flags, block_threads};')
-    parts.append('  gen::Tail::run<false>(a, &ld);')
+    parts.append('  gen::Tail::run<false, false>(a, &ld);')
     parts.append('}')
     parts.append('// the same for many tiles: several strides of partial sums in flight per lane')
     parts.append('extern "C" __global__ void __launch_bounds__(PC_TAIL_THREADS) pc_tail_big(const double* x, const double* partials0, '
@@ -358,6 +388,13 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError(f"code object {out} is not built and hipcc is not available to build it")
+    # Under rocprofv3 every child inherits the profiler's preload, which initialises the GPU; hipcc then execs clang --
+    # an exec from a process that holds the GPU, which must not happen on this pool.  Build beforehand instead.
+    preload = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in preload or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
+        raise RuntimeError(f"code object {out} is not built and this process runs under a profiler preload: build it "
+                           f"first in a plain process (python -c 'import __graft_entry__ as g; g.build()' or one "
+                           f"unprofiled run of the same command)")
     src = out[:-6] + ".hip"
     with open(src, "w") as f:
         f.write(generate_source(model, orders))

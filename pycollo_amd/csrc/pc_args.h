@@ -33,9 +33,11 @@ struct PcPhaseArgs {
   const double* qw;        // packed weight tables; the host places them right behind the A tables (qw == qa + qa_total)
   const int64_t* hslot0;  // [NHZZ] slots of the node block at node 0
   const int64_t* hslotN;  // [NHZZ] slots of the node block at node N-1
-  double* partials;       // [n_tiles][NRED] per-tile partial sums
-  long long* dbg;         // diagnostic builds only: [n_tiles][16] s_memtime stamps (dbg_stage == 9)
-  unsigned* sync;         // fused tail: [(PC_SYNC_SHARDS + 1) * 16] arrival counters, all zero between launches
+  double* partials;       // [n_tiles][NRED] per-tile partial sums (two-launch build)
+  // resident-tail build (pc_kernels.hpp, RES): values handed to the tail workgroup of the same launch as granules
+  unsigned long long* gran;      // [n_tiles][NRED][2] the per-tile partial sums
+  unsigned long long* erec;      // [n_rec][2] edge-node Hessian entries an endpoint term is added to (all phases)
+  const int32_t* edge_rec;       // [2][NHZZ + 2 NZ + NS NZ] record of every edge-node entry site, or -1 (plain store)
   const double* tab;      // device copy of scal | goff | hoff (packed, used entries only): staged into LDS by
                           // the kernels of models whose tables do not fit the scalar register file
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
@@ -47,7 +49,7 @@ struct PcPhaseArgs {
   int32_t uni_n;          // > 0: every section has uni_n nodes (index arithmetic replaces the section tables)
   int32_t spt;            // sections per tile when uniform
   int32_t lds_out;        // doubles of the output staging buffer
-  int32_t dbg_stage;      // 0 = normal; k > 0: diagnostic build of the timeline, return after stage k
+  uint32_t epoch;         // tag of this launch's granules (resident-tail build; pc_bulk_all takes it from PcMultiArgs)
   int32_t wpt;            // waves (replicas) per tile: 1, 2 or 4; > 1 only with 64-node tiles
   int32_t block_threads;  // threads per workgroup of this launch (= blockDim.x, passed for the same reason as n_blocks)
   int32_t n_blocks;       // workgroups of this launch (tile_end - tile_begin): the kernel must not read gridDim,
@@ -94,16 +96,17 @@ struct PcMultiArgs {
   const PcPhaseArgs* ph;                  // [n_phases], device memory
   int32_t flags, n_phases;
   int32_t first_block[PC_MAX_PHASES + 1];
+  uint32_t epoch;                         // tag of this launch's granules (resident-tail build)
 };
 #define PC_MAX_POINT 96           // endpoint (point) variables: y(t0), y(tF), q, t of every phase, s
 #define PC_MAX_ENDPOINT_ROWS 32   // endpoint constraint rows
 #define PC_TAIL_THREADS 256        // workgroup of the tail kernel: 4 waves, one per part of the endpoint block (8 waves
                                    // measured: +0.9 us on every evaluation, no gain on the heaviest endpoint block)
 #define PC_TAIL_OWNED_MAX 1024   // Hessian entries the tail accumulates in LDS
-#define PC_SYNC_SHARDS 64   // arrival counters of the fused tail, one 64-B line each, plus the top counter
 
 struct PcTailPhase {
   const double* partials;  // [n_tiles][NRED]
+  const unsigned long long* gran;   // resident-tail build: the same sums as granules, [n_tiles][NRED][2]
   const double* scal;
   int64_t x_off, s_off, c_int_off;
   int64_t gq_base[8];      // CSR offset of the q column of every integral row (then t, s follow)
@@ -120,7 +123,7 @@ struct PcTailArgs {
   double* G;
   double* H;
   double* fobj;                 // [1] objective value (scaled by w_J)
-  double* grad;                 // [num_x] or null (caller zero-fills)
+  double* grad_nz;              // [NGJ] structural non-zeros of grad J (scaled by w_J), or null
   double sigma, wJ;             // objective factor and objective scaling
   const int64_t* point_x;       // [n_point] x index of every point variable
   const double* point_V;        // [n_point]
@@ -133,7 +136,14 @@ struct PcTailArgs {
   int64_t c_end_off;            // first endpoint row of c
   int64_t g_end_base;           // CSR offset of the first endpoint row of G
   int32_t n_tail_owned, flags;
-  int32_t block_threads, reserved;   // threads of the workgroup that runs the tail (blockDim.x would be a late scalar load) (blockDim.x would be a late scalar load)
+  int32_t block_threads;        // threads of the workgroup that runs the tail: 64, 128 or 256 (blockDim.x would be a
+                                //   late scalar load)
+  int32_t lds_nred;             // largest NRED of any phase: sizes the tail's LDS carve (pc::tail_lds)
+  // resident-tail build
+  const unsigned long long* erec;   // [n_rec][2] granules of the edge-node Hessian entries (see PcPhaseArgs)
+  const int32_t* pt_rec;            // [n_pt_hess] record of every endpoint Hessian entry with pt_hlocal < 0, else -1
+  unsigned* timeout;                // host-visible word the tail sets when a granule never arrives (bounded spin)
+  uint32_t epoch, reserved;
   PcTailPhase ph[PC_MAX_PHASES];
   // the endpoint block's small tables by value: their loads join the argument fetch instead of forming a
   // second dependent round trip through device memory (point_x / point_V / point_r / W_end hold the same data)

@@ -2,10 +2,12 @@
 // See include/pycollo_amd.h for the contract and the reference interfaces each entry point replaces.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -83,7 +85,7 @@ struct DevBuf {
     if (count) HIP_OK(hipMalloc(&p, count * sizeof(T)));
   }
   void upload(const std::vector<T>& v) {
-    alloc(v.size());
+    if (v.size() != n) alloc(v.size());   // same size: keep the allocation (pointers held in argument blocks stay valid)
     if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   }
   void free() {
@@ -116,11 +118,12 @@ struct PhaseDev {
   DevBuf<double> sec_h, scal, partials, tab;
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
   DevBuf<int32_t> hsum_local;
-  DevBuf<long long> dbg;
+  DevBuf<unsigned long long> gran;   // resident tail: the per-tile partial sums as granules, [n_tiles][nred][2]
+  DevBuf<int32_t> edge_rec;          // resident tail: record of every edge-node Hessian entry site, or -1
   int uni_n = 0, spt = 0, lds_out = 0;
   int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
   hipFunction_t fn = nullptr;
-  hipFunction_t fn_fused = nullptr;  // last phase only: bulk kernel with the tail folded in
+  hipFunction_t fn_res = nullptr;    // single-phase problems: bulk kernel with the resident tail as block 0
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
   int tile_begin = 0, tile_end = 0;  // launched tile range (whole phase unless sharded)
   double* partials_ext = nullptr;    // caller-owned partial-sum buffer (sharded exchange), else `partials`
@@ -201,19 +204,35 @@ struct pc_handle {
   bool host_args_dirty = true;
   int wpt_all = 1, lds_all = 0;          // launch shape of pc_bulk_all
   std::vector<std::unique_ptr<PhaseDev>> pd;
-  DevBuf<double> d_qa, d_x, d_lam, d_c, d_G, d_H, d_fobj, d_grad, d_pointV, d_pointr, d_Wend, d_norms;
+  DevBuf<double> d_qa, d_pointV, d_pointr, d_Wend, d_norms;
+  // Host-pointer calls stage through ONE packed input block [x~ | lambda] and ONE packed output block
+  // [J | grad J non-zeros | c~ | G~ | H~] (pinned on the host, mirrored on the device): one copy up, one copy down.
+  DevBuf<double> d_in, d_out;
+  PinBuf<double> h_in, h_out;
+  size_t o_lam = 0, in_total = 0;                              // offsets in doubles
+  size_t o_f = 0, o_gn = 0, o_c = 0, o_G = 0, o_H = 0, out_total = 0;
+  // bit 0: the kernels read x~ / lambda straight from the pinned host block (no copy up);
+  // bit 1: the kernels write their outputs straight into the pinned host block (no copy down)
+  int host_mode = 0;
+  hipEvent_t ev_small = nullptr, ev_G = nullptr;               // completion of [J | grad | c~] and of G~ at the cached x
+  bool x_valid = false;      // the staged x~ is the caller's current point
+  bool fc_valid = false;     // J, grad J, c~, G~ at that point have been launched (new_x == 0 reuses them)
+  bool small_synced = false, G_synced = false;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
   DevBuf<int32_t> d_pt_hlocal;
   std::vector<double> h_pointV, h_pointr, h_Wend;   // host copies: travel by value in PcTailArgs
-  DevBuf<unsigned> d_sync;   // arrival counters of the fused tail (zero between launches)
-  bool allow_fuse = false;   // PYCOLLO_AMD_FUSE=1 folds the tail into the last bulk launch (experimental:
-                             // measured no faster than two launches on MI355X)
-  PinBuf<double> h_x, h_lam, h_c, h_G, h_H, h_fobj, h_grad, h_norms;
+  // resident tail (pc_kernels.hpp, RES): one launch per evaluation, the tail runs as block 0 beside the tiles
+  hipFunction_t bulk_all_res_fn = nullptr;   // multi-phase problems: pc_bulk_all with the resident tail
+  bool resident = true;                      // PYCOLLO_AMD_RESIDENT=0: always two launches (bulk, then pc_tail)
+  DevBuf<unsigned long long> d_erec;         // granules of the edge-node Hessian entries endpoint terms are added to
+  DevBuf<int32_t> d_pt_rec;                  // [n_pthess] record of every such endpoint entry, else -1
+  PinBuf<unsigned> h_timeout;                // host-visible: set by a tail whose granules never arrived
+  uint32_t epoch = 0;                        // tag of the last resident launch's granules (never 0)
+  int spin_us = 500;                         // host-pointer calls poll the stream this long before blocking (PYCOLLO_AMD_SPIN_US)
+  int tail_lds_bytes = 0, lds_nred = 0;
+  PinBuf<double> h_norms;
   std::vector<double> V_ocp, r_ocp, W_ocp;
-  // cache for new_x == 0
-  bool have_cG = false;
   int n_launches = 0;
-  int dbg_stage = 0;  // PYCOLLO_AMD_DBG_STAGE: diagnostic timeline build (profiling only)
   int lds_max = 0;
   int lds_limit = 64 * 1024;  // dynamic LDS a workgroup may request (queried from the device)
 };
@@ -231,7 +250,7 @@ void fill_point_tables(pc_handle* h, PcTailArgs& t) {
 }
 
 void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double* d_lam, double* d_c, double* d_G,
-                    double* d_H, double* d_fobj, double* d_grad, int flags, double sigma) {
+                    double* d_H, double* d_fobj, double* d_gradnz, int flags, double sigma) {
   auto& Q = h->Q;
   std::memset(&t, 0, sizeof(t));
   t.x = d_x;
@@ -240,7 +259,7 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.G = d_G;
   t.H = d_H;
   t.fobj = d_fobj;
-  t.grad = d_grad;
+  t.grad_nz = d_gradnz;
   t.sigma = sigma;
   t.wJ = h->w_J;
   t.point_x = h->d_point_x.p;
@@ -256,11 +275,16 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.n_tail_owned = (int32_t)Q.tail_owned.size();
   t.flags = flags;
   t.block_threads = PC_TAIL_THREADS;
+  t.lds_nred = h->lds_nred;
+  t.erec = h->d_erec.p;
+  t.pt_rec = h->d_pt_rec.p;
+  t.timeout = h->h_timeout.p;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
     PcTailPhase& tp = t.ph[ip];
     tp.partials = D.partials_ext ? D.partials_ext : D.partials.p;
+    tp.gran = D.gran.p;
     tp.scal = D.scal.p;
     tp.x_off = P.x_off;
     tp.s_off = Q.s_off;
@@ -302,12 +326,12 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.spt = D.spt;
   a.lds_out = D.lds_out;
   a.wpt = wpt;
-  a.dbg_stage = h->dbg_stage;
   a.hslot0 = D.hslot0.p;
   a.hslotN = D.hslotN.p;
   a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
-  a.dbg = D.dbg.p;
-  a.sync = h->d_sync.p;
+  a.gran = D.gran.p;
+  a.erec = h->d_erec.p;
+  a.edge_rec = D.edge_rec.p;
   a.tab = D.tab.p;
   a.x_off = P.x_off;
   a.s_off = Q.s_off;
@@ -330,21 +354,36 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
 }
 
 void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_c, double* d_G, double* d_H,
-                double* d_fobj, double* d_grad, int flags, hipStream_t st, double sigma, bool bulk = true,
+                double* d_fobj, double* d_gradnz, int flags, hipStream_t st, double sigma, bool bulk = true,
                 bool tail = true) {
   auto& Q = h->Q;
-  const size_t last = Q.ph.size() - 1;
-  // one launch per evaluation when the last phase runs whole: its last workgroup to arrive runs the tail
-  bool fuse = false;
-  if (bulk && tail && h->allow_fuse && (h->dbg_stage == 0 || h->dbg_stage == 9)) {
-    auto& D = *h->pd[last];
-    fuse = !h->bulk_all_fn && D.fn_fused && D.tile_begin == 0 && D.tile_end == D.n_tiles && D.n_tiles <= 8192;
+  // One launch per evaluation when every phase runs whole on this device: the tail is block 0 of the bulk launch and
+  // receives the tiles' partial sums as granules (pc_kernels.hpp, RES).  A rank of the section-sharded evaluation,
+  // whose sums travel through the all-gather first, and the bulk-only / tail-only calls take two launches.
+  bool res = bulk && tail && h->resident && (Q.ph.size() > 1 ? h->bulk_all_res_fn != nullptr : h->pd[0]->fn_res != nullptr);
+  for (size_t ip = 0; res && ip < Q.ph.size(); ++ip) {
+    auto& D = *h->pd[ip];
+    res = D.tile_begin == 0 && D.tile_end == D.n_tiles && !D.partials_ext;
   }
-  struct Both {
-    PcPhaseArgs a;
+  if (h->host_args_dirty) {
+    h->host_bulk_args.resize(Q.ph.size());
+    for (size_t ip = 0; ip < Q.ph.size(); ++ip)
+      fill_phase_args(h, ip, h->host_bulk_args[ip].a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
+    fill_tail_args(h, h->host_tail_launch.t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
+    h->host_args_dirty = false;
+  }
+  auto patch_tail = [&](PcTailArgs& t, int block_threads) {
+    t.x = d_x; t.lam = d_lam; t.c = d_c; t.G = d_G; t.H = d_H;
+    t.fobj = d_fobj; t.grad_nz = d_gradnz; t.flags = flags; t.sigma = sigma;
+    t.block_threads = block_threads;
+    t.epoch = h->epoch;
+  };
+  if (res && ++h->epoch == 0) h->epoch = 1;   // (zero is the tag of never-written granules)
+  struct MultiRes {
+    PcMultiArgs m;
     PcTailArgs t;
   };
-  if (bulk && h->bulk_all_fn) {
+  if (bulk && (res ? h->bulk_all_res_fn : h->bulk_all_fn) && Q.ph.size() > 1) {
     // several phases, one launch: the phases' workgroups run side by side instead of one kernel after another
     if (h->args_dirty) {
       std::vector<PcPhaseArgs> blocks(Q.ph.size());
@@ -354,7 +393,8 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
       HIP_OK(hipMemcpy(h->d_phase_args.p, blocks.data(), blocks.size() * sizeof(PcPhaseArgs), hipMemcpyHostToDevice));
       h->args_dirty = false;
     }
-    PcMultiArgs m;
+    MultiRes mr;
+    PcMultiArgs& m = mr.m;
     std::memset(&m, 0, sizeof(m));
     m.x = d_x;
     m.lam = d_lam;
@@ -364,12 +404,22 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     m.ph = reinterpret_cast<const PcPhaseArgs*>(h->d_phase_args.p);
     m.flags = flags;
     m.n_phases = (int32_t)Q.ph.size();
+    m.epoch = h->epoch;
     int nb = 0;
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       m.first_block[ip] = nb;
       nb += std::max(0, h->pd[ip]->tile_end - h->pd[ip]->tile_begin);
     }
     for (size_t ip = Q.ph.size(); ip <= PC_MAX_PHASES; ++ip) m.first_block[ip] = nb;
+    if (res) {
+      mr.t = h->host_tail_launch.t;
+      patch_tail(mr.t, h->TB * h->wpt_all);
+      size_t sz = sizeof(mr);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &mr, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      HIP_OK(hipModuleLaunchKernel(h->bulk_all_res_fn, nb + 1, 1, 1, h->TB * h->wpt_all, 1, 1,
+                                   std::max(h->lds_all, h->tail_lds_bytes), st, nullptr, cfg));
+      return;
+    }
     if (nb > 0) {
       size_t sz = sizeof(m);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &m, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -377,52 +427,45 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
     bulk = false;
   }
-  if (h->host_args_dirty) {
-    h->host_bulk_args.resize(Q.ph.size());
-    for (size_t ip = 0; ip < Q.ph.size(); ++ip)
-      fill_phase_args(h, ip, h->host_bulk_args[ip].a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
-    fill_tail_args(h, h->host_tail_launch.t, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1.0);
-    h->host_args_dirty = false;
-  }
-  auto patch_tail = [&](PcTailArgs& t) {
-    t.x = d_x; t.lam = d_lam; t.c = d_c; t.G = d_G; t.H = d_H;
-    t.fobj = d_fobj; t.grad = d_grad; t.flags = flags; t.sigma = sigma;
-    t.block_threads = PC_TAIL_THREADS;
+  struct BulkRes {   // what the host hands to pc_bulk_p<i>_r: (lead scalars..., PcPhaseArgs a, PcTailArgs t)
+    PcBulkArgs ba;
+    PcTailArgs t;
   };
   for (size_t ip = 0; bulk && ip < Q.ph.size(); ++ip) {
     auto& D = *h->pd[ip];
     if (D.tile_end <= D.tile_begin) continue;
     PcPhaseArgs& a = h->host_bulk_args[ip].a;
-    const int wpt = (fuse && ip == last) ? 1 : D.wpt;
     a.x = d_x; a.lam = d_lam; a.c = d_c; a.G = d_G; a.H = d_H;
     a.flags = flags;
-    a.wpt = wpt;
-    a.block_threads = h->TB * wpt;
-    if (fuse && ip == last) {
-      Both both;
-      both.a = a;
-      both.t = h->host_tail_launch.t;
-      patch_tail(both.t);
-      both.t.block_threads = h->TB;   // the tail runs inside the bulk workgroup
-      size_t sz = sizeof(both);
-      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &both, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(D.fn_fused, D.n_tiles, 1, 1, h->TB, 1, 1, D.lds_bytes, st, nullptr, cfg));
-    } else {
-      // (lead scalars..., PcPhaseArgs): the lead is what the command processor preloads into SGPRs (pc_args.h)
-      PcBulkArgs& ba = h->host_bulk_args[ip];
-      const int un = a.uni_n > 0 ? a.uni_n : 0;
-      ba.lead = PcLead{a.x + a.x_off, a.lam ? a.lam + a.c_off : nullptr, a.qa, a.sec_h, a.N, a.K, a.tile_begin, a.n_blocks,
-                       a.flags | (a.wpt << 8) | ((a.block_threads >> 6) << 12) | (a.spt << 16),
-                       un ? (a.qa_off[un] | ((a.qa_total + a.qw_off[un]) << 16)) : 0};
-      size_t sz = sizeof(ba);
-      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ba, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB * D.wpt, 1, 1, D.lds_bytes, st, nullptr, cfg));
+    a.wpt = D.wpt;
+    a.block_threads = h->TB * D.wpt;
+    a.epoch = h->epoch;
+    // (lead scalars..., PcPhaseArgs): the lead is what the command processor preloads into SGPRs (pc_args.h)
+    PcBulkArgs& ba = h->host_bulk_args[ip];
+    const int un = a.uni_n > 0 ? a.uni_n : 0;
+    ba.lead = PcLead{a.x + a.x_off, a.lam ? a.lam + a.c_off : nullptr, a.qa, a.sec_h, a.N, a.K, a.tile_begin, a.n_blocks,
+                     a.flags | (a.wpt << 8) | ((a.block_threads >> 6) << 12) | (a.spt << 16),
+                     un ? (a.qa_off[un] | ((a.qa_total + a.qw_off[un]) << 16)) : 0};
+    if (res) {   // single phase (several phases were launched above)
+      static_assert(offsetof(BulkRes, t) == sizeof(PcBulkArgs), "kernel argument layout");
+      BulkRes br;
+      br.ba = ba;
+      br.t = h->host_tail_launch.t;
+      patch_tail(br.t, a.block_threads);
+      size_t sz = sizeof(br);
+      void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &br, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+      HIP_OK(hipModuleLaunchKernel(D.fn_res, D.n_tiles + 1, 1, 1, a.block_threads, 1, 1,
+                                   std::max(D.lds_bytes, h->tail_lds_bytes), st, nullptr, cfg));
+      return;
     }
+    size_t sz = sizeof(ba);
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ba, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HIP_OK(hipModuleLaunchKernel(D.fn, D.tile_end - D.tile_begin, 1, 1, h->TB * D.wpt, 1, 1, D.lds_bytes, st, nullptr, cfg));
   }
-  if (!tail || fuse) return;
+  if (!tail) return;
   PcTailLaunch& tl = h->host_tail_launch;
   PcTailArgs& t = tl.t;
-  patch_tail(t);
+  patch_tail(t, PC_TAIL_THREADS);
   tl.lead = PcTailLead{t.x, t.ph[0].partials, t.ph[0].scal, t.ph[0].x_off, t.ph[0].n_tiles, t.ph[0].N, t.flags, t.block_threads};
   size_t sz = sizeof(tl);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
@@ -430,7 +473,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
   int max_tiles = 0;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) max_tiles = std::max(max_tiles, (int)t.ph[ip].n_tiles);
   hipFunction_t fn = (h->tail_big_fn && max_tiles > 4 * PC_TAIL_THREADS) ? h->tail_big_fn : h->tail_fn;
-  HIP_OK(hipModuleLaunchKernel(fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, st, nullptr, cfg));
+  HIP_OK(hipModuleLaunchKernel(fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, h->tail_lds_bytes, st, nullptr, cfg));
 }
 
 void upload_scaling(pc_handle* h) {
@@ -487,7 +530,7 @@ void upload_scaling(pc_handle* h) {
     h->h_pointr = pr;
     h->h_Wend = we;
   }
-  h->have_cG = false;
+  h->x_valid = h->fc_valid = false;
 }
 
 void require_device(pc_handle* h) {
@@ -499,9 +542,60 @@ void require_device(pc_handle* h) {
   HIP_OK(hipSetDevice(h->device));
 }
 
-void copy_x_in(pc_handle* h, const double* x) {
-  std::memcpy(h->h_x.p, x, h->Q.num_x * sizeof(double));
-  HIP_OK(hipMemcpyAsync(h->d_x.p, h->h_x.p, h->Q.num_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
+// ---- host-pointer staging ---------------------------------------------------------------------------
+// The resident tail spins (bounded) for values of the other workgroups; a tail that gave up says so here.
+void check_timeout(pc_handle* h) {
+  if (h->h_timeout.p && h->h_timeout.p[0]) {
+    const unsigned code = h->h_timeout.p[0];
+    h->h_timeout.p[0] = 0;
+    throw std::runtime_error("resident tail: granules of " + std::string(code >= 100 ? "an edge-node Hessian entry" : "a phase's partial sums") +
+                             " never arrived (code " + std::to_string(code) + "); the results of this evaluation are invalid");
+  }
+}
+
+// Wait for the handle's stream.  A blocking wait costs an interrupt and a wake-up (~10 us on the MI355X host, a
+// quarter of a 10 k-node callback); the stream is polled for `spin_us` first, which is where a callback completes.
+void wait_stream(pc_handle* h) {
+  if (h->spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(h->stream);
+      if (e == hipSuccess) { check_timeout(h); return; }
+      if (e != hipErrorNotReady) HIP_OK(e);
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > h->spin_us) break;
+    }
+  }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  check_timeout(h);
+}
+// what the kernels are handed for x~, lambda and the outputs: the device mirror, or the pinned host block itself
+const double* kx(pc_handle* h) { return (h->host_mode & 1) ? h->h_in.p : h->d_in.p; }
+const double* klam(pc_handle* h) { return kx(h) + h->o_lam; }
+double* kout(pc_handle* h, size_t off) { return ((h->host_mode & 2) ? h->h_out.p : h->d_out.p) + off; }
+
+// x~ of a callback: staged (and copied up) only when the caller says the point is new
+void stage_x(pc_handle* h, const double* x, int new_x) {
+  if (!new_x && h->x_valid) return;
+  if (!x) throw std::runtime_error("null x");
+  if (x != h->h_in.p) std::memcpy(h->h_in.p, x, h->Q.num_x * sizeof(double));
+  if (!(h->host_mode & 1))
+    HIP_OK(hipMemcpyAsync(h->d_in.p, h->h_in.p, h->Q.num_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->x_valid = true;
+  h->fc_valid = false;
+}
+
+void stage_lambda(pc_handle* h, const double* lambda) {
+  if (!lambda) throw std::runtime_error("null lambda");
+  double* dst = h->h_in.p + h->o_lam;
+  if (lambda != dst) std::memcpy(dst, lambda, h->Q.num_c * sizeof(double));
+  if (!(h->host_mode & 1))
+    HIP_OK(hipMemcpyAsync(h->d_in.p + h->o_lam, dst, h->Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
+}
+
+void copy_down(pc_handle* h, size_t begin, size_t end) {   // [begin, end) of the output block, device -> pinned host
+  if (h->host_mode & 2) return;                             // the kernels wrote there themselves
+  HIP_OK(hipMemcpyAsync(h->h_out.p + begin, h->d_out.p + begin, (end - begin) * sizeof(double), hipMemcpyDeviceToHost,
+                        h->stream));
 }
 
 template <class F>
@@ -612,7 +706,6 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (v >= max_nk && v <= TB) TC = v;
     }
     h->TC = TC;
-    if (const char* env = std::getenv("PYCOLLO_AMD_DBG_STAGE")) h->dbg_stage = std::atoi(env);
     pcp::build_all(Q, TC);
     if (Q.point_x.size() > PC_MAX_POINT || Q.n_b > PC_MAX_ENDPOINT_ROWS)
       throw std::runtime_error("too many endpoint variables / endpoint constraints for the tail kernel's argument block");
@@ -625,8 +718,12 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->V_ocp.assign(Q.num_ocp_x, 1.0);
     h->r_ocp.assign(Q.num_ocp_x, 0.0);
     h->W_ocp.assign(Q.num_ocp_c, 1.0);
-    bool fuse_env = false;
-    if (const char* env = std::getenv("PYCOLLO_AMD_FUSE")) fuse_env = std::atoi(env) != 0;
+    if (const char* env = std::getenv("PYCOLLO_AMD_RESIDENT")) h->resident = std::atoi(env) != 0;
+    if (const char* env = std::getenv("PYCOLLO_AMD_SPIN_US")) h->spin_us = std::atoi(env);
+    // the tail's LDS carve (pc::tail_lds): acc | part | sum | xb | lb | hold | hb
+    for (auto& P : Q.ph) h->lds_nred = std::max(h->lds_nred, P.nred);
+    h->tail_lds_bytes = 8 * (int)(Q.tail_owned.size() + 17 * (size_t)h->lds_nred + Q.point_x.size() + (size_t)Q.n_b +
+                                  2 * Q.pthess_row.size() + 2);
     h->pd.resize(Q.ph.size());
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       h->pd[ip].reset(new PhaseDev());
@@ -652,7 +749,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle
       // 381 tiles 22.7 / 19.2 / 17.6 us, 953 tiles 25.2 / 23.3 / 31.3 us, 2858 tiles 54 / 60 / 81 us).
       D.wpt = 1;
-      if (TB == 64 && !fuse_env) {
+      if (TB == 64) {
         // (one state: W = 2 measured no faster, 5.58 vs 5.49 us.  A heavy model -- Delta III, ~10k operations --
         //  loses at 834 tiles, 358 / 410 / 522 us: every sharing wave re-evaluates the node functions)
         const bool heavy = P.eval_ops > 4000;
@@ -674,7 +771,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if ((int)P.goff.size() > PC_MAX_GOFF || (int)P.hoff.size() > PC_MAX_HOFF)
         throw std::runtime_error("too many variables/constraints per phase for the kernel argument block");
     }
-    h->n_launches = (int)Q.ph.size() + 1;   // refined after the module is loaded (fused tail: one fewer)
+    h->n_launches = (int)Q.ph.size() + 1;   // refined after the module is loaded (resident tail: one launch)
     // launch shape of the all-phases kernel: the phases share one workgroup size, chosen from the total tile count
     if (Q.ph.size() > 1) {
       int total = 0, min_ny = 1 << 30;
@@ -694,7 +791,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         }
         return mx;
       };
-      if (TB == 64 && !fuse_env) {
+      if (TB == 64) {
         if (min_ny >= 2 && total <= (heavy ? 512 : 1024)) h->wpt_all = 2;
         if (min_ny >= 3 && total <= 400) h->wpt_all = 4;
         if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
@@ -725,6 +822,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (h->bulk_all_fn) {
         h->d_phase_args.alloc(Q.ph.size() * sizeof(PcPhaseArgs));
         h->n_launches = 2;
+        if (hipModuleGetFunction(&h->bulk_all_res_fn, h->module, "pc_bulk_all_r") != hipSuccess) h->bulk_all_res_fn = nullptr;
       }
     }
     {   // one buffer: the weight tables right behind the A tables (the kernels address both from `qa`)
@@ -736,10 +834,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       auto& P = Q.ph[ip];
       auto& D = *h->pd[ip];
       HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
-      if (ip + 1 == Q.ph.size()) {
-        if (hipModuleGetFunction(&D.fn_fused, h->module, (P.bulk_kernel + "_f").c_str()) != hipSuccess)
-          D.fn_fused = nullptr;   // code object without the fused variant: two launches per evaluation
-      }
+      if (Q.ph.size() == 1 && hipModuleGetFunction(&D.fn_res, h->module, (P.bulk_kernel + "_r").c_str()) != hipSuccess)
+        D.fn_res = nullptr;   // code object without the resident-tail variant: two launches per evaluation
       D.tile_k0.upload(P.tile_k0);
       {
         std::vector<int32_t> tn(P.tile_k0.size());
@@ -754,25 +850,75 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.hsum_slot.upload(P.hsum_slot);
       D.hsum_local.upload(P.hsum_local);
       D.partials.alloc((size_t)std::max(1, P.nred) * D.n_tiles);
-      if (h->dbg_stage == 9) D.dbg.alloc((size_t)64 * D.n_tiles);   // 4 waves x 16 stamps per tile
+      D.gran.upload(std::vector<unsigned long long>((size_t)2 * std::max(1, P.nred) * D.n_tiles, 0ull));   // tag 0: never written
     }
-    h->d_sync.upload(std::vector<unsigned>((PC_SYNC_SHARDS + 1) * 16, 0u));
-    if (const char* env = std::getenv("PYCOLLO_AMD_FUSE")) h->allow_fuse = std::atoi(env) != 0;
+    {
+      // Edge-node Hessian entries on which an endpoint term lands: in a resident-tail launch the edge tile hands the
+      // value to the tail workgroup (a record of two granules) instead of storing it.  pt_rec: endpoint entry ->
+      // record; edge_rec (per phase): every edge-node entry site the bulk kernel knows -> record or -1.
+      std::map<int64_t, int32_t> rec_of_slot;
+      std::vector<int32_t> pt_rec(Q.pt_hslot.size(), -1);
+      for (size_t e = 0; e < Q.pt_hslot.size(); ++e)
+        if (Q.pt_hlocal[e] < 0) {
+          pt_rec[e] = (int32_t)rec_of_slot.size();
+          rec_of_slot.emplace(Q.pt_hslot[e], pt_rec[e]);
+        }
+      h->d_pt_rec.upload(pt_rec);
+      h->d_erec.upload(std::vector<unsigned long long>(2 * std::max<size_t>(1, rec_of_slot.size()), 0ull));
+      auto rec = [&](int64_t slot) -> int32_t {
+        auto it = slot >= 0 ? rec_of_slot.find(slot) : rec_of_slot.end();
+        return it == rec_of_slot.end() ? -1 : it->second;
+      };
+      size_t used = 0;
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+        auto& P = Q.ph[ip];
+        const int NZ = P.n_z, NS = Q.n_s, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
+        std::vector<int32_t> er(2 * (size_t)NE, -1);
+        for (int edge = 0; edge < 2; ++edge) {
+          const int64_t node = edge ? P.N - 1 : 0;
+          for (int i = 0; i < NHZZ; ++i) er[edge * NE + i] = rec(edge ? P.hslotN[i] : P.hslot0[i]);
+          for (int i = 0; i < 2 * NZ + NS * NZ; ++i) {
+            const int64_t base = P.hoff[NZ + i];   // t strips (j, z) then s strips (l, z)
+            er[edge * NE + NHZZ + i] = base >= 0 ? rec(base + node) : -1;
+          }
+        }
+        for (int32_t v : er) used += v >= 0 ? 1 : 0;
+        h->pd[ip]->edge_rec.upload(er);
+      }
+      if (used != rec_of_slot.size())
+        throw std::runtime_error("internal error: an endpoint Hessian term lands on an edge-node entry no tile produces");
+    }
+    h->h_timeout.alloc(16);
+    std::memset(h->h_timeout.p, 0, 16 * sizeof(unsigned));
     h->d_point_x.upload(Q.point_x);
     h->d_tail_owned.upload(Q.tail_owned);
     h->d_pt_hslot.upload(Q.pt_hslot);
     h->d_pt_hlocal.upload(Q.pt_hlocal);
     h->d_g_indptr.upload(Q.g_indptr);
     const size_t nG = Q.g_row.size(), nH = Q.h_row.size();
-    h->d_x.alloc(Q.num_x); h->d_lam.alloc(Q.num_c); h->d_c.alloc(Q.num_c);
-    h->d_G.alloc(nG); h->d_H.alloc(nH); h->d_fobj.alloc(1);
-    h->d_grad.alloc(Q.num_x); h->d_norms.alloc(Q.num_c);
-    h->h_x.alloc(Q.num_x); h->h_lam.alloc(Q.num_c); h->h_c.alloc(Q.num_c);
-    h->h_G.alloc(nG); h->h_H.alloc(nH); h->h_fobj.alloc(1);
-    h->h_grad.alloc(Q.num_x); h->h_norms.alloc(Q.num_c);
-    HIP_OK(hipMemset(h->d_lam.p, 0, Q.num_c * sizeof(double)));
-    if (!h->bulk_all_fn && h->allow_fuse && h->pd.back()->fn_fused && h->pd.back()->n_tiles <= 8192)
-      h->n_launches = (int)Q.ph.size();
+    {
+      // every part starts on a 256-byte boundary (what a separate allocation would give the kernels)
+      auto up = [](size_t v) { return (v + 31) & ~(size_t)31; };
+      h->o_lam = up(Q.num_x);
+      h->in_total = h->o_lam + up(Q.num_c);
+      h->o_f = 0;
+      h->o_gn = 1;
+      h->o_c = up(1 + Q.jgrad_col.size());
+      h->o_G = h->o_c + up(Q.num_c);
+      h->o_H = h->o_G + up(nG);
+      h->out_total = h->o_H + up(nH);
+    }
+    h->d_in.alloc(h->in_total); h->d_out.alloc(h->out_total);
+    h->h_in.alloc(h->in_total); h->h_out.alloc(h->out_total);
+    h->d_norms.alloc(Q.num_c); h->h_norms.alloc(Q.num_c);
+    HIP_OK(hipMemset(h->d_in.p, 0, h->in_total * sizeof(double)));
+    HIP_OK(hipMemset(h->d_out.p, 0, h->out_total * sizeof(double)));
+    std::memset(h->h_in.p, 0, h->in_total * sizeof(double));
+    std::memset(h->h_out.p, 0, h->out_total * sizeof(double));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_small, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&h->ev_G, hipEventDisableTiming));
+    if (const char* env = std::getenv("PYCOLLO_AMD_HOST_MODE")) h->host_mode = std::atoi(env) & 3;
+    if (h->resident && (Q.ph.size() > 1 ? h->bulk_all_res_fn != nullptr : h->pd[0]->fn_res != nullptr)) h->n_launches = 1;
   });
   if (!ok) return 0;
   *out = h.release();
@@ -786,6 +932,8 @@ void pc_destroy(pc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
   }
   h->pd.clear();
+  if (h->ev_small) (void)hipEventDestroy(h->ev_small);
+  if (h->ev_G) (void)hipEventDestroy(h->ev_G);
   if (h->module) (void)hipModuleUnload(h->module);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -843,8 +991,9 @@ int pc_set_scaling(pc_handle* h, const double* V, const double* r, const double*
   return guarded([&] {
     if (!h || !V || !r || !W) throw std::runtime_error("null argument");
     if (h->device >= 0) {
+      // evaluations may be in flight on a caller's stream (pc_eval_all_device): none may still read the tables
       HIP_OK(hipSetDevice(h->device));
-      HIP_OK(hipStreamSynchronize(h->stream));
+      HIP_OK(hipDeviceSynchronize());
     }
     h->V_ocp.assign(V, V + h->Q.num_ocp_x);
     h->r_ocp.assign(r, r + h->Q.num_ocp_x);
@@ -862,7 +1011,7 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
                obj_factor);
   });
 }
@@ -872,7 +1021,7 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, 1.0,
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, 1.0,
                true, false);
   });
 }
@@ -882,7 +1031,7 @@ int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, co
   return guarded([&] {
     require_device(h);
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
                obj_factor, false, true);
   });
 }
@@ -892,9 +1041,13 @@ int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end) {
     if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
     auto& D = *h->pd[phase];
     if (tile_begin < 0 || tile_end < tile_begin || tile_end > D.n_tiles) throw std::runtime_error("tile range out of range");
+    if (h->device >= 0) {
+      HIP_OK(hipSetDevice(h->device));
+      HIP_OK(hipDeviceSynchronize());   // launches in flight on any stream still use the old range
+    }
     D.tile_begin = tile_begin;
     D.tile_end = tile_end;
-    h->have_cG = false;
+    h->fc_valid = false;
     h->args_dirty = true;
     h->host_args_dirty = true;
   });
@@ -913,6 +1066,10 @@ int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nre
 int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials) {
   return guarded([&] {
     if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");
+    if (h->device >= 0) {
+      HIP_OK(hipSetDevice(h->device));
+      HIP_OK(hipDeviceSynchronize());
+    }
     h->pd[phase]->partials_ext = d_partials;
     h->args_dirty = true;
     h->host_args_dirty = true;
@@ -924,149 +1081,161 @@ int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* 
   return guarded([&] {
     require_device(h);
     auto& Q = h->Q;
-    copy_x_in(h, x);
-    std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
-    HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    launch_all(h, h->d_x.p, h->d_lam.p, h->d_c.p, h->d_G.p, h->d_H.p, h->d_fobj.p, nullptr,
+    if (!x || !lambda || !g || !jac || !hess) throw std::runtime_error("null argument");
+    // one block up: [x~ | lambda] (contiguous in the pinned block, gap included)
+    if (x != h->h_in.p) std::memcpy(h->h_in.p, x, Q.num_x * sizeof(double));
+    if (lambda != h->h_in.p + h->o_lam) std::memcpy(h->h_in.p + h->o_lam, lambda, Q.num_c * sizeof(double));
+    if (!(h->host_mode & 1))
+      HIP_OK(hipMemcpyAsync(h->d_in.p, h->h_in.p, h->in_total * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    launch_all(h, kx(h), klam(h), kout(h, h->o_c), kout(h, h->o_G), kout(h, h->o_H), kout(h, h->o_f), kout(h, h->o_gn),
                PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, h->stream, obj_factor);
-    HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-    std::memcpy(g, h->h_c.p, Q.num_c * sizeof(double));
-    std::memcpy(jac, h->h_G.p, h->d_G.n * sizeof(double));
-    std::memcpy(hess, h->h_H.p, h->d_H.n * sizeof(double));
-    h->have_cG = true;
+    // one block down: [J | grad J | c~ | G~ | H~]
+    copy_down(h, 0, h->o_H + Q.h_row.size());
+    wait_stream(h);
+    if (g != h->h_out.p + h->o_c) std::memcpy(g, h->h_out.p + h->o_c, Q.num_c * sizeof(double));
+    if (jac != h->h_out.p + h->o_G) std::memcpy(jac, h->h_out.p + h->o_G, Q.g_row.size() * sizeof(double));
+    if (hess != h->h_out.p + h->o_H) std::memcpy(hess, h->h_out.p + h->o_H, Q.h_row.size() * sizeof(double));
+    h->x_valid = h->fc_valid = h->small_synced = h->G_synced = true;
   });
 }
 
-// c and G are produced together on a new x and cached for the companion call (IPOPT evaluates
-// g and jac_g at the same x; pycollo/nlp.py:53-57)
-static void eval_cG(pc_handle* h, const double* x, int new_x) {
+int pc_host_buffers(pc_handle* h, double** x, double** lambda, double** g, double** jac, double** hess) {
+  return guarded([&] {
+    require_device(h);
+    if (x) *x = h->h_in.p;
+    if (lambda) *lambda = h->h_in.p + h->o_lam;
+    if (g) *g = h->h_out.p + h->o_c;
+    if (jac) *jac = h->h_out.p + h->o_G;
+    if (hess) *hess = h->h_out.p + h->o_H;
+  });
+}
+
+int pc_set_host_mode(pc_handle* h, int mode) {
+  return guarded([&] {
+    require_device(h);
+    if (mode < 0 || mode > 3) throw std::runtime_error("host mode must be 0..3");
+    HIP_OK(hipStreamSynchronize(h->stream));
+    h->host_mode = mode;
+    h->x_valid = h->fc_valid = false;
+  });
+}
+
+// J, grad J, c~ and G~ are produced together by the first callback at a new x and kept for the companion calls
+// (IPOPT evaluates f, grad f, g, jac g at the same x, passing new_x = 1 to the first of them only;
+// pycollo/nlp.py:47-57).  The small results [J | grad J | c~] and the large one, G~, come down as two copies so that
+// eval_f / eval_g of a line-search trial point wait for the small one only.
+static void ensure_fcG(pc_handle* h, const double* x, int new_x) {
   require_device(h);
-  if (!new_x && h->have_cG) return;
-  auto& Q = h->Q;
-  copy_x_in(h, x);
-  launch_all(h, h->d_x.p, nullptr, h->d_c.p, h->d_G.p, nullptr, h->d_fobj.p, nullptr, PC_FLAG_C | PC_FLAG_G, h->stream,
-             1.0);
-  HIP_OK(hipMemcpyAsync(h->h_c.p, h->d_c.p, Q.num_c * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(h->h_G.p, h->d_G.p, h->d_G.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  h->have_cG = true;
+  stage_x(h, x, new_x);
+  if (h->fc_valid) return;
+  launch_all(h, kx(h), nullptr, kout(h, h->o_c), kout(h, h->o_G), nullptr, kout(h, h->o_f), kout(h, h->o_gn),
+             PC_FLAG_C | PC_FLAG_G, h->stream, 1.0);
+  copy_down(h, 0, h->o_c + h->Q.num_c);
+  HIP_OK(hipEventRecord(h->ev_small, h->stream));
+  copy_down(h, h->o_G, h->o_G + h->Q.g_row.size());
+  HIP_OK(hipEventRecord(h->ev_G, h->stream));
+  h->fc_valid = true;
+  h->small_synced = h->G_synced = false;
+}
+static void wait_small(pc_handle* h) {
+  if (h->small_synced) return;
+  if (h->spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipEventQuery(h->ev_small) == hipErrorNotReady &&
+           std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() <= h->spin_us) {}
+  }
+  HIP_OK(hipEventSynchronize(h->ev_small));
+  check_timeout(h);
+  h->small_synced = true;
+}
+static void wait_G(pc_handle* h) {
+  if (h->G_synced) return;
+  if (h->spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipEventQuery(h->ev_G) == hipErrorNotReady &&
+           std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() <= h->spin_us) {}
+  }
+  HIP_OK(hipEventSynchronize(h->ev_G));
+  check_timeout(h);
+  h->small_synced = h->G_synced = true;
+}
+
+int pc_eval_f(pc_handle* h, const double* x, int new_x, double* f) {
+  return guarded([&] {
+    ensure_fcG(h, x, new_x);
+    wait_small(h);
+    *f = h->h_out.p[h->o_f];
+  });
+}
+
+int pc_eval_grad_f(pc_handle* h, const double* x, int new_x, double* grad) {
+  return guarded([&] {
+    ensure_fcG(h, x, new_x);
+    wait_small(h);
+    auto& Q = h->Q;
+    std::memset(grad, 0, Q.num_x * sizeof(double));
+    for (size_t e = 0; e < Q.jgrad_col.size(); ++e) grad[Q.point_x[Q.jgrad_col[e]]] = h->h_out.p[h->o_gn + e];
+  });
 }
 
 int pc_eval_g(pc_handle* h, const double* x, int new_x, double* g) {
   return guarded([&] {
-    eval_cG(h, x, new_x);
-    std::memcpy(g, h->h_c.p, h->Q.num_c * sizeof(double));
+    ensure_fcG(h, x, new_x);
+    wait_small(h);
+    if (g != h->h_out.p + h->o_c) std::memcpy(g, h->h_out.p + h->o_c, h->Q.num_c * sizeof(double));
   });
 }
 
 int pc_eval_jac_g(pc_handle* h, const double* x, int new_x, double* values) {
   return guarded([&] {
-    eval_cG(h, x, new_x);
-    std::memcpy(values, h->h_G.p, h->d_G.n * sizeof(double));
+    ensure_fcG(h, x, new_x);
+    wait_G(h);
+    if (values != h->h_out.p + h->o_G) std::memcpy(values, h->h_out.p + h->o_G, h->Q.g_row.size() * sizeof(double));
   });
 }
 
 int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const double* lambda, int new_lambda,
               double* values) {
-  (void)new_lambda;
+  (void)new_lambda;   // sigma and lambda are cheap to restage; H~ is always re-evaluated
   return guarded([&] {
     require_device(h);
     auto& Q = h->Q;
-    if (new_x) h->have_cG = false;
-    copy_x_in(h, x);
-    std::memcpy(h->h_lam.p, lambda, Q.num_c * sizeof(double));
-    HIP_OK(hipMemcpyAsync(h->d_lam.p, h->h_lam.p, Q.num_c * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    launch_all(h, h->d_x.p, h->d_lam.p, nullptr, nullptr, h->d_H.p, h->d_fobj.p, nullptr, PC_FLAG_H, h->stream,
+    stage_x(h, x, new_x);
+    stage_lambda(h, lambda);
+    launch_all(h, kx(h), klam(h), nullptr, nullptr, kout(h, h->o_H), kout(h, h->o_f), nullptr, PC_FLAG_H, h->stream,
                obj_factor);
-    HIP_OK(hipMemcpyAsync(h->h_H.p, h->d_H.p, h->d_H.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-    std::memcpy(values, h->h_H.p, h->d_H.n * sizeof(double));
-  });
-}
-
-static void eval_obj(pc_handle* h, const double* x, bool want_grad) {
-  require_device(h);
-  auto& Q = h->Q;
-  copy_x_in(h, x);
-  if (want_grad) HIP_OK(hipMemsetAsync(h->d_grad.p, 0, Q.num_x * sizeof(double), h->stream));
-  // flags = 0: the bulk kernels are skipped entirely, only the endpoint block runs
-  PcTailLaunch tl;
-  std::memset(&tl, 0, sizeof(tl));
-  PcTailArgs& t = tl.t;
-  t.x = h->d_x.p;
-  t.fobj = h->d_fobj.p;
-  t.grad = want_grad ? h->d_grad.p : nullptr;
-  t.sigma = 1.0;
-  t.wJ = h->w_J;
-  t.point_x = h->d_point_x.p;
-  t.point_V = h->d_pointV.p;
-  t.point_r = h->d_pointr.p;
-  t.W_end = h->d_Wend.p;
-  fill_point_tables(h, t);
-  t.c_end_off = Q.c_end_off;
-  t.g_end_base = Q.g_end_base;
-  t.flags = 0;
-  t.block_threads = PC_TAIL_THREADS;
-  for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
-    t.ph[ip].n_tiles = 0;
-    t.ph[ip].partials = h->pd[ip]->partials.p;
-    t.ph[ip].scal = h->pd[ip]->scal.p;
-    t.ph[ip].x_off = Q.ph[ip].x_off;
-    t.ph[ip].N = Q.ph[ip].N;
-    t.ph[ip].t_fixed[0] = Q.ph[ip].t_fixed[0];
-    t.ph[ip].t_fixed[1] = Q.ph[ip].t_fixed[1];
-  }
-  tl.lead = PcTailLead{t.x, t.ph[0].partials, t.ph[0].scal, t.ph[0].x_off, t.ph[0].n_tiles, t.ph[0].N, t.flags, t.block_threads};
-  size_t sz = sizeof(tl);
-  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &tl, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  HIP_OK(hipModuleLaunchKernel(h->tail_fn, 1, 1, 1, PC_TAIL_THREADS, 1, 1, 0, h->stream, nullptr, cfg));
-  HIP_OK(hipMemcpyAsync(h->h_fobj.p, h->d_fobj.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (want_grad)
-    HIP_OK(hipMemcpyAsync(h->h_grad.p, h->d_grad.p, Q.num_x * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-}
-
-int pc_eval_f(pc_handle* h, const double* x, int new_x, double* f) {
-  (void)new_x;
-  return guarded([&] {
-    eval_obj(h, x, false);
-    *f = h->h_fobj.p[0];
-  });
-}
-
-int pc_eval_grad_f(pc_handle* h, const double* x, int new_x, double* grad) {
-  (void)new_x;
-  return guarded([&] {
-    eval_obj(h, x, true);
-    std::memcpy(grad, h->h_grad.p, h->Q.num_x * sizeof(double));
+    copy_down(h, h->o_H, h->o_H + Q.h_row.size());
+    wait_stream(h);
+    h->small_synced = h->G_synced = h->fc_valid;   // the stream has drained: earlier copies are complete too
+    if (values != h->h_out.p + h->o_H) std::memcpy(values, h->h_out.p + h->o_H, Q.h_row.size() * sizeof(double));
   });
 }
 
 int pc_row_norms_jac(pc_handle* h, const double* x, double* norms) {
   return guarded([&] {
-    eval_cG(h, x, 1);
+    require_device(h);
+    // always through the device mirror: the row reduction reads G~ back
+    const int mode = h->host_mode;
+    h->host_mode = 0;
+    h->x_valid = h->fc_valid = false;
+    try {
+      ensure_fcG(h, x, 1);
+    } catch (...) {
+      h->host_mode = mode;
+      throw;
+    }
+    h->host_mode = mode;
     const int64_t m = h->Q.num_c;
     const int64_t threads = m * 64;
     const int blocks = (int)((threads + 255) / 256);
-    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_g_indptr.p, h->d_G.p,
+    hipLaunchKernelGGL(row_norms_kernel, dim3(blocks), dim3(256), 0, h->stream, h->d_g_indptr.p, h->d_out.p + h->o_G,
                        h->d_norms.p, m);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(h->h_norms.p, h->d_norms.p, m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     std::memcpy(norms, h->h_norms.p, m * sizeof(double));
-  });
-}
-
-int pc_debug_stamps(pc_handle* h, int phase, long long* out, int n_tiles) {
-  return guarded([&] {
-    require_device(h);
-    auto& D = *h->pd.at(phase);
-    if (!D.dbg.p) throw std::runtime_error("no stamps: create the handle with PYCOLLO_AMD_DBG_STAGE=9");
-    HIP_OK(hipDeviceSynchronize());
-    HIP_OK(hipMemcpy(out, D.dbg.p, sizeof(long long) * 64 * std::min(n_tiles, D.n_tiles), hipMemcpyDeviceToHost));
+    h->x_valid = h->fc_valid = (mode == 0);   // the cache describes the device mirror only
+    h->small_synced = h->G_synced = h->fc_valid;
   });
 }
 
@@ -1149,8 +1318,11 @@ int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const 
     d_A.upload(std::vector<double>(tabA, tabA + oA));
     d_rel.alloc(P.K);
     d_abs.alloc((size_t)P.K * std::max(1, P.n_y));
-    copy_x_in(h, x);
-    a.x = h->d_x.p;
+    // (always through the device mirror; the callback cache no longer describes it afterwards)
+    std::memcpy(h->h_in.p, x, Q.num_x * sizeof(double));
+    HIP_OK(hipMemcpyAsync(h->d_in.p, h->h_in.p, Q.num_x * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    h->x_valid = h->fc_valid = false;
+    a.x = h->d_in.p;
     a.tile_k0 = d_tile.p;
     a.lane0 = d_lane.p;
     a.sec_s = D.sec_s.p;
@@ -1185,6 +1357,7 @@ int pc_synchronize(pc_handle* h) {
   return guarded([&] {
     require_device(h);
     HIP_OK(hipStreamSynchronize(h->stream));
+    check_timeout(h);
   });
 }
 

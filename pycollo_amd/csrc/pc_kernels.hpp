@@ -315,11 +315,12 @@ struct BulkIn {
   const double* x; const double* lam; double* c; double* G; double* H;
   const double* xz; const double* lamd;   // x + x_off, lam + c_off
   const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
-  const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials; long long* dbg;
-  unsigned* sync; const double* tab;
+  const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials;
+  unsigned long long* gran; unsigned long long* erec; const int32_t* edge_rec; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
-  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, dbg_stage, wpt, n_blocks, block_threads, qa0, qw0, qwabs;
+  int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, wpt, n_blocks, block_threads, qa0, qw0, qwabs;
+  uint32_t epoch;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -328,9 +329,6 @@ struct BulkIn {
 #define PC_PIN(v) asm volatile("" ::"s"(v))
 #ifndef PC_PIN_BUDGET
 #define PC_PIN_BUDGET 40   // SGPRs the per-variable constants may take
-#endif
-#ifndef PC_PIN_BUDGET_FUSED
-#define PC_PIN_BUDGET_FUSED 0   // the fused build also carries the tail's scalars
 #endif
 // One empty asm per value would do the forcing too, but every inline asm is a scheduling boundary: the loads
 // then come in several dependent batches (measured: 6 loads, wait, 2 loads, wait, 2 loads, wait ...).  Folding all
@@ -357,21 +355,37 @@ __device__ __forceinline__ void pin_array(PinAcc& p, const T (&a)[N]) {
 // UN > 0: the phase's mesh has UN nodes in every section and the kernel is compiled for exactly that
 // order (loops over section rows / nodes unroll, their LDS reads issue back to back, index arithmetic
 // divides by constants).  UN == 0: any mesh (orders may differ section by section).
-// Agent-scope relaxed store: `global_store ... sc1` (write-through).  Used for the few words another
-// workgroup of the same launch reads (fused tail): per-tile partial sums and the Hessian entries of the
-// edge nodes 0 / N-1 that the endpoint block accumulates into.
-__device__ __forceinline__ void store_agent(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v),
-                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+//
+// RES = false: the per-phase bulk kernel; a separate `pc_tail` launch finishes the evaluation (what a rank of the
+// section-sharded evaluation runs: its partial sums travel through the all-gather first).
+// RES = true: the "resident tail" build -- the launch carries one more workgroup (block 0) that runs the tail
+// concurrently with the tiles, so an evaluation is ONE launch and the tail's own work overlaps the bulk's.  The
+// tail needs two kinds of values other workgroups of the same launch produce: the per-tile partial sums and the
+// Hessian entries of the edge nodes 0 / N-1 that endpoint terms are added to.  Both are handed over as *granules*
+// (cdna_hip_programming.md G16, recipe R2 "the data IS the flag"): an aligned 8-byte word {epoch : 32, half of the
+// double : 32}, written with ONE agent-scope (sc1, write-through) store and polled with agent-scope loads until the
+// tag equals this launch's epoch.  No release fence, no store drain, no atomics, no counter on the producer side:
+// a tile publishes as soon as the values exist (before its bulky c~ / G~ stores) and never waits.  The tail
+// workgroup waits for producers that themselves wait for nothing, so no co-residency is required; its spin is
+// bounded and reports through PcTailArgs::timeout.
+__device__ __forceinline__ void publish_granules(unsigned long long* g, unsigned epoch, double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v), e = (unsigned long long)epoch << 32;
+  __hip_atomic_store(g, e | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, e | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one attempt, in two steps so that a caller can request many granules before it looks at the first:
+// load_granule = one agent-scope load; join_granules = true when both halves carry this launch's tag
+__device__ __forceinline__ unsigned long long load_granule(const unsigned long long* g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool join_granules(unsigned long long lo, unsigned long long hi, unsigned epoch, double& v) {
+  v = __builtin_bit_cast(double, (hi << 32) | (lo & 0xffffffffull));
+  return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+}
+#ifndef PC_SPIN_LIMIT
+#define PC_SPIN_LIMIT (1 << 21)   // passes of ~1 us each before the tail gives up (an evaluation takes < 1 ms)
+#endif
 
-// TAIL = void: the per-phase bulk kernel; a separate `pc_tail` launch finishes the evaluation.
-// TAIL = generated struct with `static void run(const PcTailArgs&)`: the last workgroup to finish runs the
-// tail inside this launch (one launch per evaluation).  Protocol (cdna_hip_programming.md G16, fan-in
-// row): payload stored sc1 -> every storing wave drains vmcnt -> workgroup barrier -> ONE lane adds to an
-// arrival counter (two levels: PC_SYNC_SHARDS shards, then a top counter, so that tens of thousands of
-// workgroups do not serialise on one word); the workgroup whose add completes the count issues ONE
-// agent-scope acquire and then reads with vector loads.  Counters reset themselves for the next launch.
 // Force compile-time evaluation of a structure helper: `constexpr` alone lets the compiler emit the helper's search
 // loop at run time (it did, 134 times in the Delta III kernel), and an array subscripted by such a run-time value
 // is demoted from registers to scratch memory.
@@ -397,10 +411,9 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 
 // MA != null: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call
 // pointers and flags come from MA, the workgroup's tile from its index relative to the phase's first block.
-template <class M, int UN, class TAIL = void>
-__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA = nullptr, const PcMultiArgs* MA = nullptr,
-                                     int first_block = 0, int block = -1, const PcLead* LD = nullptr) {
-  constexpr bool FUSED = !std::is_void<TAIL>::value;
+template <class M, int UN, bool RES = false>
+__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* MA = nullptr, int first_block = 0,
+                                     int block = -1, const PcLead* LD = nullptr) {
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
@@ -469,12 +482,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     if (LD) { A.x = KB.x; A.lam = KB.lam; A.x_off = KB.x_off; A.c_off = KB.c_off; }
     if constexpr (UN > 0) { A.uni_n = KB.uni_n; A.tile_k0 = KB.tile_k0; A.tile_n0 = KB.tile_n0; A.sec_s = KB.sec_s; }
     A.sec_E = KB.sec_E;
-    A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials; A.dbg = KB.dbg;
-    A.sync = KB.sync; A.tab = KB.tab;
+    A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials;
+    A.gran = KB.gran; A.erec = KB.erec; A.edge_rec = KB.edge_rec; A.tab = KB.tab;
+    A.epoch = MA ? MA->epoch : KB.epoch;
     A.s_off = KB.s_off; A.c_path_off = KB.c_path_off; A.c_int_off = KB.c_int_off;
     A.t_fixed[0] = KB.t_fixed[0]; A.t_fixed[1] = KB.t_fixed[1];
     A.qa_total = KB.qa_total; A.qw_total = KB.qw_total;
-    A.lds_out = KB.lds_out; A.dbg_stage = KB.dbg_stage;
+    A.lds_out = KB.lds_out;
     A.qw0 = KB.qw_off[UN > 0 ? UN : 0];
     static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KB.scal[decltype(i_)::value]; });
     static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KB.goff[decltype(i_)::value]; });
@@ -533,7 +547,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   PinAcc pin;
   pin(A.x); pin(A.lam); pin(A.sec_h); pin(A.qa); pin(A.qw);
   pin(A.x_off); pin(A.c_off); pin(A.N); pin(A.K); pin(A.flags); pin(A.qa_total); pin(A.qw_total); pin(A.tile_begin);
-  pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.dbg_stage); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
+  pin(A.uni_n); pin(A.spt); pin(A.lds_out); pin(A.wpt); pin(A.n_blocks); pin(A.block_threads);
   if constexpr (UN > 0) { pin(A.qa0); pin(A.qwabs); }
   if constexpr (NP > 0) pin(A.c_path_off);
   if constexpr (NQ > 0) pin(A.c_int_off);
@@ -542,16 +556,15 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   pin.done();
   // (hslot0 / hslotN are left lazy: only the two edge tiles read them)
   constexpr int NHO = 3 * NZ + NS * NZ;
-  constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= (FUSED ? PC_PIN_BUDGET_FUSED : PC_PIN_BUDGET);
+  constexpr bool PINNED = 2 * (St::NSCAL + NFN + NHO) <= PC_PIN_BUDGET;
   auto pin_second_group = [&]() {
     PinAcc pin2;
     pin2(A.c); pin2(A.G); pin2(A.H);
-    if constexpr (NRED > 0) pin2(A.partials);
+    if constexpr (NRED > 0) { if constexpr (RES) pin2(A.gran); else pin2(A.partials); }
     if constexpr (!M::T0_FREE) pin2(A.t_fixed[0]);
     if constexpr (!M::TF_FREE) pin2(A.t_fixed[1]);
-    if constexpr (FUSED) pin2(A.sync);
 #ifdef PC_PIN_ALL   // A/B switch: the earlier, over-full pin list
-    pin2(A.hslot0); pin2(A.hslotN); pin2(A.dbg); pin2(A.sync); pin2(A.tab); pin2(A.s_off); pin2(A.c_path_off);
+    pin2(A.hslot0); pin2(A.hslotN); pin2(A.tab); pin2(A.s_off); pin2(A.c_path_off);
     pin2(A.c_int_off); pin2(A.t_fixed[0]); pin2(A.t_fixed[1]);
     pin_array<St::NSCAL>(pin2, A.scal); pin_array<3 * NZ + NS * NZ>(pin2, A.hoff);
 #endif
@@ -636,18 +649,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
   };
 
   const bool wantC = A.flags & PC_FLAG_C, wantG = A.flags & PC_FLAG_G;
-  if (A.dbg_stage == 1) return;
-  // diagnostic timeline (dbg_stage == 9 only; never executes in a normal launch): lane 0 of each of a tile's
-  // (up to four) waves stamps s_memtime at the phase boundaries into a buffer of its own
-  const bool stamping = (A.dbg_stage == 9) && (threadIdx.x & 63) == 0;
-  auto STAMP = [&](int k) {
-    if (stamping) {
-      unsigned long long tm;
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm)::"memory");
-      A.dbg[((int64_t)tile * 4 + (threadIdx.x >> 6)) * 16 + k] = (long long)tm;
-    }
-  };
-  STAMP(0);
 
   const bool last_tile = (k1 == A.K);
 
@@ -736,8 +737,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     if (tid == 0 && n0 == 0) s_kr[0] = -1;
   }
   block_sync();
-  STAMP(1);
-  if (A.dbg_stage == 2) { if (active && v[0] == 1.2345e300) A.c[0] = v[0]; return; }
 
   // section accessors (local index ls counts from section kp)
   auto S_s = [&](int ls) -> int { return uni ? (kp + ls) * (un - 1) : s_s[ls]; };
@@ -875,14 +874,51 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
 
-  STAMP(2);
+  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile): every wave deposits its sums here.  The
+  //      two-launch build combines the waves' sums at the very end (no replica waits for another mid-kernel); the
+  //      resident-tail build publishes them at once as granules, ahead of the bulky c~ / G~ runs, so that the tail
+  //      workgroup finishes while this tile is still storing.
+  auto deposit_partials = [&]() {
+  if constexpr (NRED > 0) {
+    static_for<0, NRED>([&](auto r_) {   // replicas hold copies: the owner of the sum's item contributes
+      constexpr int r = decltype(r_)::value;
+      if (!mine(PC_ITEM(PC_CE(St::red_item(r))))) red[r] = 0.0;
+    });
+    const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
+    if (RES && wave_private) {
+      // one wave holds every node of the tile: the sum of the item's owner IS the tile's sum (the other replicas
+      // would add exact zeros), and the owner publishes it itself
+      static_for<0, NRED>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        const double sr = wave_sum(red[r]);
+        if (lane == 0 && mine(PC_ITEM(PC_CE(St::red_item(r)))))
+          publish_granules(A.gran + 2 * ((int64_t)tile * NRED + r), A.epoch, sr);
+      });
+      return;
+    }
+    static_for<0, NRED>([&](auto r_) {
+      constexpr int r = decltype(r_)::value;
+      const double sr = wave_sum(red[r]);
+      if (lane == 0) s_red[r * 16 + wave] = sr;
+    });
+    if constexpr (RES) {   // several waves share the tile's nodes: their sums meet in LDS, in wave order
+      lds_barrier();
+      if (tid < NRED) {
+        double sr = 0.0;
+        for (int ww = 0; ww < nw; ++ww) sr += s_red[tid * 16 + ww];
+        publish_granules(A.gran + 2 * ((int64_t)tile * NRED + tid), A.epoch, sr);
+      }
+    }
+  }
+  };
   // ---- model evaluation -----------------------------------------------------------------------
   // The heaviest models evaluate in two passes -- values and first partials here, second partials after the
   // Jacobian has been written -- so that the two derivative sets are never live together.  It pays only where
   // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
   // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
   // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
-  constexpr bool SPLIT = !FUSED && (NJ + NH >= PC_SPLIT_MIN);
+  constexpr bool SPLIT = (NJ + NH >= PC_SPLIT_MIN);
+  constexpr bool RED_EARLY = RES && NS == 0 && NRED > 0;
   double mult[NFN > 0 ? NFN : 1];
   if (active) {
     static_for<0, NFN>([&](auto r_) {
@@ -891,6 +927,17 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
     if constexpr (SPLIT) M::eval_fj(v, F, Jv);
     else M::eval(v, mult, F, Jv, Hv);
+    if (owns) {   // this node's terms of the integral rows' sums (backend.py:1645-1647)
+      static_for<0, NQ>([&](auto m_) {
+        constexpr int m = decltype(m_)::value;
+        constexpr int r = NY + NP + m;
+        red[St::R_Q + m] = w_node * F[r];
+        static_for<0, NS>([&](auto l_) {
+          constexpr int l = decltype(l_)::value;
+          if constexpr (PC_CE(St::dep(r, NZ + l))) red[St::R_QS + m * NS + l] = w_node * Jv[PC_CE(St::jidx(r, NZ + l))];
+        });
+      });
+    }
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       s_f[a * TN + t] = F[a];
@@ -901,9 +948,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       });
     });
   }
+  // without static parameters every partial sum is an integrand sum and complete here: the resident-tail build
+  // publishes them now, a kernel's length ahead of the tail's need for them
+  if constexpr (RED_EARLY) deposit_partials();
   node_sync();
-  STAMP(3);
-  if (A.dbg_stage == 3) { if (active && F[0] == 1.2345e300) A.c[0] = F[0]; return; }
 
   // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
   double accf[NY > 0 ? NY : 1];
@@ -925,8 +973,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
   block_sync();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
-  STAMP(4);
-  if (A.dbg_stage == 4) return;
 
   // number of nodes this tile owns, and the first one (for the staged per-node runs)
   const int n_own = T + (last_tile ? 1 : 0);
@@ -961,11 +1007,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     static_for<0, NQ>([&](auto m_) {
       constexpr int m = decltype(m_)::value;
       constexpr int r = NY + NP + m;
-      red[St::R_Q + m] = w_node * F[r];
-      static_for<0, NS>([&](auto l_) {
-        constexpr int l = decltype(l_)::value;
-        if constexpr (PC_CE(St::dep(r, NZ + l))) red[St::R_QS + m * NS + l] = w_node * Jv[PC_CE(St::jidx(r, NZ + l))];
-      });
       if (wantG && mine(PC_ITEM(St::IT_Q + m))) {
         const double k = -sc[St::O_WI + m] * stretch * w_node;
         static_for<0, NZ>([&](auto b_) {
@@ -977,9 +1018,22 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     });
   }
 
-  STAMP(5);
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
   const bool edge0 = (node == 0), edgeN = (node == N - 1);
+  // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot and the
+  // resident tail finishes it: then the value is handed over as granules instead (edge_rec[site] = record or -1;
+  // sites: the z-z entries, the t strips (j, z), the s strips (l, z), for node 0 and again for node N-1).
+  constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
+  auto edge_store = [&](int site, double* dstp, double val) {
+    if constexpr (RES) {
+      const int rec = A.edge_rec[(edge0 ? 0 : NEDGE) + site];
+      if (rec >= 0) {
+        publish_granules(A.erec + 2 * rec, A.epoch, val);
+        return;
+      }
+    }
+    *dstp = val;
+  };
   auto hess_second = [&]() {     // everything built from the second partials
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
     static_for<0, NZ>([&](auto rv_) {
@@ -996,10 +1050,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           static_for<0, NH>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr (M::hr(e) == rv)
-              {
-                double* dstp = A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))];
-                if constexpr (FUSED) store_agent(dstp, vals[PC_CE(St::hpos(e))]); else *dstp = vals[PC_CE(St::hpos(e))];
-              }
+              edge_store(PC_CE(St::hzz_index(e)), A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))],
+                         vals[PC_CE(St::hpos(e))]);
           });
         }
         if constexpr (MB == 1) {
@@ -1023,7 +1075,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
           if (mine(PC_ITEM(St::IT_HS + cv))) {
             double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
             const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
-            if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
+            if (edge0 || edgeN) edge_store(St::NHZZ + 2 * NZ + (rv - NZ) * NZ + cv, dstp, val); else *dstp = val;
           }
         } else if constexpr (rv >= NZ) {
           constexpr int l = rv - NZ, l2 = cv - NZ;
@@ -1049,7 +1101,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
                 constexpr int j = decltype(j_)::value;
                 double* dstp = A.H + hoff[St::HO_T + j * NZ + cvar] + node;
                 const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
-                if (FUSED && (edge0 || edgeN)) store_agent(dstp, val); else *dstp = val;
+                if (edge0 || edgeN) edge_store(St::NHZZ + j * NZ + cvar, dstp, val); else *dstp = val;
               });
             } else {
               red[St::R_TS + cvar - NZ] = acc;
@@ -1064,75 +1116,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
     hess_tstrips();
   }
 
-  // ---- per-tile partial sums (fixed order: lanes -> waves -> tile): every wave deposits its sums here.  In the
-  //      fused build they are combined and stored at once, followed by the arrival: everything the tail consumes
-  //      (partials, edge Hessian entries) is out before the bulky c~/G~ runs, so the store drain below waits for a
-  //      handful of stores only
-  bool is_last = false;
-  auto deposit_partials = [&]() {
-  if constexpr (NRED > 0) {
-    static_for<0, NRED>([&](auto r_) {   // replicas hold copies: the owner of the sum's item contributes
-      constexpr int r = decltype(r_)::value;
-      if (!mine(PC_ITEM(PC_CE(St::red_item(r))))) red[r] = 0.0;
-    });
-    const int wave = tid >> 6, lane = tid & 63, nw = (TB + 63) >> 6;
-    static_for<0, NRED>([&](auto r_) {
-      constexpr int r = decltype(r_)::value;
-      const double s = wave_sum(red[r]);
-      if (lane == 0) s_red[r * 16 + wave] = s;
-    });
-    if constexpr (FUSED) {
-      lds_barrier();
-      if (tid < NRED) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
-        store_agent(A.partials + (int64_t)tile * NRED + tid, s);
-      }
-    }
-  }
-  };
-  // PC_FUSED_EARLY: the fused build's first design -- arrive right after the Hessian phase so that the tail overlaps
-  // the last workgroup's own c~/G~ work; it makes every workgroup drain its stores in mid-life (~1 us each).  The
-  // default fused build arrives at the very end instead (the drain is the one a kernel end performs anyway).
-#ifndef PC_FUSED_EARLY
-#define PC_FUSED_EARLY 0
-#endif
-  constexpr bool EARLY = FUSED && PC_FUSED_EARLY;
-  __shared__ int s_last;
-  auto arrive = [&]() {
-  if constexpr (FUSED) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains (payload is sc1)
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned nblk = (unsigned)A.n_blocks;   // (gridDim would be read from the dispatch packet in host memory)
-      const unsigned nsh = nblk < PC_SYNC_SHARDS ? nblk : PC_SYNC_SHARDS;
-      const unsigned sh = blockIdx.x % nsh;
-      const unsigned members = nblk / nsh + (sh < nblk % nsh ? 1u : 0u);
-      unsigned* cnt = A.sync + 16 * sh;
-      unsigned* top = A.sync + 16 * PC_SYNC_SHARDS;
-      int last = 0;
-      if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsh - 1) {
-          __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          last = 1;
-        }
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    is_last = s_last != 0;
-    STAMP(9);
-    if (is_last) {   // ONE acquire (early arrival: its latency overlaps this workgroup's own c~/G~ work below)
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if constexpr (!EARLY) __syncthreads();   // the other waves read only after the acquiring wave has passed it
-    }
-  }
-  };
-  if constexpr (!SPLIT && (!FUSED || EARLY)) deposit_partials();
-  if constexpr (EARLY) arrive();
-  STAMP(6);
-  if (A.dbg_stage == 5) return;
+  if constexpr (!SPLIT && !RED_EARLY) deposit_partials();
   // ---- Jacobian of the defect rows (compiled.py:305-334), one state at a time:
   //      entries are produced column-wise / row-wise into the staging buffer, then the tile's
   //      contiguous CSR run of that state is written to HBM fully coalesced
@@ -1220,79 +1204,86 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcTailArgs* TA
       if (active) M::eval_h(v, mult, Hv);
       hess_second();
     }
-    deposit_partials();
+    if constexpr (!RED_EARLY) deposit_partials();
   }
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
-  STAMP(11);
-  if constexpr (NRED > 0 && !FUSED) {
+  if constexpr (NRED > 0 && !RES) {
     block_sync();
     if (tid < NRED) {
       const int nw = (TB + 63) >> 6;
-      double s = 0.0;
-      for (int w = 0; w < nw; ++w) s += s_red[tid * 16 + w];
-      A.partials[(int64_t)tile * NRED + tid] = s;
-    }
-  }
-  if constexpr (FUSED && !EARLY) {   // everything this workgroup writes is out: deposit the sums, arrive
-    deposit_partials();
-    arrive();
-  }
-  STAMP(7);
-  if (A.dbg_stage == 6) return;
-  if constexpr (EARLY) {
-    if (is_last) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
-  STAMP(8);
-  if constexpr (FUSED) {
-    if (is_last) {
-      TAIL::template run<true>(*TA);
-      STAMP(10);
+      double sr = 0.0;
+      for (int ww = 0; ww < nw; ++ww) sr += s_red[tid * 16 + ww];
+      A.partials[(int64_t)tile * NRED + tid] = sr;
     }
   }
 }
 #undef PC_ITEM
 
 // ---------------------------------------------------------------------------------------------
-// tail kernel pieces (one workgroup)
+// tail pieces (one workgroup): the separate `pc_tail` launch, or block 0 of a resident-tail bulk launch
 // ---------------------------------------------------------------------------------------------
-// Hessian entries only the tail writes (sums over tiles, endpoint terms that meet no node block) are accumulated
-// in LDS and stored once: no zero-fill of global memory to drain, no read-modify-write round trips.
-__device__ __forceinline__ double* tail_acc() {
-  __shared__ double s_acc[PC_TAIL_OWNED_MAX];
-  return s_acc;
+// All of the tail's LDS is carved from the dynamic region (the resident build shares the bulk kernel's allocation;
+// a static array would be added to every tile's footprint):
+//   acc[n_tail_owned]  Hessian entries only the tail writes (sums over tiles, endpoint terms that meet no node
+//                      block) are accumulated here and stored once: no zero-fill of global memory, no RMW round trips
+//   part[16 * nred] sum[nred]   cross-wave partial sums of one phase
+//   xb[NPV] lb[NB] hold[NPH] hb[NPH]   endpoint inputs, current edge values, endpoint Hessian terms
+struct TailLds {
+  double *acc, *part, *sum, *xb, *lb, *hold, *hb;
+};
+template <class PT>
+__device__ __forceinline__ TailLds tail_lds(const PcTailArgs& A, double* base) {
+  TailLds L;
+  L.acc = base;
+  L.part = L.acc + A.n_tail_owned;
+  L.sum = L.part + 16 * A.lds_nred;
+  L.xb = L.sum + A.lds_nred;
+  L.lb = L.xb + PT::NPV;
+  L.hold = L.lb + PT::NB;
+  L.hb = L.hold + PT::NPH;
+  return L;
 }
-__device__ __forceinline__ void tail_begin(const PcTailArgs& A) {
-  double* acc = tail_acc();
+__device__ __forceinline__ void tail_begin(const PcTailArgs& A, const TailLds& L) {
   if (A.flags & PC_FLAG_H)
-    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) L.acc[i] = 0.0;
   lds_barrier();
 }
-__device__ __forceinline__ void tail_end(const PcTailArgs& A) {
-  const double* acc = tail_acc();
+__device__ __forceinline__ void tail_end(const PcTailArgs& A, const TailLds& L) {
   lds_barrier();
   if (A.flags & PC_FLAG_H)
-    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) A.H[A.tail_owned[i]] = acc[i];
+    for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) A.H[A.tail_owned[i]] = L.acc[i];
+}
+// bounded spin of the resident tail: a pass that found a granule missing sleeps a little; PC_SPIN_LIMIT passes mean
+// the producer will never come (a launch bug): the timeout word is set and the caller's wait loop ends
+__device__ __forceinline__ bool spin_again(unsigned& spins, const PcTailArgs& A, unsigned code) {
+  __builtin_amdgcn_s_sleep(2);
+  if (++spins < (unsigned)PC_SPIN_LIMIT) return true;
+  if (A.timeout) __hip_atomic_store(A.timeout, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return false;
 }
 
-// Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.  In two steps, so
-// that the loads of the first phase can be issued at the very start of the kernel from preloaded scalars (PcTailLead).
+// Finish the cross-tile sums of one phase: integral rows of c and G, (t,s)/(s,s) Hessian sums.  The order of the
+// additions is fixed by 256 *virtual* lanes whatever the workgroup size (64, 128 or 256 threads: a lane plays
+// 4, 2 or 1 of them): virtual lane v adds the tiles v, v + 256, ... in turn, the 64 lanes of a virtual wave are
+// summed by wave_sum, the four wave totals are added in order.  Every build of the tail -- separate launch, resident
+// block of any size -- therefore returns the same bits.
+// Two steps, so that the separate launch can issue the first phase's loads at the very start of the kernel from
+// preloaded scalars (PcTailLead).
 template <class M>
 struct TailPhaseRegs {
   using St = S<M>;
   double xt[2], vt[2], rt[2];
   double xq[St::NQ > 0 ? St::NQ : 1], wi[St::NQ > 0 ? St::NQ : 1], vq[St::NQ > 0 ? St::NQ : 1], rq[St::NQ > 0 ? St::NQ : 1];
-  double vs[St::NS > 0 ? St::NS : 1], acc[St::NRED > 0 ? St::NRED : 1];
+  double vs[St::NS > 0 ? St::NS : 1], acc[4][St::NRED > 0 ? St::NRED : 1];
 };
-template <class M, bool BIG = false>
+template <class M, bool RES = false, bool BIG = false>
 __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R, const PcTailLead* L = nullptr) {
   using St = S<M>;
   constexpr int NZ = St::NZ, NQ = St::NQ, NS = St::NS, NT = St::NT, NRED = St::NRED;
   if constexpr (NRED > 0) {
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = L ? L->block_threads : A.block_threads;  // 1 to 16 waves
+    const int tid = threadIdx.x, TB = L ? L->block_threads : A.block_threads;  // 64, 128 or 256
+    const int NG = 256 / TB;                                                    // virtual lanes per lane
     const double* xv = L ? L->x : A.x;
     // lane 0's own inputs are requested before the partial sums so that the two round trips overlap
     const double* sc = L ? L->scal0 : P.scal;
@@ -1317,61 +1308,95 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
       });
       static_for<0, NS>([&](auto l_) { vs[decltype(l_)::value] = sc[St::O_VS + decltype(l_)::value]; });
     }
-    static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] = 0.0; });
-    const double* part = L ? L->partials0 : P.partials;
+    static_for<0, 4>([&](auto g_) { static_for<0, NRED>([&](auto r_) { acc[decltype(g_)::value][decltype(r_)::value] = 0.0; }); });
     const int nt = L ? L->n_tiles0 : P.n_tiles;
-    // U strides of tiles are requested before the first is added, in the same order as a plain loop would add them
-    // (a wait per stride made the tail 6 us behind a 27 us bulk kernel at 4 k tiles, 58 us at 39 k)
-    constexpr int U = NRED <= 4 ? 8 : 4;
-    // (BIG: the build of the tail kernel the host picks for many tiles, pc_tail_big; the plain loop stays the code of
-    //  pc_tail, whose few strides leave nothing to overlap)
-    if constexpr (!BIG) {
-      for (int b = tid; b < nt; b += TB)
-        static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += part[(int64_t)b * NRED + decltype(r_)::value]; });
-    } else
-    for (int b0 = tid; b0 < nt; b0 += U * TB) {
-      double tmp[U][NRED];
-      static_for<0, U>([&](auto u_) {
-        constexpr int u = decltype(u_)::value;
-        const int b = b0 + u * TB;
-        static_for<0, NRED>([&](auto r_) {
-          constexpr int r = decltype(r_)::value;
-          tmp[u][r] = b < nt ? part[(int64_t)b * NRED + r] : 0.0;
+    if constexpr (RES) {
+      // the tiles publish their sums as granules while this workgroup runs: one stride of 256 tiles at a time, every
+      // wave re-reading its granules of the stride until all carry this launch's tag
+      const unsigned long long* gr = P.gran;
+      unsigned spins = 0;
+      for (int b0 = 0; b0 < nt; b0 += 256) {
+        static_for<0, 4>([&](auto g_) {
+          constexpr int g = decltype(g_)::value;
+          if (g >= NG) return;
+          const int b = b0 + tid + TB * g;
+          const bool valid = b < nt;
+          double val[NRED];
+          for (;;) {
+            bool ok = true;
+            if (valid) {
+              unsigned long long raw[2 * NRED];
+              static_for<0, 2 * NRED>([&](auto i_) { raw[decltype(i_)::value] = load_granule(gr + 2 * (int64_t)b * NRED + decltype(i_)::value); });
+              static_for<0, NRED>([&](auto r_) {
+                constexpr int r = decltype(r_)::value;
+                ok &= join_granules(raw[2 * r], raw[2 * r + 1], A.epoch, val[r]);
+              });
+            }
+            if (__all(ok)) break;
+            if (!spin_again(spins, A, 1u + (unsigned)ip)) break;
+          }
+          if (valid) static_for<0, NRED>([&](auto r_) { acc[g][decltype(r_)::value] += val[decltype(r_)::value]; });
         });
-      });
-      static_for<0, U>([&](auto u_) {
-        constexpr int u = decltype(u_)::value;
-        if (b0 + u * TB < nt) static_for<0, NRED>([&](auto r_) { acc[decltype(r_)::value] += tmp[u][decltype(r_)::value]; });
+      }
+    } else {
+      const double* part = L ? L->partials0 : P.partials;
+      // BIG (pc_tail_big, the build the host picks for many tiles): U strides of tiles are requested before the first
+      // is added, in the same order as the plain loop adds them (a wait per stride made the tail 6 us behind a 27 us
+      // bulk kernel at 4 k tiles, 58 us at 39 k); the plain loop stays the code of pc_tail, whose few strides leave
+      // nothing to overlap
+      constexpr int U = BIG ? (NRED <= 4 ? 8 : 4) : 1;
+      static_for<0, 4>([&](auto g_) {
+        constexpr int g = decltype(g_)::value;
+        if (g >= NG) return;
+        for (int b0 = tid + TB * g; b0 < nt; b0 += U * 256) {
+          double tmp[U][NRED];
+          static_for<0, U>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const int b = b0 + u * 256;
+            static_for<0, NRED>([&](auto r_) {
+              constexpr int r = decltype(r_)::value;
+              tmp[u][r] = b < nt ? part[(int64_t)b * NRED + r] : 0.0;
+            });
+          });
+          static_for<0, U>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            if (b0 + u * 256 < nt) static_for<0, NRED>([&](auto r_) { acc[g][decltype(r_)::value] += tmp[u][decltype(r_)::value]; });
+          });
+        }
       });
     }
   }
 }
 template <class M>
-__device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R) {
+__device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, TailPhaseRegs<M>& R, const TailLds& L) {
   using St = S<M>;
   constexpr int NZ = St::NZ, NQ = St::NQ, NP = St::NP, NY = St::NY, NS = St::NS, NT = St::NT, NRED = St::NRED;
   if constexpr (NRED > 0) {
-    __shared__ double s_part[NRED * 16];
-    __shared__ double s_sum[NRED];
+    double* s_part = L.part;
+    double* s_sum = L.sum;
     const PcTailPhase& P = A.ph[ip];
-    const int tid = threadIdx.x, TB = A.block_threads;
+    const int tid = threadIdx.x, TB = A.block_threads, NG = 256 / TB;
     double (&xt)[2] = R.xt, (&vt)[2] = R.vt, (&rt)[2] = R.rt;
     auto& xq = R.xq; auto& wi = R.wi; auto& vq = R.vq; auto& rq = R.rq; auto& vs = R.vs; auto& acc = R.acc;
-    static_for<0, NRED>([&](auto r_) {
-      constexpr int r = decltype(r_)::value;
-      const double w = wave_sum(acc[r]);
-      if ((tid & 63) == 0) s_part[r * 16 + (tid >> 6)] = w;
+    lds_barrier();   // the previous phase's totals have been consumed
+    static_for<0, 4>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      if (g >= NG) return;
+      static_for<0, NRED>([&](auto r_) {
+        constexpr int r = decltype(r_)::value;
+        const double w = wave_sum(acc[g][r]);
+        if ((tid & 63) == 0) s_part[r * 16 + (tid >> 6) + (TB >> 6) * g] = w;   // virtual wave of (lane, g)
+      });
     });
     lds_barrier();
     if (tid == 0) {
-      const int nw = (TB + 63) >> 6;
       static_for<0, NRED>([&](auto r_) {
         constexpr int r = decltype(r_)::value;
         double tot = s_part[r * 16];
-        for (int w = 1; w < nw; ++w) tot += s_part[r * 16 + w];
+        for (int w = 1; w < 4; ++w) tot += s_part[r * 16 + w];
         s_sum[r] = tot;
       });
-      double* hacc = tail_acc();
+      double* hacc = L.acc;
       double t0 = P.t_fixed[0], tF = P.t_fixed[1], dst[2] = {0.0, 0.0};
       int j = 0;
       if constexpr (M::T0_FREE) {
@@ -1423,94 +1448,54 @@ __device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, T
     }
   }
 }
-template <class M, bool BIG = false>
-__device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip) {
+template <class M, bool RES = false, bool BIG = false>
+__device__ __forceinline__ void tail_phase(const PcTailArgs& A, int ip, const TailLds& L) {
   TailPhaseRegs<M> R;
-  tail_phase_issue<M, BIG>(A, ip, R);
-  tail_phase_finish<M>(A, ip, R);
+  tail_phase_issue<M, RES, BIG>(A, ip, R);
+  tail_phase_finish<M>(A, ip, R, L);
 }
 
-// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  One lane evaluates the
-// block, but its inputs -- the point variables scattered over x~, the endpoint multipliers, the edge-node Hessian
-// entries the endpoint terms are added to -- are fetched by as many lanes as there are values, all at once, into
-// LDS (tail_point_load, ahead of the phases' sums).  Fetched by the evaluating lane alone they were scalar loads
-// issued a register-file-full at a time: ~9 us of an 11 us tail for Delta III's 56 point variables.
-// A small block (few inputs) keeps the earlier form: lane 0 fetches its inputs with scalar loads into registers
-// and evaluates every part itself -- the LDS round trip of the wide form costs such a block ~0.4 us.
-template <class PT>
-struct PointIn {
-  static constexpr bool SMALL = (PT::NPV + PT::NB + PT::NPH) <= 16;
-  double* xb;   // [NPV] unscaled point variables
-  double* lb;   // [NB] scaled endpoint multipliers
-  double* hold; // [NPH] current value of the H entry an endpoint term lands on (edge-node entries only)
-  double rxb[PT::NPV > 0 ? PT::NPV : 1], rlb[PT::NB > 0 ? PT::NB : 1], rhold[PT::NPH > 0 ? PT::NPH : 1];   // SMALL
-};
-template <class PT, bool SERIAL = false>
-__device__ __forceinline__ void tail_point_load(const PcTailArgs& A, PointIn<PT>& I) {
+// Endpoint functions: objective, endpoint constraint rows, their Jacobian and Hessian.  The inputs -- the point
+// variables scattered over x~, the endpoint multipliers, (separate launch) the edge-node Hessian entries the endpoint
+// terms are added to -- are fetched by as many lanes as there are values, all at once, into LDS (fetched by the
+// evaluating lane alone they were scalar loads issued a register-file-full at a time: ~9 us of an 11 us tail for
+// Delta III's 56 point variables).  The block is generated in PT::NPARTS parts of similar cost (codegen.py); lane 0
+// of wave w evaluates the parts g with g % waves == w and stores their rows of c~ and G~; the Hessian terms go to LDS
+// and are applied by all lanes once the phases' sums are in (tail_point_apply).
+template <class PT, bool RES = false>
+__device__ __forceinline__ void tail_point_load(const PcTailArgs& A, const TailLds& L) {
   constexpr int NPV = PT::NPV, NB = PT::NB, NPH = PT::NPH;
   const bool wantH = A.flags & PC_FLAG_H;
-  if constexpr (PointIn<PT>::SMALL) {
-    I.xb = I.rxb;
-    I.lb = I.rlb;
-    I.hold = I.rhold;
-    if (threadIdx.x != 0) return;
-    static_for<0, NPV>([&](auto i_) {
-      constexpr int i = decltype(i_)::value;
-      I.rxb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
-    });
-    static_for<0, NB>([&](auto r_) {
-      constexpr int r = decltype(r_)::value;
-      I.rlb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
-    });
+  const int tid = threadIdx.x, TB = A.block_threads;
+  for (int i = tid; i < NPV; i += TB) L.xb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
+  for (int r = tid; r < NB; r += TB) L.lb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
+  if constexpr (!RES) {   // (resident build: those entries arrive as granules, see tail_point_apply)
     if (wantH)
-      static_for<0, NPH>([&](auto e_) {
-        constexpr int e = decltype(e_)::value;
-        I.rhold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
-      });
-  } else {
-    __shared__ double s_xb[NPV > 0 ? NPV : 1];
-    __shared__ double s_lb[NB > 0 ? NB : 1];
-    __shared__ double s_hold[NPH > 0 ? NPH : 1];
-    I.xb = s_xb;
-    I.lb = s_lb;
-    I.hold = s_hold;
-    // SERIAL (the fused bulk kernel): the loads stay on one lane.  With the lane-parallel form compiled into that
-    // kernel, unrelated Hessian entries of the double-pendulum model came out wrong (cause not found; the fused build
-    // is an experiment and keeps the form it was validated with).
-    const int tid = SERIAL ? (threadIdx.x == 0 ? 0 : (1 << 20)) : (int)threadIdx.x, TB = SERIAL ? 1 : A.block_threads;
-    for (int i = tid; i < NPV; i += TB) s_xb[i] = A.pt_V[i] * A.x[A.pt_x[i]] + A.pt_r[i];
-    for (int r = tid; r < NB; r += TB) s_lb[r] = wantH ? A.lam[A.c_end_off + r] * A.pt_W[r] : 0.0;
-    if (wantH)
-      for (int e = tid; e < NPH; e += TB) s_hold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
-    // (the workgroup barrier of tail_begin, which follows, publishes the three arrays)
+      for (int e = tid; e < NPH; e += TB) L.hold[e] = A.pt_hlocal[e] < 0 ? A.H[A.pt_hslot[e]] : 0.0;
   }
+  // (the workgroup barrier of tail_begin, which follows, publishes the arrays)
 }
-// The block is generated in PT::NPARTS parts of similar cost (codegen.py); lane 0 of wave w evaluates the parts
-// g with g % waves == w and stores what they produce, so a 256-thread tail runs four parts side by side.
 template <class PT>
-__device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT>& I) {
+__device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailLds& L) {
   constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
-  constexpr bool SMALL = PointIn<PT>::SMALL;
-  // the phases' sums (lane 0 of wave 0) must be in the LDS accumulator before another wave adds to it
-  if constexpr (!SMALL) lds_barrier();
-  const int tid = threadIdx.x, wave = tid >> 6, nw = SMALL ? 1 : (A.block_threads + 63) >> 6;
-  if ((tid & 63) != 0 || (SMALL && tid != 0)) return;
+  const int tid = threadIdx.x, wave = tid >> 6, nw = (A.block_threads + 63) >> 6;
+  if ((tid & 63) != 0) return;
   const double sigma = A.sigma, wJ = A.wJ;
   const bool wantH = A.flags & PC_FLAG_H;
   static_for<0, PT::NPARTS>([&](auto g_) {
     constexpr int g = decltype(g_)::value;
     if (g % nw != wave) return;
     double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
-    static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = I.xb[decltype(i_)::value]; });
-    static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = I.lb[decltype(r_)::value]; });
+    static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = L.xb[decltype(i_)::value]; });
+    static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = L.lb[decltype(r_)::value]; });
     double Jval = 0.0, gJ[NGJ > 0 ? NGJ : 1], b[NB > 0 ? NB : 1], jb[NBJ > 0 ? NBJ : 1], hb[NPH > 0 ? NPH : 1];
     PT::template eval_part<g>(xb, sigma * wJ, lb, Jval, gJ, b, jb, hb);
     if constexpr (g == 0) {
       if (A.fobj) A.fobj[0] = wJ * Jval;
-      if (A.grad) {
+      if (A.grad_nz) {
         static_for<0, NGJ>([&](auto e_) {
           constexpr int e = decltype(e_)::value;
-          A.grad[A.pt_x[PT::gc(e)]] = wJ * gJ[e] * A.pt_V[PT::gc(e)];
+          A.grad_nz[e] = wJ * gJ[e] * A.pt_V[PT::gc(e)];
         });
       }
     }
@@ -1524,19 +1509,48 @@ __device__ __forceinline__ void tail_point(const PcTailArgs& A, const PointIn<PT
         constexpr int e = decltype(e_)::value;
         if constexpr (PT::part_jb(e) == g) A.G[A.g_end_base + e] = A.pt_W[PT::br(e)] * jb[e] * A.pt_V[PT::bc(e)];
       });
-    if (wantH) {
-      double* hacc = tail_acc();
+    if (wantH)
       static_for<0, NPH>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
-        if constexpr (PT::part_hb(e) == g) {
-          const double val = hb[e] * A.pt_V[PT::phr(e)] * A.pt_V[PT::phc(e)];
-          const int hl = A.pt_hlocal[e];
-          if (hl >= 0) hacc[hl] += val;
-          else A.H[A.pt_hslot[e]] = I.hold[e] + val;   // an edge-node entry the bulk kernels wrote, plus the endpoint term
-        }
+        if constexpr (PT::part_hb(e) == g) L.hb[e] = hb[e] * A.pt_V[PT::phr(e)] * A.pt_V[PT::phc(e)];
       });
-    }
   });
+}
+// every endpoint Hessian term meets its slot: a tail-owned slot in LDS (each slot receives one term, after the
+// phases' sums), or an edge-node entry the bulk produced -- read back from H (separate launch) or received as
+// granules from the edge tile (resident build) -- plus the term
+template <class PT, bool RES = false>
+__device__ __forceinline__ void tail_point_apply(const PcTailArgs& A, const TailLds& L) {
+  constexpr int NPH = PT::NPH;
+  if constexpr (NPH > 0) {
+    lds_barrier();   // the terms (lane 0 of every wave) and the phases' sums (lane 0 of wave 0) are in LDS
+    if (!(A.flags & PC_FLAG_H)) return;
+    const int tid = threadIdx.x, TB = A.block_threads;
+    unsigned spins = 0;
+    for (int e0 = 0; e0 < NPH; e0 += TB) {
+      const int e = e0 + tid;
+      const bool valid = e < NPH;
+      const int hl = valid ? A.pt_hlocal[e] : 0;
+      if (valid && hl >= 0) L.acc[hl] += L.hb[e];
+      if constexpr (RES) {
+        const bool edge = valid && hl < 0;
+        double cur = 0.0;
+        for (;;) {
+          bool ok = true;
+          if (edge) {
+            const unsigned long long* g = A.erec + 2 * A.pt_rec[e];
+            const unsigned long long lo = load_granule(g), hi = load_granule(g + 1);
+            ok = join_granules(lo, hi, A.epoch, cur);
+          }
+          if (__all(ok)) break;
+          if (!spin_again(spins, A, 100u)) break;
+        }
+        if (edge) A.H[A.pt_hslot[e]] = cur + L.hb[e];
+      } else {
+        if (valid && hl < 0) A.H[A.pt_hslot[e]] = L.hold[e] + L.hb[e];
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

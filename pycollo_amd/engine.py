@@ -99,6 +99,8 @@ def load_library() -> C.CDLL:
     lib.pc_eval_jac_g.argtypes = [vp, vp, C.c_int, vp]
     lib.pc_eval_h.argtypes = [vp, vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.pc_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.pc_host_buffers.argtypes = [vp] + [C.POINTER(vp)] * 5
+    lib.pc_set_host_mode.argtypes = [vp, C.c_int]
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.pc_launch_bulk_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pc_launch_tail_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -300,16 +302,16 @@ class NlpEngine:
             raise ValueError(f"x must have {self.num_x} entries")
         return x
 
-    def evaluate_J(self, x):
+    def evaluate_J(self, x, new_x=True):
         x = self._x(x)
         out = C.c_double()
-        self._check(self._lib.pc_eval_f(self._h, x.ctypes.data, 1, C.addressof(out)))
+        self._check(self._lib.pc_eval_f(self._h, x.ctypes.data, int(new_x), C.addressof(out)))
         return out.value
 
-    def evaluate_g(self, x):
+    def evaluate_g(self, x, new_x=True):
         x = self._x(x)
         g = np.empty(self.num_x)
-        self._check(self._lib.pc_eval_grad_f(self._h, x.ctypes.data, 1, g.ctypes.data))
+        self._check(self._lib.pc_eval_grad_f(self._h, x.ctypes.data, int(new_x), g.ctypes.data))
         return g
 
     def evaluate_c(self, x, new_x=True):
@@ -351,6 +353,32 @@ class NlpEngine:
         self._check(self._lib.pc_eval_all(self._h, x.ctypes.data, float(obj_factor), lam.ctypes.data, c.ctypes.data,
                                           g.ctypes.data, h.ctypes.data))
         return c, g, h
+
+    # ---- zero-copy host hand-over ---------------------------------------------------------------
+    def host_buffers(self):
+        """NumPy views ``(x, lam, c, G, H)`` of the library's pinned staging blocks (``pc_host_buffers``).  Write x~ /
+        lambda into the first two, call :meth:`evaluate_all_inplace`, read the results from the last three: no host
+        memcpy on either side.  The views stay valid for the life of the engine; their contents until the next
+        evaluation."""
+        if getattr(self, "_host_views", None) is None:
+            ptrs = [C.c_void_p() for _ in range(5)]
+            self._check(self._lib.pc_host_buffers(self._h, *[C.byref(p) for p in ptrs]))
+            sizes = (self.num_x, self.num_c, self.num_c, self.nnz_jac, self.nnz_hess)
+            self._host_views = tuple(
+                np.ctypeslib.as_array(C.cast(p, _f64p), shape=(max(n, 1),))[:n] for p, n in zip(ptrs, sizes))
+        return self._host_views
+
+    def evaluate_all_inplace(self, obj_factor=1.0):
+        """Fused c, G, H at the (x~, lambda) already written into :meth:`host_buffers`; results are read there."""
+        x, lam, c, g, h = self.host_buffers()
+        self._check(self._lib.pc_eval_all(self._h, x.ctypes.data, float(obj_factor), lam.ctypes.data, c.ctypes.data,
+                                          g.ctypes.data, h.ctypes.data))
+        return c, g, h
+
+    def set_host_mode(self, mode: int):
+        """0: one DMA copy up / down; 1: kernels read x~, lambda from pinned host memory; 2: kernels write c~, G~, H~
+        to pinned host memory; 3: both (``pc_set_host_mode``)."""
+        self._check(self._lib.pc_set_host_mode(self._h, int(mode)))
 
     def G_row_norms(self, x):
         x = self._x(x)
@@ -436,25 +464,36 @@ class PycolloGpuProblem:
         self.engine = engine
         self.n, self.m = engine.num_x, engine.num_c
         self.obj_func_eval_counter = 0  # nlp.py:45
+        self._last_x = None
+
+    def _new_x(self, x) -> bool:
+        """cyipopt does not forward IPOPT's ``new_x`` flag: it is recovered by comparing with the last point
+        (n doubles; far cheaper than an evaluation), so that objective / gradient / constraints / jacobian at one
+        point share one launch (``pc_eval_*`` with ``new_x = 0``)."""
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        if self._last_x is not None and np.array_equal(x, self._last_x):
+            return False
+        self._last_x = x.copy()
+        return True
 
     def objective(self, x):
         self.obj_func_eval_counter += 1
-        return self.engine.evaluate_J(x)
+        return self.engine.evaluate_J(x, self._new_x(x))
 
     def gradient(self, x):
-        return self.engine.evaluate_g(x)
+        return self.engine.evaluate_g(x, self._new_x(x))
 
     def constraints(self, x):
-        return self.engine.evaluate_c(x)
+        return self.engine.evaluate_c(x, self._new_x(x))
 
     def jacobian(self, x):
-        return self.engine.evaluate_G_nonzeros(x)
+        return self.engine.evaluate_G_nonzeros(x, self._new_x(x))
 
     def jacobianstructure(self):
         return self.engine.evaluate_G_structure()
 
     def hessian(self, x, lagrange, obj_factor):
-        return self.engine.evaluate_H_nonzeros(x, obj_factor, lagrange)
+        return self.engine.evaluate_H_nonzeros(x, obj_factor, lagrange, self._new_x(x))
 
     def hessianstructure(self):
         return self.engine.evaluate_H_structure()

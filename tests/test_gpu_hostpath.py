@@ -1,0 +1,113 @@
+"""GPU tests of the host-pointer callbacks (what IPOPT / cyipopt see): IPOPT's new_x protocol, the packed staging
+blocks, the zero-copy hand-over and the three data-movement modes.  Reference surface: pycollo/nlp.py:47-63
+(objective / gradient / constraints / jacobian / hessian on host numpy arrays), IpStdCInterface.h's new_x flag."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle.ref_numpy import OracleNlp
+from pycollo_amd import problems
+from pycollo_amd.quadrature import QuadratureTables
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _engine(prob, **kw):
+    from pycollo_amd.engine import NlpEngine
+    return NlpEngine(prob, device=0, **kw)
+
+
+@pytest.mark.parametrize("name,kw", [("double_pendulum", {}), ("hypersensitive", dict(K=300, order=6))])
+def test_new_x_protocol(built, name, kw):
+    """The first callback at a new point carries new_x = 1 -- usually eval_f or eval_grad_f -- and the companion calls
+    carry 0: g / jac_g must then be those of the new point, never a cached c~/G~ of the previous one."""
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    rng = np.random.default_rng(5)
+    x0, x1, x2, x3 = (rng.uniform(-0.4, 0.4, eng.num_x) for _ in range(4))
+    lam = rng.normal(size=eng.num_c)
+    c0 = eng.evaluate_c(x0)                        # caches c~, G~ at x0
+    assert rel_err(c0, ora.c(x0)) < TOL
+    J1 = eng.evaluate_J(x1, new_x=True)            # new point announced to eval_f
+    assert abs(J1 - ora.J(x1)) <= TOL * max(1.0, abs(J1))
+    assert rel_err(eng.evaluate_c(x1, new_x=False), ora.c(x1)) < TOL
+    assert rel_err(eng.evaluate_G_nonzeros(x1, new_x=False), ora.G(x1)) < TOL
+    assert rel_err(eng.evaluate_g(x1, new_x=False), ora.grad_J(x1)) < TOL
+    g2 = eng.evaluate_g(x2, new_x=True)            # ... to eval_grad_f
+    assert rel_err(g2, ora.grad_J(x2)) < TOL
+    assert rel_err(eng.evaluate_G_nonzeros(x2, new_x=False), ora.G(x2)) < TOL
+    assert rel_err(eng.evaluate_c(x2, new_x=False), ora.c(x2)) < TOL
+    H3 = eng.evaluate_H_nonzeros(x3, 0.7, lam, new_x=True)   # ... to eval_h
+    assert rel_err(H3, ora.H(x3, 0.7, lam)) < TOL
+    assert rel_err(eng.evaluate_c(x3, new_x=False), ora.c(x3)) < TOL
+    assert abs(eng.evaluate_J(x3, new_x=False) - ora.J(x3)) <= TOL * max(1.0, abs(ora.J(x3)))
+    # a change of scaling invalidates the cache even if the caller says the point is old
+    W = eng.W_ocp * 2.0
+    eng.set_scaling(eng.V_ocp, eng.r_ocp, W, 1.0)
+    assert rel_err(eng.evaluate_c(x3, new_x=False), 2.0 * ora.c(x3)) < TOL
+    eng.close()
+
+
+def test_cyipopt_object_recovers_new_x(built):
+    """PycolloGpuProblem (nlp.py:36-76 method names): cyipopt passes no new_x, the object compares points."""
+    from pycollo_amd.engine import PycolloGpuProblem
+    prob = problems.cart_pole(K=60, order=4)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    p = PycolloGpuProblem(eng)
+    rng = np.random.default_rng(9)
+    lam = rng.normal(size=eng.num_c)
+    for _ in range(3):
+        x = rng.uniform(-0.4, 0.4, eng.num_x)
+        assert abs(p.objective(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+        assert rel_err(p.gradient(x), ora.grad_J(x)) < TOL
+        assert rel_err(p.constraints(x), ora.c(x)) < TOL
+        assert rel_err(p.jacobian(x), ora.G(x)) < TOL
+        assert rel_err(p.hessian(x, lam, 0.5), ora.H(x, 0.5, lam)) < TOL
+    eng.close()
+
+
+@pytest.mark.parametrize("name,kw", [("hypersensitive", dict(K=2000, order=6)), ("delta_iii", dict(K=40, order=4)),
+                                     ("double_pendulum", {})])
+def test_host_modes_and_inplace_views_write_the_same_bits(built, name, kw):
+    """DMA copies (mode 0), kernels reading / writing pinned host memory (modes 1-3) and the in-place views of the
+    pinned blocks all return exactly what the copying call returns."""
+    prob = problems.REGISTRY[name](**kw)
+    eng = _engine(prob)
+    rng = np.random.default_rng(2)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+    x = rng.uniform(lo, hi, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    ref = eng.evaluate_all(x, 0.8, lam)
+    refJ, refg = eng.evaluate_J(x), eng.evaluate_g(x)
+    hx, hl, hc, hG, hH = eng.host_buffers()
+    for mode in (0, 1, 2, 3):
+        eng.set_host_mode(mode)
+        got = eng.evaluate_all(x, 0.8, lam)
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+        hx[:] = x
+        hl[:] = lam
+        hc[:] = np.nan
+        hG[:] = np.nan
+        hH[:] = np.nan
+        c, G, H = eng.evaluate_all_inplace(0.8)
+        assert c.ctypes.data == hc.ctypes.data
+        for a, b in zip(ref, (c, G, H)):
+            np.testing.assert_array_equal(a, b)
+        # the separate callbacks in this mode
+        assert eng.evaluate_J(x) == refJ
+        np.testing.assert_array_equal(eng.evaluate_g(x, new_x=False), refg)
+        np.testing.assert_array_equal(eng.evaluate_c(x, new_x=False), ref[0])
+        np.testing.assert_array_equal(eng.evaluate_G_nonzeros(x, new_x=False), ref[1])
+        np.testing.assert_array_equal(eng.evaluate_H_nonzeros(x, 0.8, lam, new_x=False), ref[2])
+    eng.set_host_mode(0)
+    assert rel_err(eng.G_row_norms(x), np.sqrt(np.add.reduceat(ref[1] ** 2, _indptr(eng)[:-1]))) < 1e-13
+    eng.close()
+
+
+def _indptr(eng):
+    r, _ = eng.evaluate_G_structure()
+    return np.concatenate([[0], np.cumsum(np.bincount(r, minlength=eng.num_c))])

@@ -263,23 +263,50 @@ def test_device_resident_api_matches_host_api(built):
 
 
 # ---- BASELINE.json full sizes: size-independent properties --------------------------------------
+def _ph_refined(prob, K, seed=7, lo=4, hi=9):
+    """A mesh as ph refinement leaves it (pycollo/mesh_refinement.py:250-392): section widths and orders differ from
+    section to section (widths U(0.5, 1.5) before normalisation, lo..hi-1 nodes)."""
+    rr = np.random.default_rng(seed)
+    for ph in prob.phases:
+        ph.mesh.mesh_section_sizes = rr.uniform(0.5, 1.5, K)
+        ph.mesh.number_mesh_section_nodes = rr.integers(lo, hi, K)
+    return prob
+
+
+def _full_problem(name, kw):
+    kw = dict(kw)
+    refined = kw.pop("refined", False)
+    prob = problems.REGISTRY[name](**kw)
+    return _ph_refined(prob, kw["K"]) if refined else prob
+
+
+# configs[1..4] of BASELINE.json at full size; config 5 (Delta III, 4 phases, ~50 k nodes) twice: a uniform
+# 4 x 3125 x 5 mesh (4 x 12 501 nodes, the merged multi-phase launch at 800+ tiles) and a ph-refined mesh
+# (4 x 2500 sections of 4..8 nodes, ~50 k nodes: the any-order kernels)
 FULL = [("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=5000, order=4)),
-        ("shuttle", dict(K=20000, order=4))]
+        ("shuttle", dict(K=20000, order=4)), ("delta_iii", dict(K=3125, order=5)),
+        ("delta_iii", dict(K=2500, order=4, refined=True))]
 
 
 @pytest.mark.parametrize("name,kw", FULL)
 def test_full_size_properties(built, tab, name, kw):
-    """configs[1..3] at full size: (1) parity with the vectorised oracle (it still finishes in seconds),
+    """BASELINE.json's configs at full size: (1) parity with the vectorised oracle (it still finishes in seconds),
     (2) run-to-run bit reproducibility, (3) linearity of H in (sigma, lambda), (4) G^T lambda contraction
     equals the directional derivative of lambda.c (checksum of the whole Jacobian against c alone)."""
-    prob = problems.REGISTRY[name](**kw)
+    prob = _full_problem(name, kw)
     eng = _engine(prob)
+    if name == "delta_iii":
+        assert sum(pl.N for pl in eng.layout.phases) > 49000
     ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
     rng = np.random.default_rng(1234)
-    x = rng.uniform(-0.45, 0.45, eng.num_x)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)   # keep |r| away from 0 for mu/r^3
+    x = rng.uniform(lo, hi, eng.num_x)
     lam = np.random.default_rng(1235).normal(size=eng.num_c)
     c, G, H = eng.evaluate_all(x, 1.0, lam)
     assert rel_err(c, ora.c(x)) < TOL and rel_err(G, ora.G(x)) < TOL and rel_err(H, ora.H(x, 1.0, lam)) < TOL
+    for got, ref in ((eng.evaluate_G_structure(), ora.G_structure()), (eng.evaluate_H_structure(), ora.H_structure())):
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
     c2, G2, H2 = eng.evaluate_all(x, 1.0, lam)
     assert np.array_equal(c, c2) and np.array_equal(G, G2) and np.array_equal(H, H2)
     # linearity: H(2 sigma, 2 lam) = 2 H(sigma, lam);  H(s1+s2, l1+l2) = H(s1,l1) + H(s2,l2)
@@ -301,14 +328,17 @@ def test_full_size_properties(built, tab, name, kw):
 
 @pytest.mark.parametrize("name,kw,world", [("two_phase_transfer", dict(K=40, order=4), 3),
                                            ("hypersensitive", dict(K=2000, order=6), 8),
-                                           ("delta_iii", dict(K=40, order=4), 2)])
+                                           ("delta_iii", dict(K=40, order=4), 2),
+                                           ("shuttle", dict(K=20000, order=4), 8),              # config 4 as BASELINE shards it
+                                           ("delta_iii", dict(K=3125, order=5), 8),             # config 5, uniform mesh
+                                           ("delta_iii", dict(K=2500, order=4, refined=True), 8)])   # config 5, ph-refined
 def test_sharded_ranks_reassemble_bitwise(built, name, kw, world):
     """Emulate `world` ranks on one GPU: each rank's bulk kernels run over its tile range into a NaN-filled
     buffer, the plan's segments are merged (what the all-gather + unpack do), the tail runs on the merged
     buffer -- the result must equal the unsharded evaluation bit for bit."""
     import torch
     from pycollo_amd.sharding import ShardPlan
-    prob = problems.REGISTRY[name](**kw)
+    prob = _full_problem(name, kw)
     eng = _engine(prob)
     rng = np.random.default_rng(4)
     lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
@@ -410,3 +440,35 @@ def test_sharded_world1_nccl(built):
         assert np.array_equal(dc.cpu().numpy(), c) and np.array_equal(dG.cpu().numpy(), G) and np.array_equal(dH.cpu().numpy(), H)
     finally:
         dist.destroy_process_group()
+
+
+RES_CASES = [("hypersensitive", dict(K=2000, order=6), 0), ("hypersensitive", dict(K=700, order=6), 256),
+             ("double_pendulum", {}, 0), ("delta_iii", dict(K=40, order=4), 0), ("delta_iii", dict(K=9, order=4), 128),
+             ("two_phase_transfer", {}, 0), ("space_station", dict(K=12, order=4), 0), ("shuttle", dict(K=60, order=5), 0),
+             ("tumour_anti_angiogenesis", dict(K=21, order=6), 64), ("sliding_mass", dict(num_phases=3, K=7, order=4), 0)]
+
+
+@pytest.mark.parametrize("name,kw,tpb", RES_CASES)
+def test_resident_tail_writes_the_same_bits_as_two_launches(built, monkeypatch, name, kw, tpb):
+    """One launch per evaluation (the tail as block 0 of the bulk launch, fed by granules: pc_kernels.hpp RES) against
+    bulk launch + pc_tail (PYCOLLO_AMD_RESIDENT=0): identical bits for c~, G~, H~, J, grad J on every flag
+    combination the callbacks use, repeatedly (the granule tags change from launch to launch)."""
+    prob = problems.REGISTRY[name](**kw)
+    lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+    outs = {}
+    for res in (1, 0):
+        monkeypatch.setenv("PYCOLLO_AMD_RESIDENT", str(res))
+        eng = _engine(prob, threads_per_block=tpb)
+        assert eng.info["n_launches"] == (1 if res else 2)
+        rng = np.random.default_rng(17)
+        got = []
+        for rep in range(3):
+            x = rng.uniform(lo, hi, eng.num_x)
+            lam = rng.normal(size=eng.num_c)
+            got += list(eng.evaluate_all(x, 0.6, lam))
+            got += [eng.evaluate_c(x), eng.evaluate_G_nonzeros(x, new_x=False), np.array([eng.evaluate_J(x, new_x=False)]),
+                    eng.evaluate_g(x, new_x=False), eng.evaluate_H_nonzeros(x, 0.3, lam, new_x=False)]
+        outs[res] = got
+        eng.close()
+    for a, b in zip(outs[1], outs[0]):
+        np.testing.assert_array_equal(a, b)

@@ -7,9 +7,10 @@ export TMPDIR=/tmp
 R=$PWD; TAG=${1:-r01}; OUT=$R/gpurun_out/profiles_$TAG; mkdir -p $OUT; cd /tmp
 run() {  # name, bench args...
   local name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/stats -- python3 $R/bench.py --no-cpu "$@" > $OUT/$name.stats.log 2>&1 || { echo "$name stats failed"; return 1; }
+  python3 $R/bench.py --build-only "$@" > /dev/null || { echo "$name build failed"; return 1; }   # never under the profiler
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name/stats -- python3 $R/bench.py --no-cpu --no-host "$@" > $OUT/$name.stats.log 2>&1 || { echo "$name stats failed"; return 1; }
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$name/$c -- python3 $R/bench.py --no-cpu "$@" > $OUT/$name.$c.log 2>&1 || { echo "$name $c failed"; return 1; }
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$name/$c -- python3 $R/bench.py --no-cpu --no-host "$@" > $OUT/$name.$c.log 2>&1 || { echo "$name $c failed"; return 1; }
   done
   echo "$name done: $(tail -1 $OUT/$name.stats.log | cut -c1-160)"
 }

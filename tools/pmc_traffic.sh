@@ -2,8 +2,10 @@
 # usage: tools/pmc_traffic.sh <outdir> <bench args...>  -- FETCH_SIZE and WRITE_SIZE per bulk launch (two passes)
 export TMPDIR=/tmp
 R=$PWD; OUT=$R/$1; shift; mkdir -p $OUT; cd /tmp
+# the code object is built in a plain process first: no compiler may be spawned under the profiler preload
+python3 $R/bench.py --build-only "$@" > /dev/null || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu "$@" > $OUT/$c.log 2>&1 || { tail -3 $OUT/$c.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu --no-host "$@" > $OUT/$c.log 2>&1 || { tail -3 $OUT/$c.log; exit 1; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

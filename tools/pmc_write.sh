@@ -2,7 +2,9 @@
 # usage: tools/pmc_write.sh <outdir> <bench args...>   -- WRITE_SIZE per dispatch of the bulk kernels
 export TMPDIR=/tmp
 R=$PWD; OUT=$R/$1; shift; mkdir -p $OUT; cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu "$@" > $OUT/log.txt 2>&1 || { tail -3 $OUT/log.txt; exit 1; }
+# the code object is built in a plain process first: no compiler may be spawned under the profiler preload
+python3 $R/bench.py --build-only "$@" > /dev/null || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -- python3 $R/bench.py --no-cpu --no-host "$@" > $OUT/log.txt 2>&1 || { tail -3 $OUT/log.txt; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
