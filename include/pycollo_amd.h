@@ -129,6 +129,31 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
 /* fused g + jac_g + hess at one (x, sigma, lambda): the benchmarked call (host pointers) */
 int pc_eval_all(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* g,
                 double* jac, double* hess);
+/* ---- IPOPT's C callback set, with IPOPT's own signatures ----------------------------------------------
+ * IpStdCInterface.h (third-party, coin-or/Ipopt; not part of the reference tree) declares
+ *   typedef double Number; typedef int Index; typedef int Bool; typedef void* UserDataPtr;
+ *   Bool (*Eval_F_CB)     (Index n, Number* x, Bool new_x, Number* obj_value, UserDataPtr user_data);
+ *   Bool (*Eval_Grad_F_CB)(Index n, Number* x, Bool new_x, Number* grad_f, UserDataPtr user_data);
+ *   Bool (*Eval_G_CB)     (Index n, Number* x, Bool new_x, Index m, Number* g, UserDataPtr user_data);
+ *   Bool (*Eval_Jac_G_CB) (Index n, Number* x, Bool new_x, Index m, Index nele_jac, Index* iRow, Index* jCol,
+ *                          Number* values, UserDataPtr user_data);
+ *   Bool (*Eval_H_CB)     (Index n, Number* x, Bool new_x, Number obj_factor, Index m, Number* lambda,
+ *                          Bool new_lambda, Index nele_hess, Index* iRow, Index* jCol, Number* values,
+ *                          UserDataPtr user_data);
+ * The functions below have exactly these types and can be handed to CreateIpoptProblem(n, x_L, x_U, m, g_L, g_U,
+ * nele_jac, nele_hess, 0 (C-style indices), &pc_ipopt_eval_f, &pc_ipopt_eval_g, &pc_ipopt_eval_grad_f,
+ * &pc_ipopt_eval_jac_g, &pc_ipopt_eval_h) with user_data = the pc_handle*.  values == NULL asks for the structure
+ * (iRow / jCol, CSR order), as IPOPT does once before the first evaluation; a size that does not match the
+ * handle's returns 0.  They replace what cyipopt builds around IPOPTProblem's methods
+ * (pycollo/nlp.py:84-115: ipopt.problem(n, m, problem_obj, lb, ub, cl, cu)). */
+int pc_ipopt_eval_f(int n, double* x, int new_x, double* obj_value, void* user_data);
+int pc_ipopt_eval_grad_f(int n, double* x, int new_x, double* grad_f, void* user_data);
+int pc_ipopt_eval_g(int n, double* x, int new_x, int m, double* g, void* user_data);
+int pc_ipopt_eval_jac_g(int n, double* x, int new_x, int m, int nele_jac, int* iRow, int* jCol, double* values,
+                        void* user_data);
+int pc_ipopt_eval_h(int n, double* x, int new_x, double obj_factor, int m, double* lambda, int new_lambda,
+                    int nele_hess, int* iRow, int* jCol, double* values, void* user_data);
+
 /* The pinned staging blocks the host-pointer calls copy through.  A caller that writes x / lambda there and passes
  * these same pointers to pc_eval_* (inputs and/or outputs) skips the corresponding host-side memcpy: the results are
  * then read in place and stay valid until the next evaluation on the handle.  (The reference hands fresh numpy

@@ -1211,6 +1211,52 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
   });
 }
 
+// ---- IPOPT's callback types (include/pycollo_amd.h) ------------------------------------------------------
+static bool ipopt_sizes_ok(pc_handle* h, int n, int m, int64_t nele, int which) {
+  if (!h) { set_err("null user_data"); return false; }
+  const auto& Q = h->Q;
+  const int64_t want = which == 1 ? (int64_t)Q.g_row.size() : (which == 2 ? (int64_t)Q.h_row.size() : -1);
+  if (n != (int)Q.num_x || (m >= 0 && m != (int)Q.num_c) || (which && nele != want)) {
+    set_err("IPOPT callback: n / m / number of non-zeros do not match the handle");
+    return false;
+  }
+  return true;
+}
+
+int pc_ipopt_eval_f(int n, double* x, int new_x, double* obj_value, void* user_data) {
+  pc_handle* h = static_cast<pc_handle*>(user_data);
+  if (!ipopt_sizes_ok(h, n, -1, 0, 0)) return 0;
+  return pc_eval_f(h, x, new_x, obj_value);
+}
+
+int pc_ipopt_eval_grad_f(int n, double* x, int new_x, double* grad_f, void* user_data) {
+  pc_handle* h = static_cast<pc_handle*>(user_data);
+  if (!ipopt_sizes_ok(h, n, -1, 0, 0)) return 0;
+  return pc_eval_grad_f(h, x, new_x, grad_f);
+}
+
+int pc_ipopt_eval_g(int n, double* x, int new_x, int m, double* g, void* user_data) {
+  pc_handle* h = static_cast<pc_handle*>(user_data);
+  if (!ipopt_sizes_ok(h, n, m, 0, 0)) return 0;
+  return pc_eval_g(h, x, new_x, g);
+}
+
+int pc_ipopt_eval_jac_g(int n, double* x, int new_x, int m, int nele_jac, int* iRow, int* jCol, double* values,
+                        void* user_data) {
+  pc_handle* h = static_cast<pc_handle*>(user_data);
+  if (!ipopt_sizes_ok(h, n, m, nele_jac, 1)) return 0;
+  if (!values) return pc_jac_structure(h, iRow, jCol);   // IPOPT's structure query (x may be NULL)
+  return pc_eval_jac_g(h, x, new_x, values);
+}
+
+int pc_ipopt_eval_h(int n, double* x, int new_x, double obj_factor, int m, double* lambda, int new_lambda,
+                    int nele_hess, int* iRow, int* jCol, double* values, void* user_data) {
+  pc_handle* h = static_cast<pc_handle*>(user_data);
+  if (!ipopt_sizes_ok(h, n, m, nele_hess, 2)) return 0;
+  if (!values) return pc_hess_structure(h, iRow, jCol);
+  return pc_eval_h(h, x, new_x, obj_factor, lambda, new_lambda, values);
+}
+
 int pc_row_norms_jac(pc_handle* h, const double* x, double* norms) {
   return guarded([&] {
     require_device(h);
