@@ -223,13 +223,16 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase and the endpoint block")
     parts.append("  // RES: block 0 of a resident-tail bulk launch (values of other workgroups arrive as granules)")
     parts.append("  template <bool RES = false, bool BIG = false>")
-    parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr) {")
+    parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr, int arg_off = 0) {")
     parts.append("    extern __shared__ double pc_tail_smem[];")
     parts.append("    const pc::TailLds L = pc::tail_lds<Point>(a, pc_tail_smem);")
     first = model.phases[0].index
     parts.append("    if constexpr (RES) {")
+    parts.append("      pc::KernargWarm warm;")
+    parts.append("      warm.issue<(int)sizeof(PcTailArgs)>(arg_off);   // every line of the tail's argument block, at once")
     parts.append("      pc::tail_point_load<Point, true>(a, L);")
     parts.append("      pc::tail_begin(a, L);")
+    parts.append("      warm.settle();")
     parts.append("      pc::tail_point_eval<Point>(a, L);   // the endpoint rows are out before the first tile's sums arrive")
     for pm in model.phases:
         parts.append(f"      pc::tail_phase<Phase{pm.index}, true>(a, {pm.index}, L);")
@@ -264,7 +267,8 @@ def generate_source(model: Model, orders=None) -> str:
         pm = model.phases[0]
         parts.append("// resident-tail build: block 0 runs the tail beside the tiles, one launch per evaluation")
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
-        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t); return; }')
+        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs)); return; }')
+        parts.append('  if ((int)threadIdx.x >= (((wa >> 12) & 0xf) << 6)) return;   // launch widened for the tail block only')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
         parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, nullptr, 0, pc::xcd_major((int)blockIdx.x - 1, n_blocks), &ld);')
         parts.append('}')
@@ -286,7 +290,8 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append("}")
         parts.append("// the same with the resident tail as block 0")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(PcMultiArgs m, PcTailArgs t) {')
-        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t); return; }')
+        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7)); return; }')
+        parts.append('  if ((int)threadIdx.x >= m.tile_threads) return;   // launch widened for the tail block only')
         parts += all_body(True)
         parts.append("}")
     parts.append("")

@@ -10,6 +10,7 @@
 #define PC_FLAG_G 2
 #define PC_FLAG_H 4
 
+#define PC_EDGE_WORDS 4     // 128 edge-node Hessian entry sites per phase and edge (more: no resident tail)
 #define PC_MAX_GOFF 32
 #define PC_MAX_HOFF 96
 #define PC_MAX_SCAL 96
@@ -37,7 +38,6 @@ struct PcPhaseArgs {
   // resident-tail build (pc_kernels.hpp, RES): values handed to the tail workgroup of the same launch as granules
   unsigned long long* gran;      // [n_tiles][NRED][2] the per-tile partial sums
   unsigned long long* erec;      // [n_rec][2] edge-node Hessian entries an endpoint term is added to (all phases)
-  const int32_t* edge_rec;       // [2][NHZZ + 2 NZ + NS NZ] record of every edge-node entry site, or -1 (plain store)
   const double* tab;      // device copy of scal | goff | hoff (packed, used entries only): staged into LDS by
                           // the kernels of models whose tables do not fit the scalar register file
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
@@ -50,6 +50,11 @@ struct PcPhaseArgs {
   int32_t spt;            // sections per tile when uniform
   int32_t lds_out;        // doubles of the output staging buffer
   uint32_t epoch;         // tag of this launch's granules (resident-tail build; pc_bulk_all takes it from PcMultiArgs)
+  // Which edge-node Hessian entries go to the tail as granules instead of being stored: one bit per entry site
+  // (sites: NHZZ z-z entries, then the t strips (j, z), then the s strips (l, z)), for node 0 and for node N-1; the
+  // record of a flagged site is edge_rec0[edge] + the number of flagged sites before it.  Uniform: lives in SGPRs.
+  uint32_t edge_mask[2][PC_EDGE_WORDS];
+  int32_t edge_rec0[2];
   int32_t wpt;            // waves (replicas) per tile: 1, 2 or 4; > 1 only with 64-node tiles
   int32_t block_threads;  // threads per workgroup of this launch (= blockDim.x, passed for the same reason as n_blocks)
   int32_t n_blocks;       // workgroups of this launch (tile_end - tile_begin): the kernel must not read gridDim,
@@ -97,6 +102,8 @@ struct PcMultiArgs {
   int32_t flags, n_phases;
   int32_t first_block[PC_MAX_PHASES + 1];
   uint32_t epoch;                         // tag of this launch's granules (resident-tail build)
+  int32_t tile_threads;                   // resident-tail build: threads of a tile's workgroup that work (the launch may be
+                                          //   wider for the tail block's sake: the others exit at once)
 };
 #define PC_MAX_POINT 96           // endpoint (point) variables: y(t0), y(tF), q, t of every phase, s
 #define PC_MAX_ENDPOINT_ROWS 32   // endpoint constraint rows

@@ -119,7 +119,8 @@ struct PhaseDev {
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
   DevBuf<int32_t> hsum_local;
   DevBuf<unsigned long long> gran;   // resident tail: the per-tile partial sums as granules, [n_tiles][nred][2]
-  DevBuf<int32_t> edge_rec;          // resident tail: record of every edge-node Hessian entry site, or -1
+  uint32_t edge_mask[2][PC_EDGE_WORDS] = {};   // resident tail: edge-node Hessian entry sites handed to the tail
+  int32_t edge_rec0[2] = {0, 0};               // first record of each edge's flagged sites
   int uni_n = 0, spt = 0, lds_out = 0;
   int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
   hipFunction_t fn = nullptr;
@@ -230,6 +231,7 @@ struct pc_handle {
   uint32_t epoch = 0;                        // tag of the last resident launch's granules (never 0)
   int spin_us = 500;                         // host-pointer calls poll the stream this long before blocking (PYCOLLO_AMD_SPIN_US)
   int tail_lds_bytes = 0, lds_nred = 0;
+  int res_tail_threads = 0;                  // a heavy endpoint block wants a 4-wave tail: the resident launch is widened to it
   PinBuf<double> h_norms;
   std::vector<double> V_ocp, r_ocp, W_ocp;
   int n_launches = 0;
@@ -331,7 +333,9 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
   a.gran = D.gran.p;
   a.erec = h->d_erec.p;
-  a.edge_rec = D.edge_rec.p;
+  std::memcpy(a.edge_mask, D.edge_mask, sizeof(a.edge_mask));
+  a.edge_rec0[0] = D.edge_rec0[0];
+  a.edge_rec0[1] = D.edge_rec0[1];
   a.tab = D.tab.p;
   a.x_off = P.x_off;
   a.s_off = Q.s_off;
@@ -412,11 +416,13 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
     for (size_t ip = Q.ph.size(); ip <= PC_MAX_PHASES; ++ip) m.first_block[ip] = nb;
     if (res) {
+      const int wide = std::max(h->TB * h->wpt_all, h->res_tail_threads);
+      m.tile_threads = h->TB * h->wpt_all;
       mr.t = h->host_tail_launch.t;
-      patch_tail(mr.t, h->TB * h->wpt_all);
+      patch_tail(mr.t, wide);
       size_t sz = sizeof(mr);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &mr, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(h->bulk_all_res_fn, nb + 1, 1, 1, h->TB * h->wpt_all, 1, 1,
+      HIP_OK(hipModuleLaunchKernel(h->bulk_all_res_fn, nb + 1, 1, 1, wide, 1, 1,
                                    std::max(h->lds_all, h->tail_lds_bytes), st, nullptr, cfg));
       return;
     }
@@ -451,10 +457,11 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
       BulkRes br;
       br.ba = ba;
       br.t = h->host_tail_launch.t;
-      patch_tail(br.t, a.block_threads);
+      const int wide = std::max((int)a.block_threads, h->res_tail_threads);
+      patch_tail(br.t, wide);
       size_t sz = sizeof(br);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &br, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(D.fn_res, D.n_tiles + 1, 1, 1, a.block_threads, 1, 1,
+      HIP_OK(hipModuleLaunchKernel(D.fn_res, D.n_tiles + 1, 1, 1, wide, 1, 1,
                                    std::max(D.lds_bytes, h->tail_lds_bytes), st, nullptr, cfg));
       return;
     }
@@ -720,6 +727,10 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     h->W_ocp.assign(Q.num_ocp_c, 1.0);
     if (const char* env = std::getenv("PYCOLLO_AMD_RESIDENT")) h->resident = std::atoi(env) != 0;
     if (const char* env = std::getenv("PYCOLLO_AMD_SPIN_US")) h->spin_us = std::atoi(env);
+    // the endpoint block is generated in four parts, one per wave of a 256-thread tail; a small block is not worth
+    // the three extra waves every tile's workgroup then carries (they exit at their first instruction)
+    if (Q.point_x.size() + (size_t)Q.n_b + Q.pthess_row.size() > 16) h->res_tail_threads = PC_TAIL_THREADS;
+    if (const char* env = std::getenv("PYCOLLO_AMD_RES_TAIL_THREADS")) h->res_tail_threads = std::atoi(env);
     // the tail's LDS carve (pc::tail_lds): acc | part | sum | xb | lb | hold | hb
     for (auto& P : Q.ph) h->lds_nred = std::max(h->lds_nred, P.nred);
     h->tail_lds_bytes = 8 * (int)(Q.tail_owned.size() + 17 * (size_t)h->lds_nred + Q.point_x.size() + (size_t)Q.n_b +
@@ -854,39 +865,47 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     }
     {
       // Edge-node Hessian entries on which an endpoint term lands: in a resident-tail launch the edge tile hands the
-      // value to the tail workgroup (a record of two granules) instead of storing it.  pt_rec: endpoint entry ->
-      // record; edge_rec (per phase): every edge-node entry site the bulk kernel knows -> record or -1.
-      std::map<int64_t, int32_t> rec_of_slot;
-      std::vector<int32_t> pt_rec(Q.pt_hslot.size(), -1);
+      // value to the tail workgroup (a record of two granules) instead of storing it.  Records are numbered in the
+      // order (phase, edge, site) over the sites the bulk kernel knows (z-z entries, t strips, s strips), so a tile
+      // finds a site's record from a bit mask and a base (PcPhaseArgs::edge_mask / edge_rec0); pt_rec maps every
+      // endpoint entry to its record.
+      std::map<int64_t, int32_t> want;   // slot -> endpoint entry
       for (size_t e = 0; e < Q.pt_hslot.size(); ++e)
-        if (Q.pt_hlocal[e] < 0) {
-          pt_rec[e] = (int32_t)rec_of_slot.size();
-          rec_of_slot.emplace(Q.pt_hslot[e], pt_rec[e]);
-        }
-      h->d_pt_rec.upload(pt_rec);
-      h->d_erec.upload(std::vector<unsigned long long>(2 * std::max<size_t>(1, rec_of_slot.size()), 0ull));
-      auto rec = [&](int64_t slot) -> int32_t {
-        auto it = slot >= 0 ? rec_of_slot.find(slot) : rec_of_slot.end();
-        return it == rec_of_slot.end() ? -1 : it->second;
-      };
-      size_t used = 0;
+        if (Q.pt_hlocal[e] < 0) want.emplace(Q.pt_hslot[e], (int32_t)e);
+      std::vector<int32_t> pt_rec(Q.pt_hslot.size(), -1);
+      int32_t n_rec = 0;
       for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
         auto& P = Q.ph[ip];
+        auto& D = *h->pd[ip];
         const int NZ = P.n_z, NS = Q.n_s, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
-        std::vector<int32_t> er(2 * (size_t)NE, -1);
+        std::memset(D.edge_mask, 0, sizeof(D.edge_mask));
         for (int edge = 0; edge < 2; ++edge) {
           const int64_t node = edge ? P.N - 1 : 0;
-          for (int i = 0; i < NHZZ; ++i) er[edge * NE + i] = rec(edge ? P.hslotN[i] : P.hslot0[i]);
-          for (int i = 0; i < 2 * NZ + NS * NZ; ++i) {
-            const int64_t base = P.hoff[NZ + i];   // t strips (j, z) then s strips (l, z)
-            er[edge * NE + NHZZ + i] = base >= 0 ? rec(base + node) : -1;
+          D.edge_rec0[edge] = n_rec;
+          for (int site = 0; site < NE; ++site) {
+            int64_t slot = -1;
+            if (site < NHZZ) {
+              slot = edge ? P.hslotN[site] : P.hslot0[site];
+            } else {
+              const int64_t base = P.hoff[NZ + (site - NHZZ)];   // t strips (j, z) then s strips (l, z)
+              if (base >= 0) slot = base + node;
+            }
+            auto it = slot >= 0 ? want.find(slot) : want.end();
+            if (it == want.end()) continue;
+            if (site >= 32 * PC_EDGE_WORDS) {   // beyond the kernels' mask: this model keeps two launches
+              h->resident = false;
+              continue;
+            }
+            D.edge_mask[edge][site >> 5] |= 1u << (site & 31);
+            pt_rec[it->second] = n_rec++;
+            want.erase(it);
           }
         }
-        for (int32_t v : er) used += v >= 0 ? 1 : 0;
-        h->pd[ip]->edge_rec.upload(er);
       }
-      if (used != rec_of_slot.size())
+      if (h->resident && !want.empty())
         throw std::runtime_error("internal error: an endpoint Hessian term lands on an edge-node entry no tile produces");
+      h->d_pt_rec.upload(pt_rec);
+      h->d_erec.upload(std::vector<unsigned long long>(2 * (size_t)std::max(1, n_rec), 0ull));
     }
     h->h_timeout.alloc(16);
     std::memset(h->h_timeout.p, 0, 16 * sizeof(unsigned));

@@ -316,11 +316,13 @@ struct BulkIn {
   const double* xz; const double* lamd;   // x + x_off, lam + c_off
   const int32_t* tile_k0; const int32_t* tile_n0; const int32_t* sec_s; const double* sec_h; const int64_t* sec_E;
   const double* qa; const double* qw; const int64_t* hslot0; const int64_t* hslotN; double* partials;
-  unsigned long long* gran; unsigned long long* erec; const int32_t* edge_rec; const double* tab;
+  unsigned long long* gran; unsigned long long* erec; const double* tab;
   int64_t x_off, s_off, c_off, c_path_off, c_int_off;
   double t_fixed[2];
   int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, wpt, n_blocks, block_threads, qa0, qw0, qwabs;
   uint32_t epoch;
+  uint32_t edge_mask[2][PC_EDGE_WORDS];
+  int32_t edge_rec0[2];
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -483,7 +485,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
     if constexpr (UN > 0) { A.uni_n = KB.uni_n; A.tile_k0 = KB.tile_k0; A.tile_n0 = KB.tile_n0; A.sec_s = KB.sec_s; }
     A.sec_E = KB.sec_E;
     A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials;
-    A.gran = KB.gran; A.erec = KB.erec; A.edge_rec = KB.edge_rec; A.tab = KB.tab;
+    A.gran = KB.gran; A.erec = KB.erec; A.tab = KB.tab;
+    if constexpr (RES) {
+      static_for<0, 2 * PC_EDGE_WORDS>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        A.edge_mask[i / PC_EDGE_WORDS][i % PC_EDGE_WORDS] = KB.edge_mask[i / PC_EDGE_WORDS][i % PC_EDGE_WORDS];
+      });
+      A.edge_rec0[0] = KB.edge_rec0[0]; A.edge_rec0[1] = KB.edge_rec0[1];
+    }
     A.epoch = MA ? MA->epoch : KB.epoch;
     A.s_off = KB.s_off; A.c_path_off = KB.c_path_off; A.c_int_off = KB.c_int_off;
     A.t_fixed[0] = KB.t_fixed[0]; A.t_fixed[1] = KB.t_fixed[1];
@@ -1021,13 +1030,17 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
   const bool edge0 = (node == 0), edgeN = (node == N - 1);
   // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot and the
-  // resident tail finishes it: then the value is handed over as granules instead (edge_rec[site] = record or -1;
-  // sites: the z-z entries, the t strips (j, z), the s strips (l, z), for node 0 and again for node N-1).
-  constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
-  auto edge_store = [&](int site, double* dstp, double val) {
-    if constexpr (RES) {
-      const int rec = A.edge_rec[(edge0 ? 0 : NEDGE) + site];
-      if (rec >= 0) {
+  // resident tail finishes it: then the value is handed over as granules instead.  Which sites (the z-z entries, the
+  // t strips (j, z), the s strips (l, z)) is a bit mask per edge in the argument block, a site's record the number of
+  // flagged sites before it: scalar arithmetic on uniform words, no table in memory.
+  auto edge_store = [&](auto site_, double* dstp, double val) {
+    constexpr int site = decltype(site_)::value;
+    // (a site beyond the mask is never flagged: the host gives such a model no resident tail if it would have to be)
+    if constexpr (RES && site < 32 * PC_EDGE_WORDS) {
+      const int ed = edge0 ? 0 : 1;
+      if ((A.edge_mask[ed][site >> 5] >> (site & 31)) & 1u) {
+        int rec = A.edge_rec0[ed] + __builtin_popcount(A.edge_mask[ed][site >> 5] & ((1u << (site & 31)) - 1u));
+        static_for<0, (site >> 5)>([&](auto w_) { rec += __builtin_popcount(A.edge_mask[ed][decltype(w_)::value]); });
         publish_granules(A.erec + 2 * rec, A.epoch, val);
         return;
       }
@@ -1050,7 +1063,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
           static_for<0, NH>([&](auto e_) {
             constexpr int e = decltype(e_)::value;
             if constexpr (M::hr(e) == rv)
-              edge_store(PC_CE(St::hzz_index(e)), A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))],
+              edge_store(ic<St::hzz_index(e)>{}, A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))],
                          vals[PC_CE(St::hpos(e))]);
           });
         }
@@ -1075,7 +1088,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
           if (mine(PC_ITEM(St::IT_HS + cv))) {
             double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
             const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
-            if (edge0 || edgeN) edge_store(St::NHZZ + 2 * NZ + (rv - NZ) * NZ + cv, dstp, val); else *dstp = val;
+            if (edge0 || edgeN) edge_store(ic<St::NHZZ + 2 * NZ + (rv - NZ) * NZ + cv>{}, dstp, val); else *dstp = val;
           }
         } else if constexpr (rv >= NZ) {
           constexpr int l = rv - NZ, l2 = cv - NZ;
@@ -1101,7 +1114,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
                 constexpr int j = decltype(j_)::value;
                 double* dstp = A.H + hoff[St::HO_T + j * NZ + cvar] + node;
                 const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
-                if (edge0 || edgeN) edge_store(St::NHZZ + j * NZ + cvar, dstp, val); else *dstp = val;
+                if (edge0 || edgeN) edge_store(ic<St::NHZZ + j * NZ + cvar>{}, dstp, val); else *dstp = val;
               });
             } else {
               red[St::R_TS + cvar - NZ] = acc;
@@ -1253,6 +1266,23 @@ __device__ __forceinline__ void tail_end(const PcTailArgs& A, const TailLds& L) 
   if (A.flags & PC_FLAG_H)
     for (int i = threadIdx.x; i < A.n_tail_owned; i += A.block_threads) A.H[A.tail_owned[i]] = L.acc[i];
 }
+// The resident tail reads its argument block field by field, lazily: every first touch of a 64-byte line of the
+// kernarg segment is a scalar-cache miss served from device memory, one after the other along the tail's critical
+// path (measured: 1.7 us between the arrival of the last partial sum and the tail's last store, for a dozen
+// instructions of arithmetic).  `issue` touches every line of the block with one scalar load at the tail's first
+// instructions -- all misses overlap each other and the endpoint inputs' vector loads -- and `settle`, placed where
+// those have returned anyway, keeps the loads alive.
+struct KernargWarm {
+  unsigned acc = 0;
+  template <int BYTES>
+  __device__ __forceinline__ void issue(int byte_off) {
+    typedef const __attribute__((address_space(4))) unsigned* kp;
+    kp p = (kp)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + byte_off);
+#pragma unroll
+    for (int i = 0; i < BYTES / 64; ++i) acc ^= p[16 * i];
+  }
+  __device__ __forceinline__ void settle() const { asm volatile("" ::"s"(acc)); }
+};
 // bounded spin of the resident tail: a pass that found a granule missing sleeps a little; PC_SPIN_LIMIT passes mean
 // the producer will never come (a launch bug): the timeout word is set and the caller's wait loop ends
 __device__ __forceinline__ bool spin_again(unsigned& spins, const PcTailArgs& A, unsigned code) {
@@ -1315,27 +1345,42 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
       // wave re-reading its granules of the stride until all carry this launch's tag
       const unsigned long long* gr = P.gran;
       unsigned spins = 0;
-      for (int b0 = 0; b0 < nt; b0 += 256) {
-        static_for<0, 4>([&](auto g_) {
-          constexpr int g = decltype(g_)::value;
-          if (g >= NG) return;
-          const int b = b0 + tid + TB * g;
-          const bool valid = b < nt;
-          double val[NRED];
-          for (;;) {
-            bool ok = true;
-            if (valid) {
-              unsigned long long raw[2 * NRED];
-              static_for<0, 2 * NRED>([&](auto i_) { raw[decltype(i_)::value] = load_granule(gr + 2 * (int64_t)b * NRED + decltype(i_)::value); });
+      // Four tiles per lane and pass (tiles b0 + tid + TB s, s = 0..3): one virtual stride of 256 tiles for a
+      // 64-thread workgroup, four strides for a 256-thread one -- a pass is one memory round trip however many it
+      // covers, and behind a long bulk kernel the tail must not fall a round trip per stride behind.  Slot s belongs
+      // to virtual lane group s % NG and the slots of a group are added in rising tile order, as the plain loop does.
+      for (int b0 = 0; b0 < nt; b0 += 4 * TB) {
+        double val[4][NRED];
+        for (;;) {
+          // every granule this lane needs of the pass is requested before the first is looked at
+          unsigned long long raw[4][2 * NRED];
+          static_for<0, 4>([&](auto s_) {
+            constexpr int sl = decltype(s_)::value;
+            const int b = b0 + tid + TB * sl;
+            if (b < nt)
+              static_for<0, 2 * NRED>([&](auto i_) { raw[sl][decltype(i_)::value] = load_granule(gr + 2 * (int64_t)b * NRED + decltype(i_)::value); });
+          });
+          bool ok = true;
+          static_for<0, 4>([&](auto s_) {
+            constexpr int sl = decltype(s_)::value;
+            const int b = b0 + tid + TB * sl;
+            if (b < nt)
               static_for<0, NRED>([&](auto r_) {
                 constexpr int r = decltype(r_)::value;
-                ok &= join_granules(raw[2 * r], raw[2 * r + 1], A.epoch, val[r]);
+                ok &= join_granules(raw[sl][2 * r], raw[sl][2 * r + 1], A.epoch, val[sl][r]);
               });
-            }
-            if (__all(ok)) break;
-            if (!spin_again(spins, A, 1u + (unsigned)ip)) break;
-          }
-          if (valid) static_for<0, NRED>([&](auto r_) { acc[g][decltype(r_)::value] += val[decltype(r_)::value]; });
+          });
+          if (__all(ok)) break;
+          if (!spin_again(spins, A, 1u + (unsigned)ip)) break;
+        }
+        static_for<0, 4>([&](auto s_) {
+          constexpr int sl = decltype(s_)::value;
+          const int b = b0 + tid + TB * sl;
+          if (b < nt)
+            static_for<0, 4>([&](auto g_) {
+              constexpr int g = decltype(g_)::value;
+              if (g == sl % NG) static_for<0, NRED>([&](auto r_) { acc[g][decltype(r_)::value] += val[sl][decltype(r_)::value]; });
+            });
         });
       }
     } else {

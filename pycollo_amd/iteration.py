@@ -20,13 +20,17 @@ from .engine import NlpEngine, interp_linear
 from .mesh import build_phase_mesh
 from .model import compile_model
 from .quadrature import QuadratureTables
-from .scaling import constraint_scaling, objective_scaling
+from .scaling import constraint_scaling, objective_scaling, scaling_from_previous
 
 
 class MeshIteration:
-    def __init__(self, problem, *, device: int = 0, meshes=None, prev=None, threads_per_block: int = 0, number: int = 1):
+    def __init__(self, problem, *, device: int = 0, meshes=None, prev=None, threads_per_block: int = 0, number: int = 1,
+                 update_scaling: bool = False, scaling_weight: float = 0.8, history=None):
         """``prev`` = (tau per phase, y per phase, u per phase, q per phase, t per phase, s) in *unscaled*
-        variables -- the previous iteration's solution; default: the problem's user guess."""
+        variables -- the previous iteration's solution; default: the problem's user guess.
+        ``update_scaling`` / ``scaling_weight`` (pycollo/settings.py:272-296, defaults False / 0.8) with ``history`` =
+        the ``scaling_record`` of every earlier mesh iteration, oldest first: scalings averaged over the mesh
+        iterations (pycollo/scaling.py:283-344) instead of regenerated from the bounds."""
         self.problem = problem
         self.model = compile_model(problem)
         self.quad = QuadratureTables(self.model.quadrature_method)
@@ -43,9 +47,21 @@ class MeshIteration:
         self.number = int(number)
         self.w = 1.0
         self.engine.set_scaling(V, r, np.ones(self.layout.num_ocp_c), 1.0)
-        if self.number > 1:
-            self.w = objective_scaling(self.engine, self.guess_x_tilde)
-        self.W_ocp = constraint_scaling(self.engine, self.guess_x_tilde)
+        if self.number > 1 and update_scaling and history:
+            # scaling.py:204-210,283-344.  As in the reference the NLP functions keep the V, r they were generated with
+            # (backend.py:1459-1463 runs before generate_scaling, iteration.py:375-394); the averaged V, r scale the
+            # bounds and unscale the solution (self.V, self.r below).
+            w_now = objective_scaling(self.engine, self.guess_x_tilde)
+            self.w, V_upd, r_upd, self.W_ocp = scaling_from_previous(
+                self.layout, self.model, self.guess_x_tilde, V, r, w_now, history, scaling_weight,
+                lambda V_rows: constraint_scaling(self.engine, self.guess_x_tilde, V_rows))
+            self.V, self.r = self.layout.expand_x(V_upd), self.layout.expand_x(r_upd)
+            self.scaling_record = (self.w, V_upd, r_upd, self.W_ocp)
+        else:
+            if self.number > 1:
+                self.w = objective_scaling(self.engine, self.guess_x_tilde)
+            self.W_ocp = constraint_scaling(self.engine, self.guess_x_tilde)
+            self.scaling_record = (self.w, V.copy(), r.copy(), self.W_ocp)
         self.engine.set_scaling(V, r, self.W_ocp, self.w)
         self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u = self._bounds()
 

@@ -10,10 +10,11 @@ The engine consumes quadrature tables **as data** (SURVEY.md F5): for every sect
 
 Reference behaviour restated: ``pycollo/quadrature.py:116-187`` (Radau) and ``:189-261`` (Lobatto).
 The reference obtains the interior Butcher rows from the order conditions
-``sum_i w_i c_i^k a_ij = w_j (1 - c_j^(k+1)) / (k+1) - w_last w_j`` (quadrature.py:214-241); here the
-same conditions are solved as one small dense system ``M X = R`` with ``M[k, i] = w_i c_i^k`` instead
-of the reference's block-expanded system.  Tables are checked against fixtures generated from the
-reference (tests/golden/quadrature_tables.npz).
+``sum_i w_i c_i^k a_ij = w_j (1 - c_j^(k+1)) / (k+1) - w_last w_j`` (quadrature.py:214-241) as one
+block-expanded linear system; it is restated in that form (``_butcher``) because the system is
+ill-conditioned at the higher orders and the tables must equal the reference's to the last digit.
+Tables are checked against fixtures generated from the reference for every order 2..20
+(tests/golden/quadrature_tables.npz).
 """
 from __future__ import annotations
 
@@ -57,16 +58,28 @@ def _radau_points_weights(n: int):
 
 
 def _butcher(n: int, x: np.ndarray, w: np.ndarray, last_row: np.ndarray) -> np.ndarray:
-    """Butcher array with zero first row, ``last_row`` last and order-condition interior rows."""
+    """Butcher array with zero first row, ``last_row`` last and order-condition interior rows.
+
+    The interior rows come from the reference's own linear system, assembled entry by entry in its arrangement
+    (quadrature.py:140-157 / :205-241): unknown a[i, j] sits at column ``i + j (n - 2)``, the condition of power k for
+    column j at row ``j + k n``, and the whole ``n (n - 2)``-square system goes to one ``numpy.linalg.solve``.  The
+    system is a row-permuted block-diagonal copy of one small Vandermonde-like matrix and could be solved as such,
+    but it is badly conditioned from n ~ 10 on (the solution's trailing digits then depend on the elimination order),
+    and the tables have to be the reference's, digit for digit -- so the same matrix meets the same LAPACK routine."""
     c = 0.5 * (x + 1.0)  # abscissae on [0, 1] (quadrature.py:85-91 with domain=[0, 1])
     B = np.zeros((n, n))
     B[-1, :] = last_row
     if n > 2:
-        k = np.arange(n - 2)
-        M = w[1:-1][None, :] * c[1:-1][None, :] ** k[:, None]          # (n-2) x (n-2)
-        R = (w[None, :] / (k[:, None] + 1.0)) * (1.0 - c[None, :] ** (k[:, None] + 1.0)) \
-            - w[-1] * w[None, :]                                            # (n-2) x n
-        B[1:-1, :] = np.linalg.solve(M, R)
+        m = n - 2
+        A = np.zeros((n * m, n * m))
+        rhs = np.zeros(n * m)
+        for k in range(m):
+            for j in range(n):
+                row = j + k * n
+                for i in range(m):
+                    A[row, i + j * m] = w[i + 1] * c[i + 1] ** k
+                rhs[row] = (w[j] / (k + 1)) * (1 - c[j] ** (k + 1)) - w[-1] * w[j]
+        B[1:-1, :] = np.linalg.solve(A, rhs).reshape(m, -1, order="F")
     return B
 
 

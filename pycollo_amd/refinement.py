@@ -53,41 +53,106 @@ def mesh_error(engine, x_tilde):
     return out
 
 
+def _merge_sections(group, n_min):
+    """``merge_sections`` of mesh_refinement.py:252-285: a run of neighbouring sections that are resolved far better
+    than the tolerance asks is replaced by ``ceil(sum p / (n_min - P))`` sections of ``n_min`` nodes, their knots
+    placed so that the sections' "required reduction" is spread evenly (the reference's density interpolation,
+    restated with the same scipy call)."""
+    from scipy import interpolate
+    g = np.asarray(group, dtype=float)
+    P_q, h_q, p_q = g[:, 0], g[:, 1], g[:, 2]
+    T = np.sum(h_q)
+    merge_ratio = p_q / (n_min - P_q)
+    needed = int(np.ceil(np.sum(merge_ratio)))
+    if needed == 1:
+        secs = np.array([T])
+    else:
+        required_reduction = np.divide(h_q, merge_ratio)
+        reduction_factor = np.reciprocal(np.sum(required_reduction)) * required_reduction
+        knot_locations = np.cumsum(h_q) / T
+        current_density = np.cumsum(reduction_factor)
+        density_func = interpolate.interp1d(knot_locations, current_density, bounds_error=False, fill_value="extrapolate")
+        new_density = np.linspace(1 / needed, 1, needed)
+        new_knots = np.concatenate([np.array([0]), density_func(new_density)])
+        secs = T * np.diff(new_knots)
+    return secs.tolist(), [n_min] * needed
+
+
+def _subdivide_sections(group, n_min):
+    """``subdivide_sections`` of mesh_refinement.py:287-313: per section either ``k`` equal parts of ``n_min`` nodes
+    or the predicted order (never below ``n_min``)."""
+    g = np.asarray(group, dtype=float)
+    sub_req, factor, red_tol, P_q, h_q, p_q = g[:, 0].astype(bool), g[:, 1].astype(int), g[:, 2], g[:, 3], g[:, 4], g[:, 5]
+    is_red = P_q <= 0
+    predicted = P_q + p_q
+    predicted[is_red] = np.ceil(P_q[is_red] * red_tol[is_red]) + p_q[is_red]
+    nxt = np.ones_like(predicted, dtype=int) * n_min
+    nxt[~sub_req] = predicted[~sub_req]
+    nxt[nxt < n_min] = n_min
+    sizes, nodes = [], []
+    for h, k, n in zip(h_q, factor, nxt):
+        sizes.extend([h / k] * k)
+        nodes.extend([int(n)] * k)
+    return sizes, nodes
+
+
 def next_phase_mesh(sizes, nodes, max_rel_err, *, mesh_tol=MESH_TOLERANCE, n_min=COLLOCATION_POINTS_MIN,
                     n_max=COLLOCATION_POINTS_MAX):
-    """Section sizes (fractions) and node counts of the next mesh (mesh_refinement.py:250-392).
+    """Section sizes (fractions) and node counts of the next mesh (``next_iteration_phase_mesh``,
+    mesh_refinement.py:250-392).
 
     For every section the number of extra nodes is P = ceil(log(e / tol) / log(n)) (with the reference's
-    correction for P <= 0); a section whose predicted order reaches ``n_max`` is subdivided into
-    ceil(predicted / n_min) sections of ``n_min`` nodes, otherwise its order becomes the predicted one
-    (never below ``n_min``).  The reference's merge branch is disabled by its MERGE_TOLERANCE_FACTOR = 0
-    (mesh_refinement.py:344-347) and is therefore not restated."""
+    correction for P <= 0).  Sections are walked in order and grouped into alternating runs:
+    * *merge* runs -- sections whose predicted order ``P + n`` is negative, i.e. resolved several orders better than
+      the tolerance (``merge_required = predicted < MERGE_TOLERANCE_FACTOR / log(tol / e)`` with the factor 0,
+      mesh_refinement.py:344-347: the factor only zeroes the threshold, the branch is live) -- are coalesced into
+      fewer ``n_min``-node sections (:252-285);
+    * the other runs -- a section whose predicted order reaches ``n_max`` is subdivided into
+      ceil(predicted / n_min) sections of ``n_min`` nodes, otherwise its order becomes the predicted one, never
+      below ``n_min`` (:287-313)."""
     sizes = np.asarray(sizes, dtype=float)
     nodes = np.asarray(nodes, dtype=np.int64)
     err = np.asarray(max_rel_err, dtype=float)
     if not np.max(err) > mesh_tol:
         return sizes / sizes.sum(), nodes.copy(), True
-    ratio = err / mesh_tol
-    P = np.ceil(np.log(ratio) / np.log(nodes))
-    neg = P <= 0
-    P[neg] = P[neg] + np.ceil(np.log(-P[neg] + 1))
-    predicted = P + nodes
-    log_tol = np.log(mesh_tol / err)
-    with np.errstate(divide="ignore"):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        P = np.ceil(np.log(err / mesh_tol) / np.log(nodes))
+        neg = P <= 0
+        P[neg] = P[neg] + np.ceil(np.log(-P[neg] + 1))
+        predicted = P + nodes
+        log_tol = np.log(np.divide(mesh_tol, err))
+        merge_required = predicted < (0 / log_tol)                      # MERGE_TOLERANCE_FACTOR = 0
         red = 1 + np.reciprocal(log_tol)
     red[red < 0] = 0
     subdivide = predicted >= n_max
-    new_sizes, new_nodes = [], []
+    level = np.ones_like(predicted)
+    level[subdivide] = np.ceil(predicted[subdivide] / n_min)
+    merge_group, sub_group, new_sizes, new_nodes = [], [], [], []
+
+    def flush_merge():
+        nonlocal merge_group
+        if merge_group:
+            s_, n_ = _merge_sections(merge_group, n_min)
+            new_sizes.extend(s_)
+            new_nodes.extend(n_)
+            merge_group = []
+
+    def flush_sub():
+        nonlocal sub_group
+        if sub_group:
+            s_, n_ = _subdivide_sections(sub_group, n_min)
+            new_sizes.extend(s_)
+            new_nodes.extend(n_)
+            sub_group = []
+
     for k in range(len(nodes)):
-        if subdivide[k]:
-            parts = int(np.ceil(predicted[k] / n_min))
-            new_sizes += [sizes[k] / parts] * parts
-            new_nodes += [n_min] * parts
+        if merge_required[k]:
+            flush_sub()
+            merge_group.append([P[k], sizes[k], nodes[k]])
         else:
-            pn = P[k] + nodes[k]
-            if P[k] <= 0:
-                pn = np.ceil(P[k] * red[k]) + nodes[k]
-            new_sizes.append(sizes[k])
-            new_nodes.append(int(max(pn, n_min)))
+            flush_merge()
+            sub_group.append([subdivide[k], level[k], red[k], P[k], sizes[k], nodes[k]])
+    flush_merge()
+    flush_sub()
     new_sizes = np.asarray(new_sizes)
     return new_sizes / new_sizes.sum(), np.asarray(new_nodes, dtype=np.int64), False

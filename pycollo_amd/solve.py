@@ -28,15 +28,20 @@ class OcpResult:
 
 
 def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float = MESH_TOLERANCE, device: int = 0,
-              nlp_tol: float = 1e-8, nlp_max_iter: int = 1000, verbose: int = 0) -> OcpResult:
-    """Solve ``problem`` (a :class:`pycollo_amd.problem.ProblemSpec`) on its initial mesh, refine, repeat."""
+              nlp_tol: float = 1e-8, nlp_max_iter: int = 1000, verbose: int = 0, update_scaling: bool = False,
+              scaling_weight: float = 0.8) -> OcpResult:
+    """Solve ``problem`` (a :class:`pycollo_amd.problem.ProblemSpec`) on its initial mesh, refine, repeat.
+    ``update_scaling`` / ``scaling_weight``: pycollo/settings.py:272-296 (scalings averaged over the mesh iterations)."""
     prob = copy.deepcopy(problem)
     prev = None
     log = []
     it = None
     met = False
+    history = []
     for k in range(max_mesh_iterations):
-        it = MeshIteration(prob, device=device, prev=prev, number=k + 1)
+        it = MeshIteration(prob, device=device, prev=prev, number=k + 1, update_scaling=update_scaling,
+                           scaling_weight=scaling_weight, history=history)
+        history.append(it.scaling_record)
         res = it.solve_with_ipm(max_iter=nlp_max_iter, tol=nlp_tol, verbose=max(0, verbose - 1))
         errs = mesh_error(it.engine, it.x_tilde)
         worst = max(float(np.max(rel)) for rel, _ in errs)

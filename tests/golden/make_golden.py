@@ -53,13 +53,13 @@ def main():
         b.quadrature = quad
         return b
 
-    # (i) quadrature tables, orders 2..12, lobatto + radau
+    # (i) quadrature tables, every order the reference allows (2..20, quadrature.py:36-37), lobatto + radau
     out = {}
     quads = {}
     for method in ("lobatto", "radau"):
         q = quad_mod.Quadrature(backend(method))
         quads[method] = q
-        for n in range(2, 13):
+        for n in range(2, 21):
             out[f"{method}_{n}_points"] = np.asarray(q.quadrature_point(n), dtype=float)
             out[f"{method}_{n}_weights"] = np.asarray(q.quadrature_weight(n), dtype=float)
             out[f"{method}_{n}_A"] = np.asarray(q.A_matrix(n), dtype=float)

@@ -4,7 +4,7 @@ blocks, the zero-copy hand-over and the three data-movement modes.  Reference su
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import rel_err, golden_tables
 from oracle.ref_numpy import OracleNlp
 from pycollo_amd import problems
 from pycollo_amd.quadrature import QuadratureTables
@@ -24,7 +24,7 @@ def test_new_x_protocol(built, name, kw):
     carry 0: g / jac_g must then be those of the new point, never a cached c~/G~ of the previous one."""
     prob = problems.REGISTRY[name](**kw)
     eng = _engine(prob)
-    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
     rng = np.random.default_rng(5)
     x0, x1, x2, x3 = (rng.uniform(-0.4, 0.4, eng.num_x) for _ in range(4))
     lam = rng.normal(size=eng.num_c)
@@ -55,7 +55,7 @@ def test_cyipopt_object_recovers_new_x(built):
     from pycollo_amd.engine import PycolloGpuProblem
     prob = problems.cart_pole(K=60, order=4)
     eng = _engine(prob)
-    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
     p = PycolloGpuProblem(eng)
     rng = np.random.default_rng(9)
     lam = rng.normal(size=eng.num_c)

@@ -3,6 +3,7 @@ pycollo/mesh_refinement.py:63-240, and the refine -> re-solve loop."""
 import numpy as np
 import pytest
 
+from conftest import golden_tables
 from oracle.ref_numpy import OracleNlp
 from oracle.ref_refine import mesh_error as oracle_mesh_error
 from pycollo_amd import problems
@@ -33,7 +34,7 @@ def test_mesh_error_matches_oracle(built, name, kw, ragged):
     if ragged:
         prob = _ragged(prob)
     eng = NlpEngine(prob, device=0)
-    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp)
     # a smooth "solution": low-order polynomial in tau per variable, so the estimate is small but not zero
     rng = np.random.default_rng(5)
     x = np.zeros(eng.num_x)

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, rel_err
+from conftest import ROOT, rel_err, golden_tables
 from pycollo_amd import problems
 
 BUILD = os.path.join(ROOT, "tests", "_build")
@@ -28,7 +28,7 @@ def harness(built):
     lib = C.CDLL(so)
     vp, ci = C.c_void_p, C.c_int
     lib.drive_structure.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]
-    lib.drive_point.argtypes = [vp, ci, ci, ci, ci, vp, C.c_double] + [vp] * 8
+    lib.drive_point.argtypes = [vp, ci, ci, ci, ci, vp, C.c_double] + [vp] * 7
     lib.drive_wrong_sizes.argtypes = [vp, ci, ci, ci, vp, vp, vp]
     from pycollo_amd.engine import load_library
     pc = load_library()
@@ -74,7 +74,7 @@ def test_ipopt_call_sequence_on_gpu(harness, name, kw):
     lib, cb = harness
     prob = problems.REGISTRY[name](**kw)
     eng = NlpEngine(prob, device=0)
-    ora = OracleNlp(prob, QuadratureTables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
     n, m, nj, nh = eng.num_x, eng.num_c, eng.nnz_jac, eng.nnz_hess
     rng = np.random.default_rng(3)
     for _ in range(3):

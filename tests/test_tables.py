@@ -9,13 +9,15 @@ from pycollo_amd.quadrature import QuadratureTables
 
 @pytest.mark.parametrize("method", ["lobatto", "radau"])
 def test_quadrature_tables_match_reference(method, golden_quadrature):
+    """Every order the reference allows (2..20, quadrature.py:36-37).  The reference solves an ill-conditioned system
+    for the Butcher rows (quadrature.py:209-241; at n = 20 its rows miss their exact sums by 1e-5): the tables only
+    agree because the product restates that very system and hands it to the same solver -- bit for bit on the machine
+    that generated the fixtures, and within the conditioning's reach of a last-digit difference in LAPACK elsewhere."""
     q = QuadratureTables(method)
-    for n in range(2, 13):
-        # the reference solves an ill-conditioned system for the Butcher rows (quadrature.py:209-241);
-        # agreement degrades with its conditioning: 1e-13 up to n = 8, 5e-11 at n = 12
-        tol = 1e-13 if n <= 8 else 5e-11
+    for n in range(2, 21):
         np.testing.assert_allclose(q.points(n), golden_quadrature[f"{method}_{n}_points"], rtol=0, atol=1e-14)
         np.testing.assert_allclose(q.weights(n), golden_quadrature[f"{method}_{n}_weights"], rtol=1e-13, atol=1e-15)
+        tol = 1e-13 if n <= 8 else (1e-11 if n <= 12 else 1e-6)
         np.testing.assert_allclose(q.A(n), golden_quadrature[f"{method}_{n}_A"], rtol=0, atol=tol)
         np.testing.assert_array_equal(q.D(n), golden_quadrature[f"{method}_{n}_D"])
 
