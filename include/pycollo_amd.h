@@ -211,6 +211,45 @@ int pc_run_chunk(void);
 int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const int32_t* orders, const double* tabB,
                   const double* tabE, const double* tabA, double* max_rel, double* max_abs);
 
+/* ---- KKT solve on the GPU ---------------------------------------------------
+ * Replaces the sparse symmetric-indefinite linear solver IPOPT calls once per iteration -- MUMPS, which the reference
+ * selects by name only (``linear_solver``, pycollo/backend.py:1703-1711, pycollo/settings.py:49-59) -- for the
+ * interior-point system  [[W + Sigma + dw I, J^T], [J, -dc I]]  of the collocation NLP.  W = H~ and J = G~ are read
+ * where the evaluation left them in device memory (pc_eval_resident + pc_device_results): they never travel to the
+ * host.  The matrix is eliminated block-wise along the mesh (section interiors in parallel, then the chain of section
+ * boundary nodes, then the dense border of global unknowns) with 1 x 1 pivots in a fixed order; the signs of the pivots
+ * are the inertia.  The index tables (pc_kkt_desc) are built by pycollo_amd/kkt.py, which documents the layout.
+ * Unknowns, in every vector below: the nv primal ones (x~, then the slacks of the inequality rows), then the m
+ * multipliers. */
+typedef struct pc_kkt pc_kkt;
+typedef struct {
+  int64_t nu, nv, n_leaf, n_chain, n_phase, nb, total_vals, border_off, n_dst, n_src, n_mv;
+  const int64_t *perm, *leaf_ptr, *chain_ptr, *chain_phase_ptr, *leaf_left;
+  const int64_t *leafA_off, *leafS_off, *chainD_off, *chainS_off;
+  const int64_t *dst, *run_ptr;       /* assembly: destination positions and their source runs */
+  const int32_t *src_kind, *src_idx;  /* 0: G~ value, 1: H~ value, 2: the constant 1 */
+  const double* src_coef;
+  const int64_t* diag_pos;
+  const uint8_t* fixed;
+  const int64_t* mv_ptr;              /* the whole symmetric matrix as CSR over the unknowns (products) */
+  const int32_t *mv_col, *mv_kind, *mv_idx;
+  const double* mv_coef;
+} pc_kkt_desc;
+const char* pc_kkt_last_error(void);
+int pc_kkt_create(const pc_kkt_desc* desc, const double* d_jac, const double* d_hess, int device, pc_kkt** out);
+void pc_kkt_destroy(pc_kkt* k);
+/* assemble from the current device G~ / H~ (use_hess = 0: W = 0, e.g. least-squares multipliers) and dvec[nu]
+ * (host: Sigma + dw on primal unknowns, -dc on multipliers), factorise; returns the pivot signs */
+int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, int32_t* n_neg);
+int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x);                       /* host vectors [nu] */
+int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, double* y);   /* y = K x */
+/* Evaluate at (x, obj_factor, lambda) and leave g, jac_g and the Lagrangian Hessian in device memory; only J,
+ * grad J (dense n, may be NULL) and g (may be NULL) come back.  lambda == NULL: g and jac_g only. */
+int pc_eval_resident(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* f, double* grad,
+                     double* g);
+/* device pointers of the results of the last evaluation that went through the handle's own buffers */
+int pc_device_results(pc_handle* h, const double** d_g, const double** d_jac, const double** d_hess);
+
 /* timing of the last n pc_eval_all_device launches is measured by the caller with HIP events on the
  * stream it passed; this returns the stream the handle owns (hipStream_t) */
 void* pc_stream(pc_handle* h);

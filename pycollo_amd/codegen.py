@@ -417,3 +417,37 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
         print(res.stderr)
     os.replace(out + ".tmp", out)
     return out
+
+
+def kernel_resources(model: Model, orders=None) -> dict:
+    """Registers and scratch memory of every kernel of the model's code object, as hipcc reports them
+    (``-Rpass-analysis=kernel-resource-usage``): {kernel: {"vgprs", "sgprs", "scratch", "occupancy"}}.  A bulk kernel
+    with scratch memory is a bug of the templates (an array subscripted by a run-time value), not a tuning matter:
+    tests assert it stays at zero."""
+    import re
+    import tempfile
+    hipcc = hipcc_path()
+    if hipcc is None:
+        raise RuntimeError("hipcc is not available")
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "m.hip")
+        with open(src, "w") as f:
+            f.write(generate_source(model, orders))
+        cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
+               "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
+               f"-I{CSRC}", "-o", os.path.join(tmp, "m.hsaco"), src]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{res.stderr[-4000:]}")
+    out, cur = {}, None
+    for line in res.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return out

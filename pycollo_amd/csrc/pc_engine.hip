@@ -1230,6 +1230,47 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
   });
 }
 
+int pc_eval_resident(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* f, double* grad,
+                     double* g) {
+  return guarded([&] {
+    require_device(h);
+    auto& Q = h->Q;
+    if (!x) throw std::runtime_error("null x");
+    const int mode = h->host_mode;
+    h->host_mode = 0;   // results stay in (and are read from) the device mirror
+    try {
+      std::memcpy(h->h_in.p, x, Q.num_x * sizeof(double));
+      if (lambda) std::memcpy(h->h_in.p + h->o_lam, lambda, Q.num_c * sizeof(double));
+      HIP_OK(hipMemcpyAsync(h->d_in.p, h->h_in.p, (lambda ? h->in_total : (size_t)Q.num_x) * sizeof(double),
+                            hipMemcpyHostToDevice, h->stream));
+      launch_all(h, kx(h), lambda ? klam(h) : nullptr, kout(h, h->o_c), kout(h, h->o_G), lambda ? kout(h, h->o_H) : nullptr,
+                 kout(h, h->o_f), kout(h, h->o_gn), PC_FLAG_C | PC_FLAG_G | (lambda ? PC_FLAG_H : 0), h->stream, obj_factor);
+      copy_down(h, 0, h->o_c + Q.num_c);
+      wait_stream(h);
+    } catch (...) {
+      h->host_mode = mode;
+      throw;
+    }
+    h->host_mode = mode;
+    h->x_valid = h->fc_valid = false;   // (the callback cache describes the host copies; G~ was not copied)
+    if (f) *f = h->h_out.p[h->o_f];
+    if (grad) {
+      std::memset(grad, 0, Q.num_x * sizeof(double));
+      for (size_t e = 0; e < Q.jgrad_col.size(); ++e) grad[Q.point_x[Q.jgrad_col[e]]] = h->h_out.p[h->o_gn + e];
+    }
+    if (g) std::memcpy(g, h->h_out.p + h->o_c, Q.num_c * sizeof(double));
+  });
+}
+
+int pc_device_results(pc_handle* h, const double** d_g, const double** d_jac, const double** d_hess) {
+  return guarded([&] {
+    require_device(h);
+    if (d_g) *d_g = h->d_out.p + h->o_c;
+    if (d_jac) *d_jac = h->d_out.p + h->o_G;
+    if (d_hess) *d_hess = h->d_out.p + h->o_H;
+  });
+}
+
 // ---- IPOPT's callback types (include/pycollo_amd.h) ------------------------------------------------------
 static bool ipopt_sizes_ok(pc_handle* h, int n, int m, int64_t nele, int which) {
   if (!h) { set_err("null user_data"); return false; }

@@ -1037,10 +1037,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
     constexpr int site = decltype(site_)::value;
     // (a site beyond the mask is never flagged: the host gives such a model no resident tail if it would have to be)
     if constexpr (RES && site < 32 * PC_EDGE_WORDS) {
-      const int ed = edge0 ? 0 : 1;
-      if ((A.edge_mask[ed][site >> 5] >> (site & 31)) & 1u) {
-        int rec = A.edge_rec0[ed] + __builtin_popcount(A.edge_mask[ed][site >> 5] & ((1u << (site & 31)) - 1u));
-        static_for<0, (site >> 5)>([&](auto w_) { rec += __builtin_popcount(A.edge_mask[ed][decltype(w_)::value]); });
+      // (the edge is chosen per word with a select: a run-time subscript would send the whole argument copy to
+      //  scratch memory)
+      auto word = [&](auto w_) -> unsigned {
+        constexpr int w = decltype(w_)::value;
+        return edge0 ? A.edge_mask[0][w] : A.edge_mask[1][w];
+      };
+      const unsigned mw = word(ic<(site >> 5)>{});
+      if ((mw >> (site & 31)) & 1u) {
+        int rec = (edge0 ? A.edge_rec0[0] : A.edge_rec0[1]) + __builtin_popcount(mw & ((1u << (site & 31)) - 1u));
+        static_for<0, (site >> 5)>([&](auto w_) { rec += __builtin_popcount(word(w_)); });
         publish_granules(A.erec + 2 * rec, A.epoch, val);
         return;
       }
@@ -1345,23 +1351,24 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
       // wave re-reading its granules of the stride until all carry this launch's tag
       const unsigned long long* gr = P.gran;
       unsigned spins = 0;
-      // Four tiles per lane and pass (tiles b0 + tid + TB s, s = 0..3): one virtual stride of 256 tiles for a
-      // 64-thread workgroup, four strides for a 256-thread one -- a pass is one memory round trip however many it
-      // covers, and behind a long bulk kernel the tail must not fall a round trip per stride behind.  Slot s belongs
-      // to virtual lane group s % NG and the slots of a group are added in rising tile order, as the plain loop does.
-      for (int b0 = 0; b0 < nt; b0 += 4 * TB) {
-        double val[4][NRED];
+      // SL tiles per lane and pass (tiles b0 + tid + TB s, s < SL): a pass is one memory round trip however many
+      // tiles it covers, and behind a long bulk kernel the tail must not fall a round trip per stride behind; SL is
+      // what the register budget allows (the kernel's VGPR count is the tiles' occupancy too).  Tile b belongs to
+      // virtual lane group (b / TB) % NG and a group's tiles are added in rising order, as the plain loop does.
+      constexpr int SL = NRED <= 2 ? 4 : (NRED <= 4 ? 2 : 1);
+      for (int b0 = 0; b0 < nt; b0 += SL * TB) {
+        double val[SL][NRED];
         for (;;) {
           // every granule this lane needs of the pass is requested before the first is looked at
-          unsigned long long raw[4][2 * NRED];
-          static_for<0, 4>([&](auto s_) {
+          unsigned long long raw[SL][2 * NRED];
+          static_for<0, SL>([&](auto s_) {
             constexpr int sl = decltype(s_)::value;
             const int b = b0 + tid + TB * sl;
             if (b < nt)
               static_for<0, 2 * NRED>([&](auto i_) { raw[sl][decltype(i_)::value] = load_granule(gr + 2 * (int64_t)b * NRED + decltype(i_)::value); });
           });
           bool ok = true;
-          static_for<0, 4>([&](auto s_) {
+          static_for<0, SL>([&](auto s_) {
             constexpr int sl = decltype(s_)::value;
             const int b = b0 + tid + TB * sl;
             if (b < nt)
@@ -1373,14 +1380,18 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
           if (__all(ok)) break;
           if (!spin_again(spins, A, 1u + (unsigned)ip)) break;
         }
-        static_for<0, 4>([&](auto s_) {
+        const int gb = (b0 / TB) % NG;   // uniform
+        static_for<0, SL>([&](auto s_) {
           constexpr int sl = decltype(s_)::value;
           const int b = b0 + tid + TB * sl;
-          if (b < nt)
-            static_for<0, 4>([&](auto g_) {
-              constexpr int g = decltype(g_)::value;
-              if (g == sl % NG) static_for<0, NRED>([&](auto r_) { acc[g][decltype(r_)::value] += val[sl][decltype(r_)::value]; });
-            });
+          // (every group adds, the others an exact +0.0: a branch per group is folded by the compiler into a computed
+          //  subscript, and that puts the accumulators -- and the dispatch -- in scratch memory)
+          const int g = (gb + sl) % NG;
+          static_for<0, 4>([&](auto g_) {
+            constexpr int gg = decltype(g_)::value;
+            const bool hit = b < nt && g == gg;
+            static_for<0, NRED>([&](auto r_) { acc[gg][decltype(r_)::value] += hit ? val[sl][decltype(r_)::value] : 0.0; });
+          });
         });
       }
     } else {

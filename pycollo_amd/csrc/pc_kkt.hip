@@ -1,0 +1,609 @@
+// KKT solve on the GPU: block L D L^T of the interior-point system over the collocation structure
+// (leaves = mesh-section interiors, chain = section boundary nodes, border = global unknowns).
+// Tables come from pycollo_amd/kkt.py (which explains the ordering); entry points: pc_kkt_* in include/pycollo_amd.h.
+// Replaces the sparse symmetric-indefinite solver IPOPT calls (MUMPS; the reference only names it:
+// pycollo/backend.py:1703-1711, pycollo/settings.py:49-59).
+//
+// Everything a block needs lives in one value buffer: a leaf's [A | C] (its own matrix and its coupling to
+// [left node | right node | border]) is overwritten by [L, D | X = A^-1 C], its Schur block S = -C^T A^-1 C goes to a
+// slot of its own; a chain node's [D | E | F] likewise.  No atomics, no pivot search: the order of every sum is fixed
+// by the tables, two factorisations of the same matrix give the same bits.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pycollo_amd.h"
+
+namespace {
+
+thread_local std::string k_err;
+
+#define KHIP(expr)                                                                               \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+template <class T>
+struct Dev {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count;
+    if (count) KHIP(hipMalloc(&p, count * sizeof(T)));
+  }
+  void upload(const T* src, size_t count) {
+    alloc(count);
+    if (count) KHIP(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+  ~Dev() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+enum { SRC_G = 0, SRC_H = 1, SRC_ONE = 2 };
+
+// ---- assembly -------------------------------------------------------------------------------------------------
+// one thread per destination: the sources of one matrix position, summed in table order
+__global__ void kkt_scatter(double* __restrict__ vals, const int64_t* __restrict__ dst, const int64_t* __restrict__ run_ptr,
+                            const int32_t* __restrict__ kind, const int32_t* __restrict__ idx, const double* __restrict__ coef,
+                            const double* __restrict__ G, const double* __restrict__ H, int use_H, int64_t n_dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_dst) return;
+  double acc = 0.0;
+  for (int64_t e = run_ptr[i]; e < run_ptr[i + 1]; ++e) {
+    const int k = kind[e];
+    const double v = k == SRC_G ? G[idx[e]] : (k == SRC_H ? (use_H ? H[idx[e]] : 0.0) : 1.0);
+    acc += v * coef[e];
+  }
+  vals[dst[i]] = acc;
+}
+
+// diagonal: Sigma + dw on primal unknowns, -dc on multipliers (dvec); a fixed unknown is a unit pivot
+__global__ void kkt_diag(double* __restrict__ vals, const int64_t* __restrict__ diag_pos, const uint8_t* __restrict__ fixed,
+                         const double* __restrict__ dvec, int64_t nu) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nu) return;
+  double* p = vals + diag_pos[u];
+  *p = fixed[u] ? 1.0 : *p + dvec[u];
+}
+
+// y = K x over natural unknowns, one wave per row of the recipe
+__global__ void kkt_matvec(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const int32_t* __restrict__ kind,
+                           const int32_t* __restrict__ idx, const double* __restrict__ coef, const double* __restrict__ G,
+                           const double* __restrict__ H, int use_H, const uint8_t* __restrict__ fixed,
+                           const double* __restrict__ dvec, const double* __restrict__ x, double* __restrict__ y, int64_t nu) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= nu) return;
+  double acc = 0.0;
+  for (int64_t e = ptr[row] + lane; e < ptr[row + 1]; e += 64) {
+    const int k = kind[e];
+    const double v = k == SRC_G ? G[idx[e]] : (k == SRC_H ? (use_H ? H[idx[e]] : 0.0) : 1.0);
+    acc += v * coef[e] * x[col[e]];
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) y[row] = fixed[row] ? x[row] : acc + dvec[row] * x[row];
+}
+
+// ---- dense block elimination ------------------------------------------------------------------------------------
+// M = [A | C], row stride ld = m + w, A's lower triangle valid.  On return: strict lower triangle of A = L, its
+// diagonal = D, the C part = X = A^-1 C; S (w x w, may be null) = -C^T A^-1 C; cnt = (positive, negative) pivots.
+// One workgroup; lds holds 2 m + w doubles.
+__device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, double* lds) {
+  const int tid = threadIdx.x, nt = blockDim.x, ld = m + w;
+  double* colL = lds;
+  double* lcol = lds + m;
+  double* rowC = lds + 2 * m;
+  int npos = 0, nneg = 0;
+  for (int j = 0; j < m; ++j) {
+    __syncthreads();
+    const double d = M[(size_t)j * ld + j];
+    npos += d > 0.0;
+    nneg += d < 0.0;
+    for (int i = j + 1 + tid; i < m; i += nt) {
+      const double c = M[(size_t)i * ld + j];
+      colL[i] = c;
+      lcol[i] = c / d;
+    }
+    for (int c = tid; c < w; c += nt) rowC[c] = M[(size_t)j * ld + m + c];
+    __syncthreads();
+    const int rows = m - j - 1, width = rows + w;
+    for (int e = tid; e < rows * width; e += nt) {
+      const int i = j + 1 + e / width, k = e % width;
+      if (k < rows) {
+        const int kk = j + 1 + k;
+        if (kk <= i) M[(size_t)i * ld + kk] -= lcol[i] * colL[kk];
+      } else {
+        M[(size_t)i * ld + m + (k - rows)] -= lcol[i] * rowC[k - rows];
+      }
+    }
+    for (int i = j + 1 + tid; i < m; i += nt) M[(size_t)i * ld + j] = lcol[i];
+  }
+  __syncthreads();
+  if (S)   // Z = L^-1 C now sits in the C part
+    for (int e = tid; e < w * w; e += nt) {
+      const int a = e / w, b = e % w;
+      double acc = 0.0;
+      for (int j = 0; j < m; ++j) acc += M[(size_t)j * ld + m + a] * (M[(size_t)j * ld + m + b] / M[(size_t)j * ld + j]);
+      S[e] = -acc;
+    }
+  __syncthreads();
+  for (int c = tid; c < w; c += nt) {   // X = L^-T D^-1 Z, one column per thread
+    for (int j = 0; j < m; ++j) M[(size_t)j * ld + m + c] /= M[(size_t)j * ld + j];
+    for (int j = m - 1; j >= 0; --j) {
+      double acc = M[(size_t)j * ld + m + c];
+      for (int i = j + 1; i < m; ++i) acc -= M[(size_t)i * ld + j] * M[(size_t)i * ld + m + c];
+      M[(size_t)j * ld + m + c] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && cnt) {
+    cnt[0] = npos;
+    cnt[1] = nneg;
+  }
+}
+
+// t = A^-1 r for a factored block (r in lds, length m; result left there); one workgroup
+__device__ void block_solve(const double* M, int m, int ld, double* r) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = 0; j < m; ++j) {
+    __syncthreads();
+    const double rj = r[j];
+    for (int i = j + 1 + tid; i < m; i += nt) r[i] -= M[(size_t)i * ld + j] * rj;
+  }
+  __syncthreads();
+  for (int i = tid; i < m; i += nt) r[i] /= M[(size_t)i * ld + i];
+  for (int j = m - 1; j >= 0; --j) {
+    __syncthreads();
+    if (tid == 0) {
+      double acc = r[j];
+      for (int i = j + 1; i < m; ++i) acc -= M[(size_t)i * ld + j] * r[i];
+      r[j] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+struct KArgs {
+  double* vals;
+  const int64_t *leaf_ptr, *chain_ptr, *chain_phase_ptr, *leaf_left, *leafA_off, *leafS_off, *chainD_off, *chainS_off;
+  const int64_t* leaf_of_left;   // [n_chain] leaf whose left node is this chain node, -1 for the last node of a phase
+  const uint8_t* chain_last;     // [n_chain]
+  int64_t border_off, base_chain, base_border;
+  int32_t nb, n_leaf, n_chain;
+  int* counts;                   // [n_leaf + n_chain + 1][2]
+  // solve
+  double* r;                     // [nu] right-hand side, then the solution, in block order
+  double* leafG;                 // per leaf: X_C^T r_l, w doubles at leafG_off
+  double* chainG;                // per chain node: Y^T r_c, wc doubles at chainG_off
+  const int64_t *leafG_off, *chainG_off;
+};
+
+__device__ __forceinline__ int nzb_of(const KArgs& a, int64_t c) { return (int)(a.chain_ptr[c + 1] - a.chain_ptr[c]); }
+
+__global__ void kkt_leaf_factor(KArgs a) {
+  extern __shared__ double lds[];
+  const int64_t l = blockIdx.x;
+  const int m = (int)(a.leaf_ptr[l + 1] - a.leaf_ptr[l]);
+  const int64_t left = a.leaf_left[l];
+  const int w = nzb_of(a, left) + nzb_of(a, left + 1) + a.nb;
+  block_eliminate(a.vals + a.leafA_off[l], m, w, a.vals + a.leafS_off[l], a.counts + 2 * l, lds);
+}
+
+// one workgroup per phase walks its chain of boundary nodes in order
+__global__ void kkt_chain_factor(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  for (int64_t c = c0; c < c1; ++c) {
+    const int nz = nzb_of(a, c), nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb, ld = nz + wc;
+    double* M = a.vals + a.chainD_off[c];
+    __syncthreads();
+    // the diagonal block was assembled as a lower triangle; the contributions below are full blocks: mirror first
+    for (int e = tid; e < nz * nz; e += nt) {
+      const int i = e / nz, k = e % nz;
+      if (k > i) M[(size_t)i * ld + k] = M[(size_t)k * ld + i];
+    }
+    __syncthreads();
+    if (c > c0) {   // leaf on the left (its R and border rows) and the previous node's Schur block
+      const int nl = nzb_of(a, c - 1);
+      const int64_t lf = a.leaf_of_left[c - 1];
+      const double* S = a.vals + a.leafS_off[lf];
+      const int ws = nl + nz + nb;
+      const double* Cr = a.vals + a.chainS_off[c - 1];   // (nz + nb)^2
+      const int wr = nz + nb;
+      for (int e = tid; e < nz * (nz + nb); e += nt) {
+        const int i = e / (nz + nb), k = e % (nz + nb);
+        const double add = S[(size_t)(nl + i) * ws + nl + k] + Cr[(size_t)i * wr + k];
+        M[(size_t)i * ld + (k < nz ? k : nx + k)] += add;
+      }
+    }
+    __syncthreads();
+    if (!a.chain_last[c]) {   // leaf on the right: its L rows reach this node, the next one and the border
+      const int64_t lf = a.leaf_of_left[c];
+      const double* S = a.vals + a.leafS_off[lf];
+      const int ws = nz + nx + nb;
+      for (int e = tid; e < nz * ws; e += nt) {
+        const int i = e / ws, k = e % ws;
+        M[(size_t)i * ld + k] += S[(size_t)i * ws + k];
+      }
+    }
+    __syncthreads();
+    block_eliminate(M, nz, wc, a.vals + a.chainS_off[c], a.counts + 2 * (a.n_leaf + c), lds);
+    __threadfence_block();
+  }
+}
+
+// border = its own entries + the border corner of every Schur block, then its factorisation (one workgroup)
+__global__ void kkt_border_factor(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  double* B = a.vals + a.border_off;
+  for (int e = tid; e < nb * nb; e += nt) {
+    const int i = e / nb, k = e % nb;
+    if (k > i) continue;
+    double acc = B[e];
+    for (int64_t l = 0; l < a.n_leaf; ++l) {
+      const int64_t left = a.leaf_left[l];
+      const int ws = nzb_of(a, left) + nzb_of(a, left + 1) + nb, o = ws - nb;
+      acc += a.vals[a.leafS_off[l] + (size_t)(o + i) * ws + o + k];
+    }
+    for (int64_t c = 0; c < a.n_chain; ++c) {
+      const int nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb;
+      acc += a.vals[a.chainS_off[c] + (size_t)(nx + i) * wc + nx + k];
+    }
+    B[e] = acc;
+  }
+  __syncthreads();
+  block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
+}
+
+// ---- solve ----------------------------------------------------------------------------------------------------
+__global__ void kkt_perm_in(const double* __restrict__ rhs, const int64_t* __restrict__ perm, const uint8_t* __restrict__ fixed,
+                            double* __restrict__ r, int64_t nu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nu) r[i] = fixed[perm[i]] ? 0.0 : rhs[perm[i]];
+}
+__global__ void kkt_perm_out(const double* __restrict__ r, const int64_t* __restrict__ perm, double* __restrict__ x, int64_t nu) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nu) x[perm[i]] = r[i];
+}
+
+__global__ void kkt_leaf_forward(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int64_t l = blockIdx.x;
+  const int m = (int)(a.leaf_ptr[l + 1] - a.leaf_ptr[l]);
+  const int64_t left = a.leaf_left[l];
+  const int w = nzb_of(a, left) + nzb_of(a, left + 1) + a.nb, ld = m + w;
+  const double* M = a.vals + a.leafA_off[l];
+  double* rl = a.r + a.leaf_ptr[l];
+  for (int i = tid; i < m; i += nt) lds[i] = rl[i];
+  __syncthreads();
+  double* g = a.leafG + a.leafG_off[l];
+  for (int c = tid; c < w; c += nt) {   // X_C^T r_l
+    double acc = 0.0;
+    for (int i = 0; i < m; ++i) acc += M[(size_t)i * ld + m + c] * lds[i];
+    g[c] = acc;
+  }
+  block_solve(M, m, ld, lds);
+  for (int i = tid; i < m; i += nt) rl[i] = lds[i];
+}
+
+__global__ void kkt_chain_forward(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  for (int64_t c = c0; c < c1; ++c) {
+    const int nz = nzb_of(a, c), nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb, ld = nz + wc;
+    const double* M = a.vals + a.chainD_off[c];
+    double* rc = a.r + a.base_chain + a.chain_ptr[c];
+    __syncthreads();
+    for (int i = tid; i < nz; i += nt) {
+      double v = rc[i];
+      if (c > c0) {
+        const int nl = nzb_of(a, c - 1);
+        v -= a.leafG[a.leafG_off[a.leaf_of_left[c - 1]] + nl + i];   // left leaf, R part
+        v -= a.chainG[a.chainG_off[c - 1] + i];                       // previous node, next-node part
+      }
+      if (!a.chain_last[c]) v -= a.leafG[a.leafG_off[a.leaf_of_left[c]] + i];   // right leaf, L part
+      lds[i] = v;
+    }
+    __syncthreads();
+    double* g = a.chainG + a.chainG_off[c];
+    for (int k = tid; k < wc; k += nt) {
+      double acc = 0.0;
+      for (int i = 0; i < nz; ++i) acc += M[(size_t)i * ld + nz + k] * lds[i];
+      g[k] = acc;
+    }
+    block_solve(M, nz, ld, lds);
+    for (int i = tid; i < nz; i += nt) rc[i] = lds[i];
+    __threadfence_block();
+  }
+}
+
+__global__ void kkt_border_solve(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  double* rb = a.r + a.base_border;
+  for (int i = tid; i < nb; i += nt) {
+    double v = rb[i];
+    for (int64_t l = 0; l < a.n_leaf; ++l) {
+      const int64_t left = a.leaf_left[l];
+      v -= a.leafG[a.leafG_off[l] + nzb_of(a, left) + nzb_of(a, left + 1) + i];
+    }
+    for (int64_t c = 0; c < a.n_chain; ++c) v -= a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + i];
+    lds[i] = v;
+  }
+  __syncthreads();
+  block_solve(a.vals + a.border_off, nb, nb, lds);
+  for (int i = tid; i < nb; i += nt) rb[i] = lds[i];
+}
+
+__global__ void kkt_chain_backward(KArgs a) {
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  const double* xb = a.r + a.base_border;
+  for (int64_t c = c1 - 1; c >= c0; --c) {
+    const int nz = nzb_of(a, c), nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb, ld = nz + wc;
+    const double* M = a.vals + a.chainD_off[c];
+    double* xc = a.r + a.base_chain + a.chain_ptr[c];
+    const double* xn = a.r + a.base_chain + a.chain_ptr[c] + nz;   // the next node's unknowns follow in block order
+    __syncthreads();
+    for (int i = tid; i < nz; i += nt) {
+      double v = xc[i];
+      for (int k = 0; k < nx; ++k) v -= M[(size_t)i * ld + nz + k] * xn[k];
+      for (int k = 0; k < nb; ++k) v -= M[(size_t)i * ld + nz + nx + k] * xb[k];
+      xc[i] = v;
+    }
+    __threadfence_block();
+  }
+}
+
+__global__ void kkt_leaf_backward(KArgs a) {
+  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  const int64_t l = blockIdx.x;
+  const int m = (int)(a.leaf_ptr[l + 1] - a.leaf_ptr[l]);
+  const int64_t left = a.leaf_left[l];
+  const int nl = nzb_of(a, left), nr = nzb_of(a, left + 1), w = nl + nr + nb, ld = m + w;
+  const double* M = a.vals + a.leafA_off[l];
+  double* xl = a.r + a.leaf_ptr[l];
+  const double* xL = a.r + a.base_chain + a.chain_ptr[left];
+  const double* xR = a.r + a.base_chain + a.chain_ptr[left + 1];
+  const double* xb = a.r + a.base_border;
+  for (int i = tid; i < m; i += nt) {
+    double v = xl[i];
+    const double* row = M + (size_t)i * ld + m;
+    for (int k = 0; k < nl; ++k) v -= row[k] * xL[k];
+    for (int k = 0; k < nr; ++k) v -= row[nl + k] * xR[k];
+    for (int k = 0; k < nb; ++k) v -= row[nl + nr + k] * xb[k];
+    xl[i] = v;
+  }
+}
+
+template <class F>
+int guarded(F&& f) {
+  try {
+    f();
+    return 1;
+  } catch (const std::exception& e) {
+    k_err = e.what();
+    return 0;
+  }
+}
+
+}  // namespace
+
+struct pc_kkt {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  const double* d_G = nullptr;
+  const double* d_H = nullptr;
+  int64_t nu = 0, n_dst = 0, total = 0;
+  int n_leaf = 0, n_chain = 0, n_phase = 0, nb = 0;
+  int lds_leaf = 0, lds_chain = 0, lds_border = 0;
+  Dev<double> vals, r, leafG, chainG, dvec, vin, vout, src_coef, mv_coef;
+  Dev<int64_t> perm, leaf_ptr, chain_ptr, chain_phase_ptr, leaf_left, leafA_off, leafS_off, chainD_off, chainS_off,
+      leaf_of_left, leafG_off, chainG_off, dst, run_ptr, diag_pos, mv_ptr;
+  Dev<int32_t> src_kind, src_idx, mv_col, mv_kind, mv_idx;
+  Dev<uint8_t> fixed, chain_last;
+  Dev<int> counts;
+  std::vector<int> h_counts;
+  KArgs args{};
+  bool factored = false;
+};
+
+extern "C" {
+
+const char* pc_kkt_last_error(void) { return k_err.c_str(); }
+
+int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hess, int device, pc_kkt** out) {
+  if (out) *out = nullptr;
+  pc_kkt* k = nullptr;
+  const int ok = guarded([&] {
+    if (!d || !out || !d_jac || !d_hess) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(device));
+    k = new pc_kkt();
+    k->device = device;
+    KHIP(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+    k->d_G = d_jac;
+    k->d_H = d_hess;
+    k->nu = d->nu;
+    k->n_leaf = (int)d->n_leaf;
+    k->n_chain = (int)d->n_chain;
+    k->n_phase = (int)d->n_phase;
+    k->nb = (int)d->nb;
+    k->n_dst = d->n_dst;
+    k->total = d->total_vals;
+    k->perm.upload(d->perm, d->nu);
+    k->leaf_ptr.upload(d->leaf_ptr, d->n_leaf + 1);
+    k->chain_ptr.upload(d->chain_ptr, d->n_chain + 1);
+    k->chain_phase_ptr.upload(d->chain_phase_ptr, d->n_phase + 1);
+    k->leaf_left.upload(d->leaf_left, d->n_leaf);
+    k->leafA_off.upload(d->leafA_off, d->n_leaf);
+    k->leafS_off.upload(d->leafS_off, d->n_leaf);
+    k->chainD_off.upload(d->chainD_off, d->n_chain);
+    k->chainS_off.upload(d->chainS_off, d->n_chain);
+    k->dst.upload(d->dst, d->n_dst);
+    k->run_ptr.upload(d->run_ptr, d->n_dst + 1);
+    k->src_kind.upload(d->src_kind, d->n_src);
+    k->src_idx.upload(d->src_idx, d->n_src);
+    k->src_coef.upload(d->src_coef, d->n_src);
+    k->diag_pos.upload(d->diag_pos, d->nu);
+    k->fixed.upload(d->fixed, d->nu);
+    k->mv_ptr.upload(d->mv_ptr, d->nu + 1);
+    k->mv_col.upload(d->mv_col, d->n_mv);
+    k->mv_kind.upload(d->mv_kind, d->n_mv);
+    k->mv_idx.upload(d->mv_idx, d->n_mv);
+    k->mv_coef.upload(d->mv_coef, d->n_mv);
+    // derived tables
+    std::vector<uint8_t> last(d->n_chain, 0);
+    for (int64_t p = 0; p < d->n_phase; ++p) last[d->chain_phase_ptr[p + 1] - 1] = 1;
+    std::vector<int64_t> leaf_of_left(d->n_chain, -1), leafG_off(d->n_leaf), chainG_off(d->n_chain);
+    int64_t og = 0, mmax = 1, wmax = 1, nzmax = 1, wcmax = 1;
+    for (int64_t l = 0; l < d->n_leaf; ++l) {
+      const int64_t left = d->leaf_left[l];
+      leaf_of_left[left] = l;
+      const int64_t m = d->leaf_ptr[l + 1] - d->leaf_ptr[l];
+      const int64_t w = (d->chain_ptr[left + 1] - d->chain_ptr[left]) + (d->chain_ptr[left + 2] - d->chain_ptr[left + 1]) + d->nb;
+      leafG_off[l] = og;
+      og += w;
+      mmax = std::max(mmax, m);
+      wmax = std::max(wmax, w);
+    }
+    k->leafG.alloc((size_t)std::max<int64_t>(1, og));
+    og = 0;
+    for (int64_t c = 0; c < d->n_chain; ++c) {
+      const int64_t nz = d->chain_ptr[c + 1] - d->chain_ptr[c];
+      const int64_t nx = last[c] ? 0 : d->chain_ptr[c + 2] - d->chain_ptr[c + 1];
+      if (!last[c] && leaf_of_left[c] < 0) throw std::runtime_error("chain node without a leaf on its right");
+      chainG_off[c] = og;
+      og += nx + d->nb;
+      nzmax = std::max(nzmax, nz);
+      wcmax = std::max(wcmax, nx + d->nb);
+    }
+    k->chainG.alloc((size_t)std::max<int64_t>(1, og));
+    k->chain_last.upload(last.data(), last.size());
+    k->leaf_of_left.upload(leaf_of_left.data(), leaf_of_left.size());
+    k->leafG_off.upload(leafG_off.data(), leafG_off.size());
+    k->chainG_off.upload(chainG_off.data(), chainG_off.size());
+    k->lds_leaf = (int)(8 * (2 * mmax + wmax + 2));
+    k->lds_chain = (int)(8 * (2 * nzmax + wcmax + 2));
+    k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2));
+    if (k->lds_leaf > 60000 || k->lds_chain > 60000 || k->lds_border > 60000)
+      throw std::runtime_error("KKT block too large for the solver's LDS staging");
+    k->vals.alloc((size_t)d->total_vals);
+    k->r.alloc((size_t)d->nu);
+    k->dvec.alloc((size_t)d->nu);
+    k->vin.alloc((size_t)d->nu);
+    k->vout.alloc((size_t)d->nu);
+    k->counts.alloc((size_t)2 * (d->n_leaf + d->n_chain + 1));
+    k->h_counts.resize((size_t)2 * (d->n_leaf + d->n_chain + 1));
+    KArgs& a = k->args;
+    a.vals = k->vals.p;
+    a.leaf_ptr = k->leaf_ptr.p; a.chain_ptr = k->chain_ptr.p; a.chain_phase_ptr = k->chain_phase_ptr.p;
+    a.leaf_left = k->leaf_left.p; a.leafA_off = k->leafA_off.p; a.leafS_off = k->leafS_off.p;
+    a.chainD_off = k->chainD_off.p; a.chainS_off = k->chainS_off.p;
+    a.leaf_of_left = k->leaf_of_left.p; a.chain_last = k->chain_last.p;
+    a.border_off = d->border_off;
+    a.base_chain = d->leaf_ptr[d->n_leaf];
+    a.base_border = a.base_chain + d->chain_ptr[d->n_chain];
+    a.nb = (int32_t)d->nb; a.n_leaf = (int32_t)d->n_leaf; a.n_chain = (int32_t)d->n_chain;
+    a.counts = k->counts.p;
+    a.r = k->r.p; a.leafG = k->leafG.p; a.chainG = k->chainG.p;
+    a.leafG_off = k->leafG_off.p; a.chainG_off = k->chainG_off.p;
+  });
+  if (!ok) {
+    delete k;
+    return 0;
+  }
+  *out = k;
+  return 1;
+}
+
+void pc_kkt_destroy(pc_kkt* k) {
+  if (!k) return;
+  (void)hipSetDevice(k->device);
+  if (k->stream) {
+    (void)hipStreamSynchronize(k->stream);
+    (void)hipStreamDestroy(k->stream);
+  }
+  delete k;
+}
+
+int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, int32_t* n_neg) {
+  return guarded([&] {
+    if (!k || !dvec) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    KHIP(hipMemcpyAsync(k->dvec.p, dvec, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemsetAsync(k->vals.p, 0, (size_t)k->total * sizeof(double), st));
+    if (k->n_dst)
+      hipLaunchKernelGGL(kkt_scatter, dim3((unsigned)((k->n_dst + 255) / 256)), dim3(256), 0, st, k->vals.p, k->dst.p, k->run_ptr.p,
+                         k->src_kind.p, k->src_idx.p, k->src_coef.p, k->d_G, k->d_H, use_hess, k->n_dst);
+    hipLaunchKernelGGL(kkt_diag, dim3((unsigned)((k->nu + 255) / 256)), dim3(256), 0, st, k->vals.p, k->diag_pos.p, k->fixed.p,
+                       k->dvec.p, k->nu);
+    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
+    hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+    hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
+    KHIP(hipGetLastError());
+    KHIP(hipMemcpyAsync(k->h_counts.data(), k->counts.p, k->h_counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    int64_t p = 0, q = 0;
+    for (size_t i = 0; i < k->h_counts.size(); i += 2) {
+      p += k->h_counts[i];
+      q += k->h_counts[i + 1];
+    }
+    if (n_pos) *n_pos = (int32_t)p;
+    if (n_neg) *n_neg = (int32_t)q;
+    k->factored = true;
+  });
+}
+
+int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
+  return guarded([&] {
+    if (!k || !rhs || !x) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_solve before pc_kkt_factor");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    const unsigned nbk = (unsigned)((k->nu + 255) / 256);
+    KHIP(hipMemcpyAsync(k->vin.p, rhs, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, k->vin.p, k->perm.p, k->fixed.p, k->r.p, k->nu);
+    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
+    hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+    hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(64), k->lds_border, st, k->args);
+    hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
+    hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, k->vout.p, k->nu);
+    KHIP(hipGetLastError());
+    KHIP(hipMemcpyAsync(x, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+  });
+}
+
+int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, double* y) {
+  return guarded([&] {
+    if (!k || !dvec || !x || !y) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    KHIP(hipMemcpyAsync(k->dvec.p, dvec, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(k->vin.p, x, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    const int64_t threads = k->nu * 64;
+    hipLaunchKernelGGL(kkt_matvec, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k->mv_ptr.p, k->mv_col.p, k->mv_kind.p,
+                       k->mv_idx.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, k->dvec.p, k->vin.p, k->vout.p, k->nu);
+    KHIP(hipGetLastError());
+    KHIP(hipMemcpyAsync(y, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+  });
+}
+
+}  // extern "C"

@@ -99,6 +99,7 @@ def load_library() -> C.CDLL:
     lib.pc_eval_jac_g.argtypes = [vp, vp, C.c_int, vp]
     lib.pc_eval_h.argtypes = [vp, vp, C.c_int, C.c_double, vp, C.c_int, vp]
     lib.pc_eval_all.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.pc_eval_resident.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
     lib.pc_host_buffers.argtypes = [vp] + [C.POINTER(vp)] * 5
     lib.pc_set_host_mode.argtypes = [vp, C.c_int]
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -379,6 +380,18 @@ class NlpEngine:
         """0: one DMA copy up / down; 1: kernels read x~, lambda from pinned host memory; 2: kernels write c~, G~, H~
         to pinned host memory; 3: both (``pc_set_host_mode``)."""
         self._check(self._lib.pc_set_host_mode(self._h, int(mode)))
+
+    def evaluate_resident(self, x, obj_factor=1.0, lagrange=None, want_grad=True):
+        """Evaluate and LEAVE c~, G~ (and H~ when ``lagrange`` is given) in device memory for the GPU KKT solver
+        (``pycollo_amd.kkt.GpuKkt``); returns the small results ``(J, grad J or None, c~)``."""
+        x = self._x(x)
+        lam = None if lagrange is None else np.ascontiguousarray(lagrange, dtype=np.float64).reshape(-1)
+        f = C.c_double()
+        grad = np.empty(self.num_x) if want_grad else None
+        c = np.empty(self.num_c)
+        self._check(self._lib.pc_eval_resident(self._h, x.ctypes.data, float(obj_factor), None if lam is None else lam.ctypes.data,
+                                               C.addressof(f), None if grad is None else grad.ctypes.data, c.ctypes.data))
+        return f.value, grad, c
 
     def G_row_norms(self, x):
         x = self._x(x)

@@ -1,0 +1,366 @@
+"""Symbolic side of the GPU KKT solve.
+
+What it replaces: the sparse symmetric-indefinite factorisation inside IPOPT -- MUMPS by default -- that the reference
+selects by name only (``linear_solver``, pycollo/backend.py:1703-1711, pycollo/settings.py:49-59).  One interior-point
+iteration solves
+
+    [ W + Sigma + dw I    J^T   ] [dv  ]   [r1]
+    [ J                 -dc I   ] [dlam] = [r2]
+
+with W = the Lagrangian Hessian H~, J = the constraint Jacobian G~ (plus -1 columns of the slacks of inequality rows).
+The matrix is *quasi-definite* whenever the (1,1) block is positive definite, so L D L^T exists for every symmetric
+ordering with 1 x 1 pivots, and the signs of D are the inertia IPOPT's regularisation is driven by.  That freedom is
+spent on the collocation structure (no fill-reducing heuristic, no pivot search):
+
+  leaf (p, k)     the interior nodes of mesh section k of phase p: their z, path slacks and path multipliers, and the
+                  defect multipliers of the rows that end on those nodes.  Leaves touch each other only through
+                  separators, so all K leaves are eliminated at once (one workgroup each).
+  chain node      a section boundary node (its z, path slacks / multipliers) and the defect multipliers of the section
+  (p, k)          rows that end on it.  After the leaves are gone the boundary nodes of a phase form a block-tridiagonal
+                  chain, eliminated in order by one workgroup per phase.
+  border          everything global: integrals q, free times, static parameters, integral and endpoint multipliers,
+                  endpoint slacks, and any endpoint variable an endpoint Hessian term couples across nodes.  Dense,
+                  factorised last.
+
+Every defect multiplier sits with the node its row ends on, i.e. next to the -W V entry that pairs it with that node's
+state, so no block's multiplier part rests on the -dc I regularisation alone.
+
+This module only builds index tables (NumPy); the numeric work is in ``csrc/pc_kkt.hip`` (``pc_kkt_*`` in
+include/pycollo_amd.h).  ``oracle/ref_kkt.py`` holds a NumPy execution of the same tables for the tests.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+LEAF, CHAIN, BORDER = 0, 1, 2
+SRC_G, SRC_H, SRC_ONE = 0, 1, 2
+
+
+@dataclass
+class KktTables:
+    """Everything ``pc_kkt_create`` needs, as flat arrays (see ``pc_kkt_desc`` in include/pycollo_amd.h)."""
+    nu: int                      # unknowns: nv primal (x, slacks) then m multipliers, natural order
+    nv: int
+    n_leaf: int
+    n_chain: int
+    n_phase: int
+    nb: int                      # border size
+    n_primal: int                # expected positive pivots (unit pivots of fixed unknowns included)
+    n_dual: int                  # expected negative pivots
+    # unknown -> block
+    perm: np.ndarray             # [nu] natural index of every unknown in block order: leaves, chain nodes, border
+    leaf_ptr: np.ndarray         # [n_leaf + 1] into perm
+    chain_ptr: np.ndarray        # [n_chain + 1] into perm (offset by leaf_ptr[-1])
+    chain_phase_ptr: np.ndarray  # [n_phase + 1] chain nodes of every phase (consecutive)
+    leaf_left: np.ndarray        # [n_leaf] chain node on the left of a leaf; the right one is left + 1
+    # value buffer layout (doubles)
+    leafA_off: np.ndarray        # [n_leaf] A | C of a leaf, row stride m + w
+    leafS_off: np.ndarray        # [n_leaf] Schur block of a leaf, w x w
+    chainD_off: np.ndarray       # [n_chain] D | E | F of a chain node, row stride nzb + nzb_next + nb
+    chainS_off: np.ndarray       # [n_chain] Schur block of a chain node, (nzb_next + nb)^2
+    border_off: int
+    total_vals: int
+    # scatter recipe: destination runs
+    dst: np.ndarray              # [n_dst] int64 position in the value buffer
+    run_ptr: np.ndarray          # [n_dst + 1]
+    src_kind: np.ndarray         # [n_src] int32 SRC_*
+    src_idx: np.ndarray          # [n_src] int32 index into G~ / H~ values
+    src_coef: np.ndarray         # [n_src] double
+    diag_pos: np.ndarray         # [nu] position of every unknown's diagonal entry (natural order)
+    fixed: np.ndarray            # [nu] uint8
+    # full symmetric matrix as CSR over natural unknowns, for products K x (refinement, J^T lambda)
+    mv_ptr: np.ndarray
+    mv_col: np.ndarray
+    mv_kind: np.ndarray
+    mv_idx: np.ndarray
+    mv_coef: np.ndarray
+
+
+def _node_maps(engine):
+    """Per phase: section starts, node -> (is boundary, section index)."""
+    out = []
+    for mesh in engine.meshes:
+        s = np.asarray(mesh.s, dtype=np.int64)
+        N = int(s[-1]) + 1
+        is_b = np.zeros(N, bool)
+        is_b[s] = True
+        sec = np.searchsorted(s, np.arange(N), side="right") - 1      # section whose start <= node
+        out.append((s, N, is_b, sec))
+    return out
+
+
+def build_tables(engine, ineq_rows, fixed_v, row_scale) -> KktTables:
+    """``ineq_rows``: constraint rows with a slack (in order); ``fixed_v`` [n + ns]: primal unknowns held fixed;
+    ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise)."""
+    lay, model = engine.layout, engine.model
+    n, m = engine.num_x, engine.num_c
+    ineq_rows = np.asarray(ineq_rows, dtype=np.int64)
+    ns = len(ineq_rows)
+    nv, nu = n + ns, n + ns + m
+    fixed = np.zeros(nu, bool)
+    fixed[:nv] = np.asarray(fixed_v, bool)
+    maps = _node_maps(engine)
+    n_phase = len(lay.phases)
+    chain_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) for mp in maps])]).astype(np.int64)
+    leaf_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) - 1 for mp in maps])]).astype(np.int64)
+    n_chain, n_leaf = int(chain_phase_ptr[-1]), int(leaf_phase_ptr[-1])
+
+    cls = np.full(nu, BORDER, np.int8)
+    blk = np.zeros(nu, np.int64)
+    key_node = np.zeros(nu, np.int64)      # ordering inside a block: primal before dual, then node, kind, index
+    key_kind = np.zeros(nu, np.int64)
+    key_idx = np.arange(nu, dtype=np.int64)
+    dual = np.zeros(nu, bool)
+    dual[nv:] = True
+
+    def place_nodes(u, ip, nodes):
+        s, N, is_b, sec = maps[ip]
+        b = is_b[nodes]
+        cls[u] = np.where(b, CHAIN, LEAF)
+        blk[u] = np.where(b, chain_phase_ptr[ip] + sec[nodes], leaf_phase_ptr[ip] + sec[nodes])
+        key_node[u] = nodes
+
+    row_slack = np.full(m, -1, np.int64)
+    row_slack[ineq_rows] = np.arange(ns)
+    for ip, (pl, pm) in enumerate(zip(lay.phases, model.phases)):
+        s, N, is_b, sec = maps[ip]
+        nz = pm.n_z
+        u = pl.x_off + np.arange(nz * N, dtype=np.int64)
+        place_nodes(u, ip, (u - pl.x_off) % N)
+        key_kind[u] = 0
+        # defect rows: the row of node i >= 1 goes with node i
+        for a in range(pm.n_y):
+            rows = pl.c_off + a * (N - 1) + np.arange(N - 1, dtype=np.int64)
+            place_nodes(nv + rows, ip, np.arange(1, N, dtype=np.int64))
+            key_kind[nv + rows] = 1
+        for mm in range(pm.n_p):
+            rows = pl.c_path_off + mm * N + np.arange(N, dtype=np.int64)
+            place_nodes(nv + rows, ip, np.arange(N, dtype=np.int64))
+            key_kind[nv + rows] = 0
+            sl = row_slack[rows]
+            has = sl >= 0
+            if has.any():
+                place_nodes(n + sl[has], ip, np.arange(N, dtype=np.int64)[has])
+                key_kind[n + sl[has]] = 1
+    # endpoint Hessian terms that couple two different nodes: both variables move to the border
+    hr, hc = (np.asarray(a, np.int64) for a in engine.evaluate_H_structure())
+    both_node = (cls[hr] != BORDER) & (cls[hc] != BORDER)
+    cross = both_node & ((cls[hr] != cls[hc]) | (blk[hr] != blk[hc]))
+    promoted = np.unique(np.concatenate([hr[cross], hc[cross]]))
+    cls[promoted] = BORDER
+    blk[cls == BORDER] = 0
+    key_node[cls == BORDER] = 0
+    # block order
+    order = np.lexsort((key_idx, key_kind, key_node, dual, blk, cls))
+    perm = order.astype(np.int64)
+    counts_leaf = np.bincount(blk[cls == LEAF], minlength=n_leaf) if n_leaf else np.zeros(0, np.int64)
+    counts_chain = np.bincount(blk[cls == CHAIN], minlength=n_chain)
+    leaf_ptr = np.concatenate([[0], np.cumsum(counts_leaf)]).astype(np.int64)
+    chain_ptr = np.concatenate([[0], np.cumsum(counts_chain)]).astype(np.int64)
+    nb = int(np.sum(cls == BORDER))
+    local = np.empty(nu, np.int64)          # index inside its block
+    pos = np.empty(nu, np.int64)
+    pos[perm] = np.arange(nu)
+    base_leaf, base_chain = 0, int(leaf_ptr[-1])
+    base_border = base_chain + int(chain_ptr[-1])
+    is_leaf, is_chain, is_border = cls == LEAF, cls == CHAIN, cls == BORDER
+    local[is_leaf] = pos[is_leaf] - base_leaf - leaf_ptr[blk[is_leaf]]
+    local[is_chain] = pos[is_chain] - base_chain - chain_ptr[blk[is_chain]]
+    local[is_border] = pos[is_border] - base_border
+
+    leaf_left = np.concatenate([chain_phase_ptr[ip] + np.arange(len(maps[ip][0]) - 1) for ip in range(n_phase)]).astype(np.int64) \
+        if n_leaf else np.zeros(0, np.int64)
+    nzb = counts_chain.astype(np.int64)
+    last_of_phase = np.zeros(n_chain, bool)
+    last_of_phase[chain_phase_ptr[1:] - 1] = True
+    nzb_next = np.where(last_of_phase, 0, np.concatenate([nzb[1:], [0]]))
+    m_l = counts_leaf.astype(np.int64)
+    w_l = (nzb[leaf_left] + nzb[leaf_left + 1] + nb) if n_leaf else np.zeros(0, np.int64)
+    # value buffer layout
+    sizeA = m_l * (m_l + w_l)
+    sizeS = w_l * w_l
+    leafA_off = np.concatenate([[0], np.cumsum(sizeA)])[:-1] if n_leaf else np.zeros(0, np.int64)
+    o = int(np.sum(sizeA))
+    leafS_off = o + (np.concatenate([[0], np.cumsum(sizeS)])[:-1] if n_leaf else np.zeros(0, np.int64))
+    o += int(np.sum(sizeS))
+    wc = nzb_next + nb
+    sizeD = nzb * (nzb + wc)
+    chainD_off = o + np.concatenate([[0], np.cumsum(sizeD)])[:-1]
+    o += int(np.sum(sizeD))
+    chainS_off = o + np.concatenate([[0], np.cumsum(wc * wc)])[:-1]
+    o += int(np.sum(wc * wc))
+    border_off = o
+    total = o + nb * nb
+
+    # ---- matrix entries (natural unknown pairs), lower triangle of K ------------------------------------------
+    jr, jc = (np.asarray(a, np.int64) for a in engine.evaluate_G_structure())
+    eu = np.concatenate([hr, nv + jr, nv + ineq_rows])
+    ev = np.concatenate([hc, jc, n + np.arange(ns, dtype=np.int64)])
+    ekind = np.concatenate([np.full(len(hr), SRC_H), np.full(len(jr), SRC_G), np.full(ns, SRC_ONE)]).astype(np.int32)
+    eidx = np.concatenate([np.arange(len(hr)), np.arange(len(jr)), np.zeros(ns, np.int64)]).astype(np.int64)
+    ecoef = np.concatenate([np.ones(len(hr)), np.asarray(row_scale, float)[jr], -np.ones(ns)])
+    keep = ~(fixed[eu] | fixed[ev])
+    eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
+
+    def dest(u, v):
+        """Position in the value buffer of K[u, v] (u, v natural), vectorised; -1 where the pair has no place."""
+        cu, cv = cls[u], cls[v]
+        # order the pair so that `a` is the one eliminated first: leaf < chain < border; inside a class lower block first
+        swap = (cu > cv) | ((cu == cv) & (blk[u] > blk[v])) | ((cu == cv) & (blk[u] == blk[v]) & (local[u] < local[v]))
+        a, b = np.where(swap, v, u), np.where(swap, u, v)
+        ca, cb, ba, bb, la, lb = cls[a], cls[b], blk[a], blk[b], local[a], local[b]
+        out = np.full(len(u), -1, np.int64)
+        # leaf x leaf (same leaf): lower triangle of A (a has the larger local index after the swap rule above)
+        k = (ca == LEAF) & (cb == LEAF) & (ba == bb)
+        out[k] = leafA_off[ba[k]] + la[k] * (m_l[ba[k]] + w_l[ba[k]]) + lb[k]
+        # leaf x chain
+        k = (ca == LEAF) & (cb == CHAIN)
+        left = leaf_left[ba[k]]
+        col = np.where(bb[k] == left, lb[k], np.where(bb[k] == left + 1, nzb[left] + lb[k], -1))
+        ok = col >= 0
+        tmp = np.full(int(k.sum()), -1, np.int64)
+        tmp[ok] = leafA_off[ba[k]][ok] + la[k][ok] * (m_l[ba[k]] + w_l[ba[k]])[ok] + m_l[ba[k]][ok] + col[ok]
+        out[k] = tmp
+        # leaf x border
+        k = (ca == LEAF) & (cb == BORDER)
+        left = leaf_left[ba[k]]
+        out[k] = leafA_off[ba[k]] + la[k] * (m_l[ba[k]] + w_l[ba[k]]) + m_l[ba[k]] + nzb[left] + nzb[left + 1] + lb[k]
+        # chain x chain
+        k = (ca == CHAIN) & (cb == CHAIN) & (ba == bb)
+        out[k] = chainD_off[ba[k]] + la[k] * (nzb[ba[k]] + wc[ba[k]]) + lb[k]
+        k = (ca == CHAIN) & (cb == CHAIN) & (bb == ba + 1) & ~last_of_phase[ba]
+        out[k] = chainD_off[ba[k]] + la[k] * (nzb[ba[k]] + wc[ba[k]]) + nzb[ba[k]] + lb[k]
+        # chain x border
+        k = (ca == CHAIN) & (cb == BORDER)
+        out[k] = chainD_off[ba[k]] + la[k] * (nzb[ba[k]] + wc[ba[k]]) + nzb[ba[k]] + nzb_next[ba[k]] + lb[k]
+        # border x border, lower
+        k = (ca == BORDER) & (cb == BORDER)
+        out[k] = border_off + la[k] * nb + lb[k]
+        return out
+
+    d = dest(eu, ev)
+    if np.any(d < 0):
+        bad = np.nonzero(d < 0)[0][0]
+        raise RuntimeError(f"KKT entry ({eu[bad]}, {ev[bad]}) couples two blocks the elimination order keeps apart")
+    so = np.argsort(d, kind="stable")
+    d_sorted = d[so]
+    first = np.concatenate([[True], d_sorted[1:] != d_sorted[:-1]])
+    dst = d_sorted[first]
+    run_ptr = np.concatenate([np.nonzero(first)[0], [len(d_sorted)]]).astype(np.int64)
+    diag_pos = dest(np.arange(nu, dtype=np.int64), np.arange(nu, dtype=np.int64))
+
+    # ---- full symmetric CSR over natural unknowns (products) ----------------------------------------------------
+    off = eu != ev
+    ru = np.concatenate([eu, ev[off]])
+    rv = np.concatenate([ev, eu[off]])
+    rk = np.concatenate([ekind, ekind[off]])
+    ri = np.concatenate([eidx, eidx[off]])
+    rc = np.concatenate([ecoef, ecoef[off]])
+    o2 = np.lexsort((rv, ru))
+    mv_ptr = np.concatenate([[0], np.cumsum(np.bincount(ru, minlength=nu))]).astype(np.int64)
+
+    return KktTables(
+        nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=nv, n_dual=m,
+        perm=perm, leaf_ptr=leaf_ptr, chain_ptr=chain_ptr, chain_phase_ptr=chain_phase_ptr, leaf_left=leaf_left,
+        leafA_off=np.asarray(leafA_off, np.int64), leafS_off=np.asarray(leafS_off, np.int64),
+        chainD_off=np.asarray(chainD_off, np.int64), chainS_off=np.asarray(chainS_off, np.int64),
+        border_off=int(border_off), total_vals=int(total),
+        dst=dst.astype(np.int64), run_ptr=run_ptr, src_kind=ekind[so].astype(np.int32), src_idx=eidx[so].astype(np.int32),
+        src_coef=ecoef[so].astype(np.float64), diag_pos=diag_pos.astype(np.int64), fixed=fixed.astype(np.uint8),
+        mv_ptr=mv_ptr, mv_col=rv[o2].astype(np.int32), mv_kind=rk[o2].astype(np.int32), mv_idx=ri[o2].astype(np.int32),
+        mv_coef=rc[o2].astype(np.float64))
+
+
+class _Desc(C.Structure):
+    _i64p, _i32p, _f64p, _u8p = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    _fields_ = ([(k, C.c_int64) for k in ("nu", "nv", "n_leaf", "n_chain", "n_phase", "nb", "total_vals", "border_off",
+                                          "n_dst", "n_src", "n_mv")]
+                + [(k, C.POINTER(C.c_int64)) for k in ("perm", "leaf_ptr", "chain_ptr", "chain_phase_ptr", "leaf_left",
+                                                       "leafA_off", "leafS_off", "chainD_off", "chainS_off", "dst", "run_ptr")]
+                + [("src_kind", C.POINTER(C.c_int32)), ("src_idx", C.POINTER(C.c_int32)), ("src_coef", C.POINTER(C.c_double)),
+                   ("diag_pos", C.POINTER(C.c_int64)), ("fixed", C.POINTER(C.c_uint8)), ("mv_ptr", C.POINTER(C.c_int64)),
+                   ("mv_col", C.POINTER(C.c_int32)), ("mv_kind", C.POINTER(C.c_int32)), ("mv_idx", C.POINTER(C.c_int32)),
+                   ("mv_coef", C.POINTER(C.c_double))])
+
+
+class GpuKkt:
+    """The factorisation object: ``pc_kkt_*`` bound to one engine's device-resident G~ / H~."""
+
+    def __init__(self, engine, ineq_rows, fixed_v, row_scale):
+        from .engine import load_library
+        if engine.device < 0:
+            raise RuntimeError("the KKT solver needs a GPU engine; pycollo_amd has no CPU fallback")
+        self.engine = engine
+        self.tables = T = build_tables(engine, ineq_rows, fixed_v, row_scale)
+        self._lib = lib = load_library()
+        vp = C.c_void_p
+        lib.pc_kkt_last_error.restype = C.c_char_p
+        lib.pc_kkt_create.argtypes = [C.POINTER(_Desc), vp, vp, C.c_int, C.POINTER(vp)]
+        lib.pc_kkt_destroy.argtypes = [vp]
+        lib.pc_kkt_destroy.restype = None
+        lib.pc_kkt_factor.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.pc_kkt_solve.argtypes = [vp, vp, vp]
+        lib.pc_kkt_matvec.argtypes = [vp, C.c_int, vp, vp, vp]
+        lib.pc_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        d = _Desc()
+        self._keep = []
+        for k in ("nu", "nv", "n_leaf", "n_chain", "n_phase", "nb", "total_vals", "border_off"):
+            setattr(d, k, int(getattr(T, k)))
+        d.n_dst, d.n_src, d.n_mv = len(T.dst), len(T.src_kind), len(T.mv_col)
+        for k, typ in (("perm", np.int64), ("leaf_ptr", np.int64), ("chain_ptr", np.int64), ("chain_phase_ptr", np.int64),
+                       ("leaf_left", np.int64), ("leafA_off", np.int64), ("leafS_off", np.int64), ("chainD_off", np.int64),
+                       ("chainS_off", np.int64), ("dst", np.int64), ("run_ptr", np.int64), ("src_kind", np.int32),
+                       ("src_idx", np.int32), ("src_coef", np.float64), ("diag_pos", np.int64), ("fixed", np.uint8),
+                       ("mv_ptr", np.int64), ("mv_col", np.int32), ("mv_kind", np.int32), ("mv_idx", np.int32),
+                       ("mv_coef", np.float64)):
+            arr = np.ascontiguousarray(getattr(T, k), dtype=typ)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=typ)
+            self._keep.append(arr)
+            ctype = {np.int64: C.c_int64, np.int32: C.c_int32, np.float64: C.c_double, np.uint8: C.c_uint8}[typ]
+            setattr(d, k, arr.ctypes.data_as(C.POINTER(ctype)))
+        dg, dj, dh = vp(), vp(), vp()
+        if not lib.pc_device_results(engine._h, C.byref(dg), C.byref(dj), C.byref(dh)):
+            raise RuntimeError(lib.pc_last_error().decode())
+        self._h = vp()
+        if not lib.pc_kkt_create(C.byref(d), dj, dh, int(engine.device), C.byref(self._h)):
+            raise RuntimeError("pc_kkt_create failed: " + lib.pc_kkt_last_error().decode())
+        self.nu = T.nu
+
+    def _check(self, ok):
+        if not ok:
+            raise RuntimeError(self._lib.pc_kkt_last_error().decode())
+
+    def factor(self, dvec, use_hess=True):
+        """Assemble from the engine's current device G~ / H~ and factorise; returns (n_pos, n_neg) pivots."""
+        dvec = np.ascontiguousarray(dvec, dtype=np.float64)
+        p, q = C.c_int32(), C.c_int32()
+        self._check(self._lib.pc_kkt_factor(self._h, int(bool(use_hess)), dvec.ctypes.data, C.byref(p), C.byref(q)))
+        return p.value, q.value
+
+    def solve(self, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.empty(self.nu)
+        self._check(self._lib.pc_kkt_solve(self._h, rhs.ctypes.data, x.ctypes.data))
+        return x
+
+    def matvec(self, dvec, x, use_hess=True):
+        dvec = np.ascontiguousarray(dvec, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty(self.nu)
+        self._check(self._lib.pc_kkt_matvec(self._h, int(bool(use_hess)), dvec.ctypes.data, x.ctypes.data, y.ctypes.data))
+        return y
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pc_kkt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
