@@ -295,7 +295,11 @@ def main():
         d_batches = sorted(timed_batch(step) for _ in range(n_batches))
         dev_step_ms = d_batches[n_batches // 2]
         del blk
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+        # One launch per evaluation (resident tail): the dominant kernel IS the evaluation, pc_bulk_p0_r / pc_bulk_all_r,
+        # and its launch time is the device time per step; the tile-only kernel is reported beside it.
+        one_launch = world == 1 and extra.get("launches_per_eval") == 1
+        kname = ("pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0") + ("_r" if one_launch else "")
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process); only quoted when the workload is the one those passes profiled
         traffic = None
         traffic_source = None
@@ -306,16 +310,12 @@ def main():
                 pmc = json.load(f)
             for entry in pmc.values():
                 if world == 1 and isinstance(entry, dict) and entry.get("workload") == workload:
-                    traffic = sum(k.get("hbm_bytes_per_launch", 0) for name, k in entry["kernels"].items()
-                                  if name.startswith("pc_bulk")) or None
-                    traffic_source = (f"profiles/{os.path.basename(latest)} (separate rocprofv3 --pmc passes over this "
-                                      f"workload; not measured by this run)")
+                    traffic = entry["kernels"].get(kname, {}).get("hbm_bytes_per_launch")
+                    if traffic:
+                        traffic_source = (f"profiles/{os.path.basename(latest)} (separate rocprofv3 --pmc passes over this "
+                                          f"workload; not measured by this run)")
         except (OSError, IndexError):
             pass
-        # One launch per evaluation (resident tail): the dominant kernel IS the evaluation, pc_bulk_p0_r / pc_bulk_all_r,
-        # and its launch time is the device time per step; the tile-only kernel is reported beside it.
-        one_launch = world == 1 and extra.get("launches_per_eval") == 1
-        kname = ("pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0") + ("_r" if one_launch else "")
         dom_ms = dev_step_ms if one_launch else k_ms
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -163,6 +163,10 @@ int pc_host_buffers(pc_handle* h, double** x, double** lambda, double** g, doubl
  * (no copy up), bit 1 = the kernels write their results straight into the pinned host block (no copy down).
  * 0 = one DMA copy up, one down (default; PYCOLLO_AMD_HOST_MODE overrides at pc_create). */
 int pc_set_host_mode(pc_handle* h, int mode);
+/* 1 (default): the first callback at a new point also starts the copy of jac_g to the host, which IPOPT asks for
+ * next; 0: jac_g stays in device memory until pc_eval_jac_g is called (a solver whose linear algebra runs on the
+ * GPU, pc_kkt_*, never asks) */
+int pc_set_prefetch_jac(pc_handle* h, int on);
 /* same with every vector resident in device memory; asynchronous on `stream` (hipStream_t, NULL =
  * the handle's stream).  No host synchronisation is performed. */
 int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda,

@@ -261,7 +261,7 @@ def generate_source(model: Model, orders=None) -> str:
         # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}({lead_sig}, PcPhaseArgs a) {{')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, nullptr, 0, -1, &ld);')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, false, 0, -1, &ld);')
         parts.append('}')
     if len(model.phases) == 1:
         pm = model.phases[0]
@@ -270,7 +270,7 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs)); return; }')
         parts.append('  if ((int)threadIdx.x >= (((wa >> 12) & 0xf) << 6)) return;   // launch widened for the tail block only')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, nullptr, 0, pc::xcd_major((int)blockIdx.x - 1, n_blocks), &ld);')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - 1, n_blocks), &ld);')
         parts.append('}')
     else:
         np_ = len(model.phases)
@@ -278,20 +278,26 @@ def generate_source(model: Model, orders=None) -> str:
         def all_body(res: bool):
             out = []
             blk = "(int)blockIdx.x - 1" if res else "(int)blockIdx.x"
-            out.append(f"  const int b = pc::xcd_major({blk}, m.first_block[{np_}]);")
+            out.append(f"  const int b = pc::xcd_major({blk}, fb{np_});")
             for i, pm in enumerate(model.phases):
-                cond = f"if (b < m.first_block[{i + 1}]) " if i + 1 < np_ else ""
+                cond = f"if (b < fb{i + 1}) " if i + 1 < np_ else ""
                 out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {'true' if res else 'false'}>"
-                           f"(m.ph[{i}], &m, m.first_block[{i}], b); return; }}")
+                           f"(ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch); return; }}")
             return out
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
-        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(PcMultiArgs m) {')
+        # The members of PcMultiArgs travel as separate scalar parameters (same order, same offsets: the host still
+        # hands over the struct) and reach pc::bulk as values: as ONE by-value struct whose address is passed on, a
+        # large kernel keeps it in scratch memory (seen: 112 B per lane, a scratch set-up on every wave of the launch).
+        multi_sig = ("const double* x, const double* lam, double* c, double* G, double* H, const PcPhaseArgs* ph, int flags, "
+                     "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tile_threads")
+        parts.append("static_assert(PC_MAX_PHASES + 1 == 9, \"pc_bulk_all spells PcMultiArgs::first_block out\");")
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(' + multi_sig + ') {')
         parts += all_body(False)
         parts.append("}")
         parts.append("// the same with the resident tail as block 0")
-        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(PcMultiArgs m, PcTailArgs t) {')
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(' + multi_sig + ', PcTailArgs t) {')
         parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7)); return; }')
-        parts.append('  if ((int)threadIdx.x >= m.tile_threads) return;   // launch widened for the tail block only')
+        parts.append('  if ((int)threadIdx.x >= tile_threads) return;   // launch widened for the tail block only')
         parts += all_body(True)
         parts.append("}")
     parts.append("")

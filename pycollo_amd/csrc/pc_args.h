@@ -10,7 +10,6 @@
 #define PC_FLAG_G 2
 #define PC_FLAG_H 4
 
-#define PC_EDGE_WORDS 4     // 128 edge-node Hessian entry sites per phase and edge (more: no resident tail)
 #define PC_MAX_GOFF 32
 #define PC_MAX_HOFF 96
 #define PC_MAX_SCAL 96
@@ -50,11 +49,11 @@ struct PcPhaseArgs {
   int32_t spt;            // sections per tile when uniform
   int32_t lds_out;        // doubles of the output staging buffer
   uint32_t epoch;         // tag of this launch's granules (resident-tail build; pc_bulk_all takes it from PcMultiArgs)
-  // Which edge-node Hessian entries go to the tail as granules instead of being stored: one bit per entry site
-  // (sites: NHZZ z-z entries, then the t strips (j, z), then the s strips (l, z)), for node 0 and for node N-1; the
-  // record of a flagged site is edge_rec0[edge] + the number of flagged sites before it.  Uniform: lives in SGPRs.
-  uint32_t edge_mask[2][PC_EDGE_WORDS];
-  int32_t edge_rec0[2];
+  // Resident-tail build: every Hessian entry of the edge nodes 0 / N-1 goes to the tail workgroup as a record of two
+  // granules instead of being stored (the tail adds the endpoint term that lands on it, if any, and stores it).  Record
+  // of a site = erec0 + (node N-1 ? NEDGE : 0) + site; sites: the NHZZ z-z entries, then the t strips (j, z), then the
+  // s strips (l, z) -- NEDGE = NHZZ + 2 NZ + NS NZ of them.
+  int32_t erec0, reserved0;
   int32_t wpt;            // waves (replicas) per tile: 1, 2 or 4; > 1 only with 64-node tiles
   int32_t block_threads;  // threads per workgroup of this launch (= blockDim.x, passed for the same reason as n_blocks)
   int32_t n_blocks;       // workgroups of this launch (tile_end - tile_begin): the kernel must not read gridDim,
@@ -148,7 +147,9 @@ struct PcTailArgs {
   int32_t lds_nred;             // largest NRED of any phase: sizes the tail's LDS carve (pc::tail_lds)
   // resident-tail build
   const unsigned long long* erec;   // [n_rec][2] granules of the edge-node Hessian entries (see PcPhaseArgs)
-  const int32_t* pt_rec;            // [n_pt_hess] record of every endpoint Hessian entry with pt_hlocal < 0, else -1
+  const int64_t* rec_slot;          // [n_rec] H slot of every record, -1: the site does not exist in this model
+  const int32_t* rec_term;          // [n_rec] endpoint Hessian entry whose term is added to the record, or -1
+  int32_t n_rec, reserved1;
   unsigned* timeout;                // host-visible word the tail sets when a granule never arrives (bounded spin)
   uint32_t epoch, reserved;
   PcTailPhase ph[PC_MAX_PHASES];

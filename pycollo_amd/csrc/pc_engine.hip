@@ -119,8 +119,7 @@ struct PhaseDev {
   DevBuf<int64_t> sec_E, hslot0, hslotN, hsum_slot;
   DevBuf<int32_t> hsum_local;
   DevBuf<unsigned long long> gran;   // resident tail: the per-tile partial sums as granules, [n_tiles][nred][2]
-  uint32_t edge_mask[2][PC_EDGE_WORDS] = {};   // resident tail: edge-node Hessian entry sites handed to the tail
-  int32_t edge_rec0[2] = {0, 0};               // first record of each edge's flagged sites
+  int32_t erec0 = 0;                 // resident tail: first record of this phase's edge-node Hessian entries
   int uni_n = 0, spt = 0, lds_out = 0;
   int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
   hipFunction_t fn = nullptr;
@@ -219,6 +218,8 @@ struct pc_handle {
   bool x_valid = false;      // the staged x~ is the caller's current point
   bool fc_valid = false;     // J, grad J, c~, G~ at that point have been launched (new_x == 0 reuses them)
   bool small_synced = false, G_synced = false;
+  bool prefetch_jac = true;  // copy G~ down with every new point (IPOPT asks for it next); off: only when eval_jac_g asks
+  bool G_copied = false;
   DevBuf<int64_t> d_point_x, d_tail_owned, d_pt_hslot, d_g_indptr;
   DevBuf<int32_t> d_pt_hlocal;
   std::vector<double> h_pointV, h_pointr, h_Wend;   // host copies: travel by value in PcTailArgs
@@ -226,7 +227,9 @@ struct pc_handle {
   hipFunction_t bulk_all_res_fn = nullptr;   // multi-phase problems: pc_bulk_all with the resident tail
   bool resident = true;                      // PYCOLLO_AMD_RESIDENT=0: always two launches (bulk, then pc_tail)
   DevBuf<unsigned long long> d_erec;         // granules of the edge-node Hessian entries endpoint terms are added to
-  DevBuf<int32_t> d_pt_rec;                  // [n_pthess] record of every such endpoint entry, else -1
+  DevBuf<int64_t> d_rec_slot;                // [n_rec] H slot of every record (-1: site absent)
+  DevBuf<int32_t> d_rec_term;                // [n_rec] endpoint Hessian entry added to the record, or -1
+  int32_t n_rec = 0;
   PinBuf<unsigned> h_timeout;                // host-visible: set by a tail whose granules never arrived
   uint32_t epoch = 0;                        // tag of the last resident launch's granules (never 0)
   int spin_us = 500;                         // host-pointer calls poll the stream this long before blocking (PYCOLLO_AMD_SPIN_US)
@@ -279,7 +282,9 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.block_threads = PC_TAIL_THREADS;
   t.lds_nred = h->lds_nred;
   t.erec = h->d_erec.p;
-  t.pt_rec = h->d_pt_rec.p;
+  t.rec_slot = h->d_rec_slot.p;
+  t.rec_term = h->d_rec_term.p;
+  t.n_rec = h->n_rec;
   t.timeout = h->h_timeout.p;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
@@ -333,9 +338,7 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.partials = D.partials_ext ? D.partials_ext : D.partials.p;
   a.gran = D.gran.p;
   a.erec = h->d_erec.p;
-  std::memcpy(a.edge_mask, D.edge_mask, sizeof(a.edge_mask));
-  a.edge_rec0[0] = D.edge_rec0[0];
-  a.edge_rec0[1] = D.edge_rec0[1];
+  a.erec0 = D.erec0;
   a.tab = D.tab.p;
   a.x_off = P.x_off;
   a.s_off = Q.s_off;
@@ -864,24 +867,21 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.gran.upload(std::vector<unsigned long long>((size_t)2 * std::max(1, P.nred) * D.n_tiles, 0ull));   // tag 0: never written
     }
     {
-      // Edge-node Hessian entries on which an endpoint term lands: in a resident-tail launch the edge tile hands the
-      // value to the tail workgroup (a record of two granules) instead of storing it.  Records are numbered in the
-      // order (phase, edge, site) over the sites the bulk kernel knows (z-z entries, t strips, s strips), so a tile
-      // finds a site's record from a bit mask and a base (PcPhaseArgs::edge_mask / edge_rec0); pt_rec maps every
-      // endpoint entry to its record.
-      std::map<int64_t, int32_t> want;   // slot -> endpoint entry
+      // Resident tail: every Hessian entry of the edge nodes 0 / N-1 reaches the tail workgroup as a record (two
+      // granules) and is stored by it, with the endpoint term that lands on the same slot where there is one.
+      // Records: per phase, node 0 then node N-1, the sites in the kernels' order (z-z entries, t strips, s strips).
+      std::map<int64_t, int32_t> term_of_slot;   // slot -> endpoint entry
       for (size_t e = 0; e < Q.pt_hslot.size(); ++e)
-        if (Q.pt_hlocal[e] < 0) want.emplace(Q.pt_hslot[e], (int32_t)e);
-      std::vector<int32_t> pt_rec(Q.pt_hslot.size(), -1);
-      int32_t n_rec = 0;
+        if (Q.pt_hlocal[e] < 0) term_of_slot.emplace(Q.pt_hslot[e], (int32_t)e);
+      std::vector<int64_t> rec_slot;
+      std::vector<int32_t> rec_term;
+      size_t used = 0;
       for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
         auto& P = Q.ph[ip];
-        auto& D = *h->pd[ip];
         const int NZ = P.n_z, NS = Q.n_s, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
-        std::memset(D.edge_mask, 0, sizeof(D.edge_mask));
+        h->pd[ip]->erec0 = (int32_t)rec_slot.size();
         for (int edge = 0; edge < 2; ++edge) {
           const int64_t node = edge ? P.N - 1 : 0;
-          D.edge_rec0[edge] = n_rec;
           for (int site = 0; site < NE; ++site) {
             int64_t slot = -1;
             if (site < NHZZ) {
@@ -890,22 +890,21 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
               const int64_t base = P.hoff[NZ + (site - NHZZ)];   // t strips (j, z) then s strips (l, z)
               if (base >= 0) slot = base + node;
             }
-            auto it = slot >= 0 ? want.find(slot) : want.end();
-            if (it == want.end()) continue;
-            if (site >= 32 * PC_EDGE_WORDS) {   // beyond the kernels' mask: this model keeps two launches
-              h->resident = false;
-              continue;
-            }
-            D.edge_mask[edge][site >> 5] |= 1u << (site & 31);
-            pt_rec[it->second] = n_rec++;
-            want.erase(it);
+            if (P.N == 1 && edge == 1) slot = -1;
+            auto it = slot >= 0 ? term_of_slot.find(slot) : term_of_slot.end();
+            rec_slot.push_back(slot);
+            rec_term.push_back(it == term_of_slot.end() ? -1 : it->second);
+            used += it == term_of_slot.end() ? 0 : 1;
           }
         }
       }
-      if (h->resident && !want.empty())
+      if (used != term_of_slot.size())
         throw std::runtime_error("internal error: an endpoint Hessian term lands on an edge-node entry no tile produces");
-      h->d_pt_rec.upload(pt_rec);
-      h->d_erec.upload(std::vector<unsigned long long>(2 * (size_t)std::max(1, n_rec), 0ull));
+      h->n_rec = (int32_t)rec_slot.size();
+      if (rec_slot.empty()) { rec_slot.push_back(-1); rec_term.push_back(-1); }
+      h->d_rec_slot.upload(rec_slot);
+      h->d_rec_term.upload(rec_term);
+      h->d_erec.upload(std::vector<unsigned long long>(2 * rec_slot.size(), 0ull));
     }
     h->h_timeout.alloc(16);
     std::memset(h->h_timeout.p, 0, 16 * sizeof(unsigned));
@@ -1129,6 +1128,13 @@ int pc_host_buffers(pc_handle* h, double** x, double** lambda, double** g, doubl
   });
 }
 
+int pc_set_prefetch_jac(pc_handle* h, int on) {
+  return guarded([&] {
+    require_device(h);
+    h->prefetch_jac = on != 0;
+  });
+}
+
 int pc_set_host_mode(pc_handle* h, int mode) {
   return guarded([&] {
     require_device(h);
@@ -1151,8 +1157,11 @@ static void ensure_fcG(pc_handle* h, const double* x, int new_x) {
              PC_FLAG_C | PC_FLAG_G, h->stream, 1.0);
   copy_down(h, 0, h->o_c + h->Q.num_c);
   HIP_OK(hipEventRecord(h->ev_small, h->stream));
-  copy_down(h, h->o_G, h->o_G + h->Q.g_row.size());
-  HIP_OK(hipEventRecord(h->ev_G, h->stream));
+  h->G_copied = h->prefetch_jac || (h->host_mode & 2);
+  if (h->G_copied) {
+    copy_down(h, h->o_G, h->o_G + h->Q.g_row.size());
+    HIP_OK(hipEventRecord(h->ev_G, h->stream));
+  }
   h->fc_valid = true;
   h->small_synced = h->G_synced = false;
 }
@@ -1169,6 +1178,11 @@ static void wait_small(pc_handle* h) {
 }
 static void wait_G(pc_handle* h) {
   if (h->G_synced) return;
+  if (!h->G_copied) {   // G~ stayed on the device until somebody asked for it
+    copy_down(h, h->o_G, h->o_G + h->Q.g_row.size());
+    HIP_OK(hipEventRecord(h->ev_G, h->stream));
+    h->G_copied = true;
+  }
   if (h->spin_us > 0) {
     const auto t0 = std::chrono::steady_clock::now();
     while (hipEventQuery(h->ev_G) == hipErrorNotReady &&

@@ -321,8 +321,7 @@ struct BulkIn {
   double t_fixed[2];
   int32_t N, K, flags, qa_total, qw_total, tile_begin, uni_n, spt, lds_out, wpt, n_blocks, block_threads, qa0, qw0, qwabs;
   uint32_t epoch;
-  uint32_t edge_mask[2][PC_EDGE_WORDS];
-  int32_t edge_rec0[2];
+  int32_t erec0;
   double scal[St::NSCAL > 0 ? St::NSCAL : 1];
   int64_t goff[St::NFN > 0 ? St::NFN : 1];
   int64_t hoff[3 * St::NZ + St::NS * St::NZ > 0 ? 3 * St::NZ + St::NS * St::NZ : 1];
@@ -411,11 +410,15 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 #endif
 }
 
-// MA != null: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call
-// pointers and flags come from MA, the workgroup's tile from its index relative to the phase's first block.
+// MULTI: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call pointers, the
+// flags and the granule tag arrive as plain values (mx .. mepoch: the members of PcMultiArgs the kernel needs --
+// handed over as a pointer to the struct, a large kernel keeps the whole struct in scratch memory), the workgroup's
+// tile from its index relative to the phase's first block.
 template <class M, int UN, bool RES = false>
-__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* MA = nullptr, int first_block = 0,
-                                     int block = -1, const PcLead* LD = nullptr) {
+__device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, int first_block = 0, int block = -1,
+                                     const PcLead* LD = nullptr, const double* mx = nullptr, const double* mlam = nullptr,
+                                     double* mc = nullptr, double* mG = nullptr, double* mH = nullptr, int mflags = 0,
+                                     unsigned mepoch = 0) {
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
@@ -429,10 +432,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
     A.flags = wa & 0xff; A.wpt = (wa >> 8) & 0xf; A.block_threads = ((wa >> 12) & 0xf) << 6; A.spt = wa >> 16;
     A.qa0 = wb & 0xffff; A.qwabs = wb >> 16;
   } else {
-    A.x = MA ? MA->x : KA.x; A.lam = MA ? MA->lam : KA.lam; A.x_off = KA.x_off; A.c_off = KA.c_off; A.N = KA.N; A.K = KA.K;
+    A.x = MULTI ? mx : KA.x; A.lam = MULTI ? mlam : KA.lam; A.x_off = KA.x_off; A.c_off = KA.c_off; A.N = KA.N; A.K = KA.K;
     A.xz = A.x + A.x_off; A.lamd = A.lam + A.c_off; A.qa = KA.qa; A.sec_h = KA.sec_h;
     A.tile_begin = KA.tile_begin; A.spt = KA.spt; A.n_blocks = KA.n_blocks;
-    A.flags = MA ? MA->flags : KA.flags; A.wpt = KA.wpt; A.block_threads = KA.block_threads;
+    A.flags = MULTI ? mflags : KA.flags; A.wpt = KA.wpt; A.block_threads = KA.block_threads;
     A.qa0 = KA.qa_off[UN > 0 ? UN : 0]; A.qwabs = KA.qa_total + KA.qw_off[UN > 0 ? UN : 0];
   }
   if constexpr (UN == 0) { A.uni_n = KA.uni_n; A.tile_k0 = KA.tile_k0; A.tile_n0 = KA.tile_n0; A.sec_s = KA.sec_s; }
@@ -476,8 +479,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
   // block is read through the kernarg segment pointer passed through an empty asm, so that the scalar loads below
   // (and the wait their first use needs) depend on a point after the node loads and cannot be hoisted above them.
   auto part2 = [&](const auto& KB) {
-    if (MA) {
-      A.c = MA->c; A.G = MA->G; A.H = MA->H;
+    if (MULTI) {
+      A.c = mc; A.G = mG; A.H = mH;
     } else {
       A.c = KB.c; A.G = KB.G; A.H = KB.H;
     }
@@ -486,14 +489,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
     A.sec_E = KB.sec_E;
     A.qw = KB.qw; A.hslot0 = KB.hslot0; A.hslotN = KB.hslotN; A.partials = KB.partials;
     A.gran = KB.gran; A.erec = KB.erec; A.tab = KB.tab;
-    if constexpr (RES) {
-      static_for<0, 2 * PC_EDGE_WORDS>([&](auto i_) {
-        constexpr int i = decltype(i_)::value;
-        A.edge_mask[i / PC_EDGE_WORDS][i % PC_EDGE_WORDS] = KB.edge_mask[i / PC_EDGE_WORDS][i % PC_EDGE_WORDS];
-      });
-      A.edge_rec0[0] = KB.edge_rec0[0]; A.edge_rec0[1] = KB.edge_rec0[1];
-    }
-    A.epoch = MA ? MA->epoch : KB.epoch;
+    A.erec0 = KB.erec0;
+    A.epoch = MULTI ? mepoch : KB.epoch;
     A.s_off = KB.s_off; A.c_path_off = KB.c_path_off; A.c_int_off = KB.c_int_off;
     A.t_fixed[0] = KB.t_fixed[0]; A.t_fixed[1] = KB.t_fixed[1];
     A.qa_total = KB.qa_total; A.qw_total = KB.qw_total;
@@ -1029,29 +1026,18 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, const PcMultiArgs* M
 
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
   const bool edge0 = (node == 0), edgeN = (node == N - 1);
-  // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot and the
-  // resident tail finishes it: then the value is handed over as granules instead.  Which sites (the z-z entries, the
-  // t strips (j, z), the s strips (l, z)) is a bit mask per edge in the argument block, a site's record the number of
-  // flagged sites before it: scalar arithmetic on uniform words, no table in memory.
+  // A Hessian entry of an edge node (0 or N-1) is stored -- except in the resident-tail build, where it goes to the
+  // tail workgroup as a record (an endpoint term may land on the same slot; the tail adds it and stores the entry).
+  // Record = erec0 + (node N-1 ? NEDGE : 0) + site: no table, no mask, one uniform scalar.
+  constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
   auto edge_store = [&](auto site_, double* dstp, double val) {
     constexpr int site = decltype(site_)::value;
-    // (a site beyond the mask is never flagged: the host gives such a model no resident tail if it would have to be)
-    if constexpr (RES && site < 32 * PC_EDGE_WORDS) {
-      // (the edge is chosen per word with a select: a run-time subscript would send the whole argument copy to
-      //  scratch memory)
-      auto word = [&](auto w_) -> unsigned {
-        constexpr int w = decltype(w_)::value;
-        return edge0 ? A.edge_mask[0][w] : A.edge_mask[1][w];
-      };
-      const unsigned mw = word(ic<(site >> 5)>{});
-      if ((mw >> (site & 31)) & 1u) {
-        int rec = (edge0 ? A.edge_rec0[0] : A.edge_rec0[1]) + __builtin_popcount(mw & ((1u << (site & 31)) - 1u));
-        static_for<0, (site >> 5)>([&](auto w_) { rec += __builtin_popcount(word(w_)); });
-        publish_granules(A.erec + 2 * rec, A.epoch, val);
-        return;
-      }
+    if constexpr (RES) {
+      (void)dstp;
+      publish_granules(A.erec + 2 * (int64_t)(A.erec0 + (edge0 ? 0 : NEDGE) + site), A.epoch, val);
+    } else {
+      *dstp = val;
     }
-    *dstp = val;
   };
   auto hess_second = [&]() {     // everything built from the second partials
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
@@ -1578,32 +1564,38 @@ __device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailL
 template <class PT, bool RES = false>
 __device__ __forceinline__ void tail_point_apply(const PcTailArgs& A, const TailLds& L) {
   constexpr int NPH = PT::NPH;
+  lds_barrier();   // the terms (lane 0 of every wave) and the phases' sums (lane 0 of wave 0) are in LDS
+  if (!(A.flags & PC_FLAG_H)) return;
+  const int tid = threadIdx.x, TB = A.block_threads;
   if constexpr (NPH > 0) {
-    lds_barrier();   // the terms (lane 0 of every wave) and the phases' sums (lane 0 of wave 0) are in LDS
-    if (!(A.flags & PC_FLAG_H)) return;
-    const int tid = threadIdx.x, TB = A.block_threads;
+    for (int e = tid; e < NPH; e += TB) {
+      const int hl = A.pt_hlocal[e];
+      if (hl >= 0) L.acc[hl] += L.hb[e];
+      else if constexpr (!RES) A.H[A.pt_hslot[e]] = L.hold[e] + L.hb[e];
+    }
+  }
+  if constexpr (RES) {
+    // every Hessian entry of the edge nodes arrives here as a record; stored as it is, or with its endpoint term
     unsigned spins = 0;
-    for (int e0 = 0; e0 < NPH; e0 += TB) {
-      const int e = e0 + tid;
-      const bool valid = e < NPH;
-      const int hl = valid ? A.pt_hlocal[e] : 0;
-      if (valid && hl >= 0) L.acc[hl] += L.hb[e];
-      if constexpr (RES) {
-        const bool edge = valid && hl < 0;
-        double cur = 0.0;
-        for (;;) {
-          bool ok = true;
-          if (edge) {
-            const unsigned long long* g = A.erec + 2 * A.pt_rec[e];
-            const unsigned long long lo = load_granule(g), hi = load_granule(g + 1);
-            ok = join_granules(lo, hi, A.epoch, cur);
-          }
-          if (__all(ok)) break;
-          if (!spin_again(spins, A, 100u)) break;
+    for (int r0 = 0; r0 < A.n_rec; r0 += TB) {
+      const int r = r0 + tid;
+      const int64_t slot = r < A.n_rec ? A.rec_slot[r] : -1;
+      const bool live = slot >= 0;
+      double cur = 0.0;
+      for (;;) {
+        bool ok = true;
+        if (live) {
+          const unsigned long long* g = A.erec + 2 * (int64_t)r;
+          const unsigned long long lo = load_granule(g), hi = load_granule(g + 1);
+          ok = join_granules(lo, hi, A.epoch, cur);
         }
-        if (edge) A.H[A.pt_hslot[e]] = cur + L.hb[e];
-      } else {
-        if (valid && hl < 0) A.H[A.pt_hslot[e]] = L.hold[e] + L.hb[e];
+        if (__all(ok)) break;
+        if (!spin_again(spins, A, 100u)) break;
+      }
+      if (live) {
+        const int term = A.rec_term[r];
+        if constexpr (NPH > 0) A.H[slot] = term >= 0 ? cur + L.hb[term] : cur;
+        else A.H[slot] = cur;
       }
     }
   }

@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.pc_eval_resident.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp]
     lib.pc_host_buffers.argtypes = [vp] + [C.POINTER(vp)] * 5
     lib.pc_set_host_mode.argtypes = [vp, C.c_int]
+    lib.pc_set_prefetch_jac.argtypes = [vp, C.c_int]
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.pc_launch_bulk_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pc_launch_tail_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
@@ -392,6 +393,10 @@ class NlpEngine:
         self._check(self._lib.pc_eval_resident(self._h, x.ctypes.data, float(obj_factor), None if lam is None else lam.ctypes.data,
                                                C.addressof(f), None if grad is None else grad.ctypes.data, c.ctypes.data))
         return f.value, grad, c
+
+    def set_prefetch_jac(self, on: bool):
+        """Whether a new point's G~ is copied to the host at once (``pc_set_prefetch_jac``)."""
+        self._check(self._lib.pc_set_prefetch_jac(self._h, int(bool(on))))
 
     def G_row_norms(self, x):
         x = self._x(x)

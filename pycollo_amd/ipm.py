@@ -16,8 +16,11 @@ method IPOPT implements, without its restoration phase and second-order correcti
   inertia-free regularisation (curvature test on the step), fraction-to-the-boundary rule, filter on
   (constraint violation, barrier objective), monotone mu update.
 
-The KKT systems are solved on the host with SuperLU (``scipy.sparse.linalg.splu``); row N4 (that solve on the GPU)
-is not started.  Multiplier sign convention: L = obj_factor f + lambda^T c, as IPOPT's ``eval_h`` expects.
+The linear algebra goes through four methods (``_JT``, ``_solve_kkt``, ``_ls_multipliers``, ``_gn_step``).
+:class:`InteriorPointSolver` implements them on the host with SuperLU (``scipy.sparse.linalg.splu``) on matrices the
+callbacks delivered as host arrays; :class:`GpuInteriorPointSolver` (row N4) implements them with the block L D L^T
+of ``pycollo_amd.kkt`` on G~ / H~ that never leave device memory -- only vectors cross the bus.
+Multiplier sign convention: L = obj_factor f + lambda^T c, as IPOPT's ``eval_h`` expects.
 """
 from __future__ import annotations
 
@@ -208,6 +211,34 @@ class InteriorPointSolver:
                 break
         raise RuntimeError("KKT regularisation failed")
 
+    def _JT(self, J, lam):
+        """J^T lambda over v = [x ; s]."""
+        return J.T @ lam
+
+    def _ls_multipliers(self, J, gz):
+        """Least-squares multiplier estimate: lambda of  min ||gz + J^T lambda||  over the free unknowns (IPOPT's
+        initial multipliers); zeros when the estimate is unusable."""
+        lam = np.zeros(self.m)
+        try:
+            Jf = J[:, self.free]
+            K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, None]], format="csc")
+            sol = spla.splu(K).solve(np.concatenate([-gz[self.free], np.zeros(self.m)]))
+            if self.m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[self.nf:])) <= 1e3:
+                lam = sol[self.nf:]
+        except RuntimeError:
+            pass
+        return lam
+
+    def _gn_step(self, J, c):
+        """Minimum-norm step onto the linearised constraints (restoration): dv of [[I, J^T], [J, -1e-10 I]]."""
+        Jf = J[:, self.free]
+        self.counts["factorisations"] += 1
+        K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, -1e-10 * sp.identity(self.m)]], format="csc")
+        sol = spla.splu(K).solve(np.concatenate([np.zeros(self.nf), -c]))
+        dr = np.zeros(self.nv)
+        dr[self.free] = sol[:self.nf]
+        return dr
+
     # ---- main loop --------------------------------------------------------------------------------
     def solve(self, x0) -> IpmResult:
         t_start = time.perf_counter()
@@ -241,16 +272,7 @@ class InteriorPointSolver:
         zu = np.where(self.hasu, 1.0, 0.0)
         f, g = self._f(v[:n]), np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
         c, J = self._c(v), self._J(v[:n])
-        # least-squares multipliers
-        lam = np.zeros(m)
-        try:
-            Jf = J[:, self.free]
-            K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, None]], format="csc")
-            sol = spla.splu(K).solve(np.concatenate([-(g - zl + zu)[self.free], np.zeros(m)]))
-            if m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[self.nf:])) <= 1e3:
-                lam = sol[self.nf:]
-        except RuntimeError:
-            pass
+        lam = self._ls_multipliers(J, g - zl + zu)
         filt: list[tuple[float, float]] = []
         theta0 = float(np.sum(np.abs(c)))
         theta_max, theta_min = 1e4 * max(1.0, theta0), 1e-4 * max(1.0, theta0)
@@ -264,7 +286,7 @@ class InteriorPointSolver:
         inf_pr = inf_du = np.inf
 
         def errors(mu_):
-            dL = (g + J.T @ lam - zl + zu)[self.free]
+            dL = (g + JTlam - zl + zu)[self.free]
             nz = max(1, int(self.hasl.sum() + self.hasu.sum()))
             sd = max(s_max, (np.sum(np.abs(lam)) + np.sum(zl) + np.sum(zu)) / (m + nz)) / s_max
             scz = max(s_max, (np.sum(zl) + np.sum(zu)) / nz) / s_max
@@ -278,6 +300,7 @@ class InteriorPointSolver:
             return max(e_du / sd, e_pr, comp / scz), e_pr, e_du
 
         for it in range(self.max_iter + 1):
+            JTlam = self._JT(J, lam)
             e0, inf_pr, inf_du = errors(0.0)
             hist.append((it, f, inf_pr, inf_du, mu))
             if self.verbose:
@@ -302,7 +325,7 @@ class InteriorPointSolver:
             W = self._W(v[:n], lam)
             grad_phi = g - np.where(self.hasl, mu / dlv, 0.0) + np.where(self.hasu, mu / duv, 0.0)
             try:
-                dv, dlam, dw_last = self._solve_kkt(W, Sigma, J, -(grad_phi + J.T @ lam), -c, dw_last)
+                dv, dlam, dw_last = self._solve_kkt(W, Sigma, J, -(grad_phi + JTlam), -c, dw_last)
             except RuntimeError:
                 status = "kkt_failure"
                 break
@@ -345,15 +368,10 @@ class InteriorPointSolver:
                 vr, cr_, Jr, ok_r = v.copy(), c, J, False
                 for _ in range(30):
                     th_r = float(np.sum(np.abs(cr_)))
-                    Jf = Jr[:, self.free]
                     try:
-                        self.counts["factorisations"] += 1
-                        K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, -1e-10 * sp.identity(m)]], format="csc")
-                        sol = spla.splu(K).solve(np.concatenate([np.zeros(self.nf), -cr_]))
+                        dr = self._gn_step(Jr, cr_)
                     except RuntimeError:
                         break
-                    dr = np.zeros(nv)
-                    dr[self.free] = sol[:self.nf]
                     if not np.all(np.isfinite(dr)):
                         break
                     a = self._alpha_max(vr, dr, tau)
@@ -384,13 +402,7 @@ class InteriorPointSolver:
                 last_alpha, last_amax, last_tag = 0.0, a_max, " R"
                 g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
                 # multipliers after restoration: least squares, as at the start
-                try:
-                    Jf = J[:, self.free]
-                    K = sp.bmat([[sp.identity(self.nf), Jf.T], [Jf, None]], format="csc")
-                    sol = spla.splu(K).solve(np.concatenate([-(g - zl + zu)[self.free], np.zeros(m)]))
-                    lam = sol[self.nf:] if m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[self.nf:])) <= 1e3 else np.zeros(m)
-                except RuntimeError:
-                    lam = np.zeros(m)
+                lam = self._ls_multipliers(J, g - zl + zu)
                 continue
             last_alpha, last_amax, last_tag = alpha, a_max, ""
             v = v + alpha * dv
@@ -407,6 +419,123 @@ class InteriorPointSolver:
             J = self._J(v[:n])
         return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
                          inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=dict(self.counts), history=hist)
+
+
+class GpuInteriorPointSolver(InteriorPointSolver):
+    """The same algorithm with its linear algebra on the GPU.
+
+    G~ and H~ are evaluated into device memory (``NlpEngine.evaluate_resident``) and consumed there by the block
+    L D L^T of ``pycollo_amd.kkt.GpuKkt``; what crosses the bus per iteration is a handful of vectors (x~, lambda,
+    Sigma, right-hand sides, the step).  ``problem_obj`` must be a :class:`pycollo_amd.engine.PycolloGpuProblem`.
+    Replaces the linear solver inside IPOPT that the reference picks by name (pycollo/backend.py:1703-1711)."""
+
+    def __init__(self, problem_obj, n, m, lb, ub, cl, cu, **kw):
+        super().__init__(problem_obj, n, m, lb, ub, cl, cu, **kw)
+        self.engine = problem_obj.engine
+        self.kkt = None          # built in solve(), once the row scaling is known
+        self.times = {"evaluate": 0.0, "factor": 0.0, "solve": 0.0, "matvec": 0.0}
+
+    def _ensure_kkt(self):
+        if self.kkt is None:
+            from .kkt import GpuKkt
+            self.kkt = GpuKkt(self.engine, self.ineq, self.fixed, self.sc)
+        return self.kkt
+
+    # G~ (and H~) live on the device; the "matrix" handed around is a token saying at which point they were evaluated
+    def _J(self, x):
+        self.counts["jacobian"] += 1
+        t0 = time.perf_counter()
+        self.engine.evaluate_resident(x, self.sf, None, want_grad=False)
+        self.times["evaluate"] += time.perf_counter() - t0
+        return ("resident", self.counts["jacobian"])
+
+    def _W(self, x, lam):
+        self.counts["hessian"] += 1
+        t0 = time.perf_counter()
+        self.engine.evaluate_resident(x, self.sf, self.sc * lam, want_grad=False)
+        self.times["evaluate"] += time.perf_counter() - t0
+        return ("resident", self.counts["hessian"])
+
+    def _JT(self, J, lam):
+        k = self._ensure_kkt()
+        t0 = time.perf_counter()
+        y = k.matvec(np.zeros(self.nv + self.m), np.concatenate([np.zeros(self.nv), lam]), use_hess=False)
+        self.times["matvec"] += time.perf_counter() - t0
+        return y[:self.nv]
+
+    def _factor(self, dvec, use_hess):
+        self.counts["factorisations"] += 1
+        t0 = time.perf_counter()
+        out = self._ensure_kkt().factor(dvec, use_hess)
+        self.times["factor"] += time.perf_counter() - t0
+        return out
+
+    def _refined_solve(self, rhs, dvec_true, use_hess):
+        """Solve with the current factors, refined against the system with ``dvec_true`` on the diagonal."""
+        k = self.kkt
+        t0 = time.perf_counter()
+        sol = k.solve(rhs)
+        res = rhs - k.matvec(dvec_true, sol, use_hess)
+        for _ in range(3):
+            trial = sol + k.solve(res)
+            res_t = rhs - k.matvec(dvec_true, trial, use_hess)
+            if not np.all(np.isfinite(trial)) or np.linalg.norm(res_t) >= 0.5 * np.linalg.norm(res):
+                break
+            sol, res = trial, res_t
+        self.times["solve"] += time.perf_counter() - t0
+        return sol
+
+    def _solve_kkt(self, W, Sigma, J, r1, r2, dw_last):
+        nv, m = self.nv, self.m
+        rhs = np.concatenate([np.where(self.fixed, 0.0, r1), r2])
+        dw, dc = 0.0, 0.0
+        for attempt in range(40):
+            dc_eff = max(dc, 1e-9)
+            dvec = np.concatenate([Sigma + dw, np.full(m, -dc_eff)])
+            npos, nneg = self._factor(dvec, True)
+            sol = None
+            if npos == nv and nneg == m:        # fixed unknowns are unit pivots: counted with the primal ones
+                with np.errstate(all="ignore"):
+                    sol = self._refined_solve(rhs, np.concatenate([Sigma + dw, np.full(m, -dc)]), True)
+                if np.all(np.isfinite(sol)):
+                    return np.where(self.fixed, 0.0, sol[:nv]), sol[nv:], dw
+            if dw >= 1e20:
+                break
+            if dw == 0.0:
+                dw = 1e-4 if dw_last == 0.0 else max(1e-20, dw_last / 3.0)
+            else:
+                dw *= 100.0 if dw_last == 0.0 else 8.0
+        raise RuntimeError("KKT regularisation failed")
+
+    def _ls_multipliers(self, J, gz):
+        lam = np.zeros(self.m)
+        nv, m = self.nv, self.m
+        dvec = np.concatenate([np.ones(nv), np.full(m, -1e-10)])
+        self._factor(dvec, False)
+        with np.errstate(all="ignore"):
+            sol = self._refined_solve(np.concatenate([np.where(self.fixed, 0.0, -gz), np.zeros(m)]), dvec, False)
+        if m and np.all(np.isfinite(sol)) and np.max(np.abs(sol[nv:])) <= 1e3:
+            lam = sol[nv:]
+        return lam
+
+    def _gn_step(self, J, c):
+        nv, m = self.nv, self.m
+        dvec = np.concatenate([np.ones(nv), np.full(m, -1e-10)])
+        self._factor(dvec, False)
+        sol = self._refined_solve(np.concatenate([np.zeros(nv), -c]), dvec, False)
+        return np.where(self.fixed, 0.0, sol[:nv])
+
+    def solve(self, x0) -> IpmResult:
+        self.engine.set_prefetch_jac(False)     # G~ is consumed where it is produced
+        try:
+            res = super().solve(x0)
+        finally:
+            self.engine.set_prefetch_jac(True)
+        res.evaluations["gpu_seconds"] = dict(self.times)
+        if self.kkt is not None:
+            self.kkt.close()
+            self.kkt = None
+        return res
 
 
 def solve_nlp(problem_obj, x0, lb, ub, cl, cu, **options) -> IpmResult:

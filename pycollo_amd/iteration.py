@@ -128,14 +128,18 @@ class MeshIteration:
         return ((xb[:, 0] - self.r) / self.V, (xb[:, 1] - self.r) / self.V, W * cb[:, 0], W * cb[:, 1])
 
     # ---- solve -------------------------------------------------------------------------------------
-    def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0):
+    def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0, linear_solver: str = "gpu"):
         """Solve the scaled NLP with the interior-point stand-in for IPOPT (``pycollo_amd.ipm``), driven through
-        the cyipopt-protocol object exactly as ``ipopt.problem(...).solve(x0)`` would be (pycollo/nlp.py:84-115)."""
+        the cyipopt-protocol object exactly as ``ipopt.problem(...).solve(x0)`` would be (pycollo/nlp.py:84-115).
+        ``linear_solver``: "gpu" -- the KKT systems are assembled from device-resident G~ / H~ and factorised on the
+        GPU (``pycollo_amd.kkt``; the role of IPOPT's ``linear_solver`` option, pycollo/backend.py:1703-1711);
+        "host" -- the callbacks deliver host arrays and SuperLU factorises (what a host-side IPOPT would do)."""
         from .engine import PycolloGpuProblem
-        from .ipm import InteriorPointSolver
+        from .ipm import GpuInteriorPointSolver, InteriorPointSolver
         pobj = PycolloGpuProblem(self.engine)
-        solver = InteriorPointSolver(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
-                                     tol=tol, max_iter=max_iter, verbose=verbose)
+        cls = {"gpu": GpuInteriorPointSolver, "host": InteriorPointSolver}[linear_solver]
+        solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
+                     tol=tol, max_iter=max_iter, verbose=verbose)
         res = solver.solve(self.guess_x_tilde)
         self.result = res
         self.x_tilde = res.x
