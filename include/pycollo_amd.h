@@ -48,6 +48,8 @@ typedef struct {
   const char* bulk_kernel;         /* kernel symbol inside the code object */
   int32_t compiled_order;          /* 0: the kernel handles any mesh; n > 0: it was compiled for sections of
                                       exactly n nodes (every n_k must equal n) */
+  int32_t n_edge_rec[2];           /* Hessian entries of node 0 / node N-1 an endpoint term lands on: what the phase's
+                                      kernel was generated with (codegen.edge_flags); checked against the pattern */
   int32_t eval_ops;                /* arithmetic operations in the phase's node functions and their derivatives
                                       (0 = unknown); a launch-shape hint only: heavy models share a tile between
                                       fewer waves because every sharing wave re-evaluates the node functions */

@@ -105,7 +105,41 @@ def _constexpr_table(name: str, values: list[int]) -> str:
     return (f"  static constexpr int {name}(int e) {{ constexpr int t[{len(values)}] = {{{body}}}; return t[e]; }}")
 
 
-def _phase_struct(pm: PhaseModel) -> str:
+def edge_flags(model: Model, pm: PhaseModel) -> list[int]:
+    """Which Hessian entries of the phase's edge nodes (node 0, then node N-1) an endpoint term lands on -- a
+    property of the model alone.  Sites per edge, in the kernels' order: the z-z entries of the node block (rows of
+    ``pm.hess`` with both indices < n_z), the t strips (j, z), the s strips (l, z).  In the resident-tail build these
+    entries travel from the edge tile to the tail workgroup as records; all others are stored by the tile."""
+    nz, ns = pm.n_z, model.n_s
+    zz = [(r, c) for r, c, _ in pm.hess if r < nz and c < nz]
+    hm, jm = pm.hess_mask(), pm.jac_mask()
+    tz = [any(jm[r, b] for r in range(pm.n_fn) if not (pm.n_y <= r < pm.n_y + pm.n_p)) for b in range(nz)]
+    n_t = int(pm.t_free[0]) + int(pm.t_free[1])
+    ne = len(zz) + 2 * nz + ns * nz
+    flags = [0] * (2 * ne)
+    pv = model.point.vars
+    for r, c, _ in model.point.hess:
+        a, b = pv[r], pv[c]
+        for u, v in ((a, b), (b, a)):
+            if u.phase != pm.index or u.kind not in ("y0", "yF"):
+                continue
+            edge = 0 if u.kind == "y0" else 1
+            site = None
+            if v.phase == pm.index and v.kind == u.kind:                      # node block
+                key = (max(u.idx, v.idx), min(u.idx, v.idx))
+                if key in zz:
+                    site = zz.index(key)
+            elif v.phase == pm.index and v.kind in ("t0", "tF") and n_t > 0 and tz[u.idx]:
+                j = 0 if v.kind == "t0" else (1 if pm.t_free[0] else 0)
+                site = len(zz) + j * nz + u.idx
+            elif v.kind == "s" and hm[nz + v.idx, u.idx]:
+                site = len(zz) + 2 * nz + v.idx * nz + u.idx
+            if site is not None:
+                flags[edge * ne + site] = 1
+    return flags
+
+
+def _phase_struct(pm: PhaseModel, model: Model | None = None) -> str:
     name = f"Phase{pm.index}"
     nfn, nv = pm.n_fn, pm.n_v
     v_in = {s: sym.Symbol(f"v[{i}]") for i, s in enumerate(pm.z + pm.s)}
@@ -126,6 +160,8 @@ def _phase_struct(pm: PhaseModel) -> str:
              _constexpr_table("jc", [c for _, c, _ in pm.jac]),
              _constexpr_table("hr", [r for r, _, _ in pm.hess]),
              _constexpr_table("hc", [c for _, c, _ in pm.hess]),
+             "  // edge-node Hessian entry sites (node 0, then node N-1) whose value goes to the tail as a record",
+             _constexpr_table("efl", edge_flags(model, pm) if model is not None else []),
              "  __device__ static __forceinline__ void eval(const double* __restrict__ v, const double* __restrict__ mult,",
              "      double* __restrict__ F, double* __restrict__ Jv, double* __restrict__ Hv) {",
              "    (void)v; (void)mult; (void)F; (void)Jv; (void)Hv;"]
@@ -216,14 +252,15 @@ def generate_source(model: Model, orders=None) -> str:
              "",
              "namespace gen {"]
     for pm in model.phases:
-        parts.append(_phase_struct(pm))
+        parts.append(_phase_struct(pm, model))
     parts.append(_point_struct(model.point))
     parts.append("}  // namespace gen\n")
     parts.append("namespace gen {")
     parts.append("struct Tail {   // finishes one evaluation: cross-tile sums of every phase and the endpoint block")
     parts.append("  // RES: block 0 of a resident-tail bulk launch (values of other workgroups arrive as granules)")
     parts.append("  template <bool RES = false, bool BIG = false>")
-    parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr, int arg_off = 0) {")
+    parts.append("  __device__ static __forceinline__ void run(const PcTailArgs& a, const PcTailLead* ld = nullptr, int arg_off = 0,")
+    parts.append("                                             int tb = 0, int ntb = 1) {")
     parts.append("    extern __shared__ double pc_tail_smem[];")
     parts.append("    const pc::TailLds L = pc::tail_lds<Point>(a, pc_tail_smem);")
     first = model.phases[0].index
@@ -233,9 +270,11 @@ def generate_source(model: Model, orders=None) -> str:
     parts.append("      pc::tail_point_load<Point, true>(a, L);")
     parts.append("      pc::tail_begin(a, L);")
     parts.append("      warm.settle();")
-    parts.append("      pc::tail_point_eval<Point>(a, L);   // the endpoint rows are out before the first tile's sums arrive")
+    parts.append("      pc::tail_point_eval<Point>(a, L, tb, ntb);   // the endpoint rows are out before the first tile's sums arrive")
+    parts.append("      if (tb > 0) { pc::tail_point_publish<Point>(a, L, tb, ntb); return; }   // helper block: its parts only")
     for pm in model.phases:
         parts.append(f"      pc::tail_phase<Phase{pm.index}, true>(a, {pm.index}, L);")
+    parts.append("      pc::tail_point_collect<Point>(a, L, ntb);")
     parts.append("      pc::tail_point_apply<Point, true>(a, L);")
     parts.append("      pc::tail_end(a, L);")
     parts.append("    } else {")
@@ -267,17 +306,17 @@ def generate_source(model: Model, orders=None) -> str:
         pm = model.phases[0]
         parts.append("// resident-tail build: block 0 runs the tail beside the tiles, one launch per evaluation")
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
-        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs)); return; }')
-        parts.append('  if ((int)threadIdx.x >= (((wa >> 12) & 0xf) << 6)) return;   // launch widened for the tail block only')
+        parts.append('  const int ntb = (wa >> 28) & 7;   // leading workgroups that run the tail')
+        parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - 1, n_blocks), &ld);')
+        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - ntb, n_blocks), &ld);')
         parts.append('}')
     else:
         np_ = len(model.phases)
 
         def all_body(res: bool):
             out = []
-            blk = "(int)blockIdx.x - 1" if res else "(int)blockIdx.x"
+            blk = "(int)blockIdx.x - tail_blocks" if res else "(int)blockIdx.x"
             out.append(f"  const int b = pc::xcd_major({blk}, fb{np_});")
             for i, pm in enumerate(model.phases):
                 cond = f"if (b < fb{i + 1}) " if i + 1 < np_ else ""
@@ -289,15 +328,14 @@ def generate_source(model: Model, orders=None) -> str:
         # hands over the struct) and reach pc::bulk as values: as ONE by-value struct whose address is passed on, a
         # large kernel keeps it in scratch memory (seen: 112 B per lane, a scratch set-up on every wave of the launch).
         multi_sig = ("const double* x, const double* lam, double* c, double* G, double* H, const PcPhaseArgs* ph, int flags, "
-                     "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tile_threads")
+                     "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tail_blocks")
         parts.append("static_assert(PC_MAX_PHASES + 1 == 9, \"pc_bulk_all spells PcMultiArgs::first_block out\");")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(' + multi_sig + ') {')
         parts += all_body(False)
         parts.append("}")
         parts.append("// the same with the resident tail as block 0")
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(' + multi_sig + ', PcTailArgs t) {')
-        parts.append('  if (blockIdx.x == 0) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7)); return; }')
-        parts.append('  if ((int)threadIdx.x >= tile_threads) return;   // launch widened for the tail block only')
+        parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
         parts += all_body(True)
         parts.append("}")
     parts.append("")

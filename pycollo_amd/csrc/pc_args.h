@@ -76,7 +76,7 @@ struct PcLead {
   const double* qa;     // packed A tables, the packed weight tables right behind them (qw == qa + qa_total)
   const double* sec_h;  // section widths
   int32_t N, K, tile_begin, n_blocks;
-  int32_t wa;           // flags | wpt << 8 | (block_threads / 64) << 12 | spt << 16
+  int32_t wa;           // flags | wpt << 8 | (block_threads / 64) << 12 | spt << 16 | tail blocks (resident build) << 28
   int32_t wb;           // uniform order n: qa_off[n] | (qa_total + qw_off[n]) << 16 (both relative to qa); else 0
 };
 // what the host hands to pc_bulk_p<i>: (lead scalars..., PcPhaseArgs a)
@@ -101,8 +101,8 @@ struct PcMultiArgs {
   int32_t flags, n_phases;
   int32_t first_block[PC_MAX_PHASES + 1];
   uint32_t epoch;                         // tag of this launch's granules (resident-tail build)
-  int32_t tile_threads;                   // resident-tail build: threads of a tile's workgroup that work (the launch may be
-                                          //   wider for the tail block's sake: the others exit at once)
+  int32_t tail_blocks;                    // resident-tail build: leading workgroups that run the tail (1, or one per part
+                                          //   of a heavy endpoint block); the tiles follow
 };
 #define PC_MAX_POINT 96           // endpoint (point) variables: y(t0), y(tF), q, t of every phase, s
 #define PC_MAX_ENDPOINT_ROWS 32   // endpoint constraint rows
@@ -149,7 +149,9 @@ struct PcTailArgs {
   const unsigned long long* erec;   // [n_rec][2] granules of the edge-node Hessian entries (see PcPhaseArgs)
   const int64_t* rec_slot;          // [n_rec] H slot of every record, -1: the site does not exist in this model
   const int32_t* rec_term;          // [n_rec] endpoint Hessian entry whose term is added to the record, or -1
-  int32_t n_rec, reserved1;
+  int32_t n_rec;
+  int32_t n_tail_blocks;            // workgroups sharing the tail's endpoint block (see pc_kernels.hpp, Tail)
+  unsigned long long* hb_gran;      // [n_pt_hess][2] endpoint Hessian terms handed from the helper tail blocks to block 0
   unsigned* timeout;                // host-visible word the tail sets when a granule never arrives (bounded spin)
   uint32_t epoch, reserved;
   PcTailPhase ph[PC_MAX_PHASES];

@@ -234,7 +234,9 @@ struct pc_handle {
   uint32_t epoch = 0;                        // tag of the last resident launch's granules (never 0)
   int spin_us = 500;                         // host-pointer calls poll the stream this long before blocking (PYCOLLO_AMD_SPIN_US)
   int tail_lds_bytes = 0, lds_nred = 0;
-  int res_tail_threads = 0;                  // a heavy endpoint block wants a 4-wave tail: the resident launch is widened to it
+  bool heavy_point = false;                  // the endpoint block is worth one tail workgroup per part when tiles are single waves
+  int tail_blocks_env = 0;
+  DevBuf<unsigned long long> d_hb_gran;      // endpoint Hessian terms handed between the tail's workgroups
   PinBuf<double> h_norms;
   std::vector<double> V_ocp, r_ocp, W_ocp;
   int n_launches = 0;
@@ -285,6 +287,8 @@ void fill_tail_args(pc_handle* h, PcTailArgs& t, const double* d_x, const double
   t.rec_slot = h->d_rec_slot.p;
   t.rec_term = h->d_rec_term.p;
   t.n_rec = h->n_rec;
+  t.n_tail_blocks = 1;
+  t.hb_gran = h->d_hb_gran.p;
   t.timeout = h->h_timeout.p;
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
@@ -419,13 +423,15 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     }
     for (size_t ip = Q.ph.size(); ip <= PC_MAX_PHASES; ++ip) m.first_block[ip] = nb;
     if (res) {
-      const int wide = std::max(h->TB * h->wpt_all, h->res_tail_threads);
-      m.tile_threads = h->TB * h->wpt_all;
+      const int bt = h->TB * h->wpt_all;
+      const int ntb = h->tail_blocks_env > 0 ? h->tail_blocks_env : ((h->heavy_point && bt < 256) ? 4 : 1);
+      m.tail_blocks = ntb;
       mr.t = h->host_tail_launch.t;
-      patch_tail(mr.t, wide);
+      patch_tail(mr.t, bt);
+      mr.t.n_tail_blocks = ntb;
       size_t sz = sizeof(mr);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &mr, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(h->bulk_all_res_fn, nb + 1, 1, 1, wide, 1, 1,
+      HIP_OK(hipModuleLaunchKernel(h->bulk_all_res_fn, nb + ntb, 1, 1, bt, 1, 1,
                                    std::max(h->lds_all, h->tail_lds_bytes), st, nullptr, cfg));
       return;
     }
@@ -460,11 +466,13 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
       BulkRes br;
       br.ba = ba;
       br.t = h->host_tail_launch.t;
-      const int wide = std::max((int)a.block_threads, h->res_tail_threads);
-      patch_tail(br.t, wide);
+      const int ntb = h->tail_blocks_env > 0 ? h->tail_blocks_env : ((h->heavy_point && a.block_threads < 256) ? 4 : 1);
+      br.ba.lead.wa |= ntb << 28;
+      patch_tail(br.t, a.block_threads);
+      br.t.n_tail_blocks = ntb;
       size_t sz = sizeof(br);
       void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &br, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-      HIP_OK(hipModuleLaunchKernel(D.fn_res, D.n_tiles + 1, 1, 1, wide, 1, 1,
+      HIP_OK(hipModuleLaunchKernel(D.fn_res, D.n_tiles + ntb, 1, 1, a.block_threads, 1, 1,
                                    std::max(D.lds_bytes, h->tail_lds_bytes), st, nullptr, cfg));
       return;
     }
@@ -732,8 +740,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     if (const char* env = std::getenv("PYCOLLO_AMD_SPIN_US")) h->spin_us = std::atoi(env);
     // the endpoint block is generated in four parts, one per wave of a 256-thread tail; a small block is not worth
     // the three extra waves every tile's workgroup then carries (they exit at their first instruction)
-    if (Q.point_x.size() + (size_t)Q.n_b + Q.pthess_row.size() > 16) h->res_tail_threads = PC_TAIL_THREADS;
-    if (const char* env = std::getenv("PYCOLLO_AMD_RES_TAIL_THREADS")) h->res_tail_threads = std::atoi(env);
+    h->heavy_point = Q.point_x.size() + (size_t)Q.n_b + Q.pthess_row.size() > 16;
+    if (const char* env = std::getenv("PYCOLLO_AMD_TAIL_BLOCKS")) h->tail_blocks_env = std::min(4, std::max(0, std::atoi(env)));
     // the tail's LDS carve (pc::tail_lds): acc | part | sum | xb | lb | hold | hb
     for (auto& P : Q.ph) h->lds_nred = std::max(h->lds_nred, P.nred);
     h->tail_lds_bytes = 8 * (int)(Q.tail_owned.size() + 17 * (size_t)h->lds_nred + Q.point_x.size() + (size_t)Q.n_b +
@@ -867,19 +875,20 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.gran.upload(std::vector<unsigned long long>((size_t)2 * std::max(1, P.nred) * D.n_tiles, 0ull));   // tag 0: never written
     }
     {
-      // Resident tail: every Hessian entry of the edge nodes 0 / N-1 reaches the tail workgroup as a record (two
-      // granules) and is stored by it, with the endpoint term that lands on the same slot where there is one.
-      // Records: per phase, node 0 then node N-1, the sites in the kernels' order (z-z entries, t strips, s strips).
+      // Resident tail: a Hessian entry of an edge node 0 / N-1 on which an endpoint term lands reaches the tail
+      // workgroup as a record (two granules); the tail adds the term and stores the entry.  Records are numbered per
+      // phase, node 0 then node N-1, in the kernels' site order (z-z entries, t strips, s strips) -- the order the
+      // generated kernels rank their compile-time flags in (codegen.edge_flags, S<M>::erank).
       std::map<int64_t, int32_t> term_of_slot;   // slot -> endpoint entry
       for (size_t e = 0; e < Q.pt_hslot.size(); ++e)
         if (Q.pt_hlocal[e] < 0) term_of_slot.emplace(Q.pt_hslot[e], (int32_t)e);
       std::vector<int64_t> rec_slot;
       std::vector<int32_t> rec_term;
-      size_t used = 0;
       for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
         auto& P = Q.ph[ip];
         const int NZ = P.n_z, NS = Q.n_s, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
         h->pd[ip]->erec0 = (int32_t)rec_slot.size();
+        int found[2] = {0, 0};
         for (int edge = 0; edge < 2; ++edge) {
           const int64_t node = edge ? P.N - 1 : 0;
           for (int site = 0; site < NE; ++site) {
@@ -890,15 +899,19 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
               const int64_t base = P.hoff[NZ + (site - NHZZ)];   // t strips (j, z) then s strips (l, z)
               if (base >= 0) slot = base + node;
             }
-            if (P.N == 1 && edge == 1) slot = -1;
             auto it = slot >= 0 ? term_of_slot.find(slot) : term_of_slot.end();
+            if (it == term_of_slot.end()) continue;
             rec_slot.push_back(slot);
-            rec_term.push_back(it == term_of_slot.end() ? -1 : it->second);
-            used += it == term_of_slot.end() ? 0 : 1;
+            rec_term.push_back(it->second);
+            term_of_slot.erase(it);
+            ++found[edge];
           }
         }
+        if (d->phases[ip].n_edge_rec[0] != found[0] || d->phases[ip].n_edge_rec[1] != found[1])
+          throw std::runtime_error("the phase descriptor's edge-record counts do not match the Hessian pattern "
+                                   "(codegen.edge_flags and pc_pattern.hpp disagree)");
       }
-      if (used != term_of_slot.size())
+      if (!term_of_slot.empty())
         throw std::runtime_error("internal error: an endpoint Hessian term lands on an edge-node entry no tile produces");
       h->n_rec = (int32_t)rec_slot.size();
       if (rec_slot.empty()) { rec_slot.push_back(-1); rec_term.push_back(-1); }
@@ -906,6 +919,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       h->d_rec_term.upload(rec_term);
       h->d_erec.upload(std::vector<unsigned long long>(2 * rec_slot.size(), 0ull));
     }
+    h->d_hb_gran.upload(std::vector<unsigned long long>(2 * std::max<size_t>(1, Q.pthess_row.size()), 0ull));
     h->h_timeout.alloc(16);
     std::memset(h->h_timeout.p, 0, 16 * sizeof(unsigned));
     h->d_point_x.upload(Q.point_x);

@@ -136,6 +136,12 @@ struct S {
       if (!(r >= NY && r < NY + NP) && dep(r, c)) return true;
     return false;
   }
+  // rank of an edge-node entry site among the flagged ones (M::efl), node 0's sites first
+  static constexpr int erank(int i) {
+    int n = 0;
+    for (int k = 0; k < i; ++k) n += M::efl(k) ? 1 : 0;
+    return n;
+  }
   // ---- reductions (per tile): [NQ] sum w g | [NQ*NS] sum w dg/ds | [NS] t-s | [NS*(NS+1)/2] s-s
   static constexpr int R_Q = 0, R_QS = NQ, R_TS = NQ + NQ * NS, R_SS = NQ + NQ * NS + NS;
   static constexpr int NRED = NQ + NQ * NS + NS + NS * (NS + 1) / 2;
@@ -429,7 +435,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     const int wa = LD->wa, wb = LD->wb;
     A.xz = LD->xz; A.lamd = LD->lamd; A.qa = LD->qa; A.sec_h = LD->sec_h; A.N = LD->N; A.K = LD->K;
     A.tile_begin = LD->tile_begin; A.n_blocks = LD->n_blocks;
-    A.flags = wa & 0xff; A.wpt = (wa >> 8) & 0xf; A.block_threads = ((wa >> 12) & 0xf) << 6; A.spt = wa >> 16;
+    A.flags = wa & 0xff; A.wpt = (wa >> 8) & 0xf; A.block_threads = ((wa >> 12) & 0xf) << 6; A.spt = (wa >> 16) & 0xfff;
     A.qa0 = wb & 0xffff; A.qwabs = wb >> 16;
   } else {
     A.x = MULTI ? mx : KA.x; A.lam = MULTI ? mlam : KA.lam; A.x_off = KA.x_off; A.c_off = KA.c_off; A.N = KA.N; A.K = KA.K;
@@ -1026,18 +1032,22 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
 
   // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
   const bool edge0 = (node == 0), edgeN = (node == N - 1);
-  // A Hessian entry of an edge node (0 or N-1) is stored -- except in the resident-tail build, where it goes to the
-  // tail workgroup as a record (an endpoint term may land on the same slot; the tail adds it and stores the entry).
-  // Record = erec0 + (node N-1 ? NEDGE : 0) + site: no table, no mask, one uniform scalar.
+  // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot: in the
+  // resident-tail build such an entry goes to the tail workgroup as a record (the tail adds the term and stores it).
+  // Which sites those are is a property of the model (M::efl, compile time); the record of a flagged site is
+  // erec0 + its rank among the flagged sites (node 0's first).  A model without such terms pays nothing.
   constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
   auto edge_store = [&](auto site_, double* dstp, double val) {
     constexpr int site = decltype(site_)::value;
-    if constexpr (RES) {
-      (void)dstp;
-      publish_granules(A.erec + 2 * (int64_t)(A.erec0 + (edge0 ? 0 : NEDGE) + site), A.epoch, val);
-    } else {
-      *dstp = val;
+    constexpr bool f0 = M::efl(site) != 0, fN = M::efl(NEDGE + site) != 0;
+    if constexpr (RES && (f0 || fN)) {
+      constexpr int r0 = PC_CE(St::erank(site)), rN = PC_CE(St::erank(NEDGE + site));
+      if (edge0 ? f0 : fN) {
+        publish_granules(A.erec + 2 * (int64_t)(A.erec0 + (edge0 ? r0 : rN)), A.epoch, val);
+        return;
+      }
     }
+    *dstp = val;
   };
   auto hess_second = [&]() {     // everything built from the second partials
     // bands: one variable block row at a time; rows with several entries go through the staging buffer
@@ -1517,8 +1527,11 @@ __device__ __forceinline__ void tail_point_load(const PcTailArgs& A, const TailL
   }
   // (the workgroup barrier of tail_begin, which follows, publishes the arrays)
 }
+// (tb, ntb): this workgroup is tail block tb of ntb -- a heavy endpoint block whose tiles run as single waves gets
+// one single-wave tail block per part instead of one four-wave block (a wider launch would cost every tile three
+// idle waves' registers); block tb evaluates the parts g with g % ntb == tb, one per wave.
 template <class PT>
-__device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailLds& L) {
+__device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailLds& L, int tb = 0, int ntb = 1) {
   constexpr int NPV = PT::NPV, NB = PT::NB, NGJ = PT::NGJ, NBJ = PT::NBJ, NPH = PT::NPH;
   const int tid = threadIdx.x, wave = tid >> 6, nw = (A.block_threads + 63) >> 6;
   if ((tid & 63) != 0) return;
@@ -1526,7 +1539,7 @@ __device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailL
   const bool wantH = A.flags & PC_FLAG_H;
   static_for<0, PT::NPARTS>([&](auto g_) {
     constexpr int g = decltype(g_)::value;
-    if (g % nw != wave) return;
+    if (g % ntb != tb || (g / ntb) % nw != wave) return;
     double xb[NPV > 0 ? NPV : 1], lb[NB > 0 ? NB : 1];
     static_for<0, NPV>([&](auto i_) { xb[decltype(i_)::value] = L.xb[decltype(i_)::value]; });
     static_for<0, NB>([&](auto r_) { lb[decltype(r_)::value] = L.lb[decltype(r_)::value]; });
@@ -1558,6 +1571,41 @@ __device__ __forceinline__ void tail_point_eval(const PcTailArgs& A, const TailL
       });
   });
 }
+// helper tail blocks hand the Hessian terms of their parts to block 0 as granules; block 0 collects them
+template <class PT>
+__device__ __forceinline__ void tail_point_publish(const PcTailArgs& A, const TailLds& L, int tb, int ntb) {
+  constexpr int NPH = PT::NPH;
+  lds_barrier();
+  if constexpr (NPH > 0) {
+    if (!(A.flags & PC_FLAG_H)) return;
+    for (int e = threadIdx.x; e < NPH; e += A.block_threads)
+      if (PT::part_hb(e) % ntb == tb) publish_granules(A.hb_gran + 2 * e, A.epoch, L.hb[e]);
+  }
+}
+template <class PT>
+__device__ __forceinline__ void tail_point_collect(const PcTailArgs& A, const TailLds& L, int ntb) {
+  constexpr int NPH = PT::NPH;
+  if constexpr (NPH > 0) {
+    if (ntb <= 1 || !(A.flags & PC_FLAG_H)) return;
+    unsigned spins = 0;
+    for (int e0 = 0; e0 < NPH; e0 += A.block_threads) {
+      const int e = e0 + threadIdx.x;
+      const bool mine = e < NPH && PT::part_hb(e) % ntb != 0;
+      double v = 0.0;
+      for (;;) {
+        bool ok = true;
+        if (mine) {
+          const unsigned long long lo = load_granule(A.hb_gran + 2 * e), hi = load_granule(A.hb_gran + 2 * e + 1);
+          ok = join_granules(lo, hi, A.epoch, v);
+        }
+        if (__all(ok)) break;
+        if (!spin_again(spins, A, 200u)) break;
+      }
+      if (mine) L.hb[e] = v;
+    }
+  }
+}
+
 // every endpoint Hessian term meets its slot: a tail-owned slot in LDS (each slot receives one term, after the
 // phases' sums), or an edge-node entry the bulk produced -- read back from H (separate launch) or received as
 // granules from the edge tile (resident build) -- plus the term

@@ -42,7 +42,8 @@ class _PhaseDesc(C.Structure):
                 ("K", C.c_int32), ("n_k", _i32p), ("h_k", _f64p),
                 ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
-                ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("eval_ops", C.c_int32)]
+                ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("n_edge_rec", C.c_int32 * 2),
+                ("eval_ops", C.c_int32)]
 
 
 class _ProblemDesc(C.Structure):
@@ -213,6 +214,8 @@ class NlpEngine:
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
             d.compiled_order = self.orders[i] if self.device >= 0 else 0
             d.eval_ops = pm.eval_ops
+            fl = codegen.edge_flags(m, pm)
+            d.n_edge_rec[0], d.n_edge_rec[1] = sum(fl[:len(fl) // 2]), sum(fl[len(fl) // 2:])
         pt = m.point
         pp = _i32([v.phase for v in pt.vars])
         pk = _i32([_KIND[v.kind] for v in pt.vars])

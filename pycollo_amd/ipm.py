@@ -85,6 +85,7 @@ class InteriorPointSolver:
         self.sf = 1.0                       # IPOPT's gradient-based NLP scaling (set in solve())
         self.sc = np.ones(self.m)
         self.counts = {"objective": 0, "gradient": 0, "constraints": 0, "jacobian": 0, "hessian": 0, "factorisations": 0}
+        self.kkt_seconds = 0.0              # wall time inside _solve_kkt (assembly, factorisations, solves, refinement)
 
     # ---- callbacks --------------------------------------------------------------------------------
     def _f(self, x):
@@ -324,11 +325,14 @@ class InteriorPointSolver:
             Sigma = np.where(self.hasl, zl / dlv, 0.0) + np.where(self.hasu, zu / duv, 0.0)
             W = self._W(v[:n], lam)
             grad_phi = g - np.where(self.hasl, mu / dlv, 0.0) + np.where(self.hasu, mu / duv, 0.0)
+            t_kkt = time.perf_counter()
             try:
                 dv, dlam, dw_last = self._solve_kkt(W, Sigma, J, -(grad_phi + JTlam), -c, dw_last)
             except RuntimeError:
                 status = "kkt_failure"
                 break
+            finally:
+                self.kkt_seconds += time.perf_counter() - t_kkt
             dzl = np.where(self.hasl, mu / dlv - zl - zl / dlv * dv, 0.0)
             dzu = np.where(self.hasu, mu / duv - zu + zu / duv * dv, 0.0)
             a_max = self._alpha_max(v, dv, tau)
@@ -417,8 +421,10 @@ class InteriorPointSolver:
             f, c = ft, ct
             g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
             J = self._J(v[:n])
+        ev = dict(self.counts)
+        ev["kkt_seconds"] = self.kkt_seconds
         return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
-                         inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=dict(self.counts), history=hist)
+                         inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist)
 
 
 class GpuInteriorPointSolver(InteriorPointSolver):
