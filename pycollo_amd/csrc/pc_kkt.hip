@@ -162,13 +162,10 @@ __device__ void block_solve(const double* M, int m, int ld, double* r) {
   }
   __syncthreads();
   for (int i = tid; i < m; i += nt) r[i] /= M[(size_t)i * ld + i];
-  for (int j = m - 1; j >= 0; --j) {
+  for (int j = m - 1; j > 0; --j) {   // L^T x = r, column-oriented: x_j is final, rows above it lose L[j][i] x_j
     __syncthreads();
-    if (tid == 0) {
-      double acc = r[j];
-      for (int i = j + 1; i < m; ++i) acc -= M[(size_t)i * ld + j] * r[i];
-      r[j] = acc;
-    }
+    const double rj = r[j];
+    for (int i = tid; i < j; i += nt) r[i] -= M[(size_t)j * ld + i] * rj;
   }
   __syncthreads();
 }
@@ -181,6 +178,8 @@ struct KArgs {
   int64_t border_off, base_chain, base_border;
   int32_t nb, n_leaf, n_chain;
   int* counts;                   // [n_leaf + n_chain + 1][2]
+  int32_t lds_doubles;           // doubles of dynamic LDS the launch provides
+  int32_t chain_lds, nzmax, wcmax;   // chain factorisation in LDS: largest node block and coupling width
   // solve
   double* r;                     // [nu] right-hand side, then the solution, in block order
   double* leafG;                 // per leaf: X_C^T r_l, w doubles at leafG_off
@@ -190,55 +189,86 @@ struct KArgs {
 
 __device__ __forceinline__ int nzb_of(const KArgs& a, int64_t c) { return (int)(a.chain_ptr[c + 1] - a.chain_ptr[c]); }
 
+// a leaf whose [A | C] fits the workgroup's LDS is eliminated there (every step of the elimination is a round trip
+// through the block: in LDS instead of L2) and written back once
 __global__ void kkt_leaf_factor(KArgs a) {
   extern __shared__ double lds[];
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int64_t l = blockIdx.x;
   const int m = (int)(a.leaf_ptr[l + 1] - a.leaf_ptr[l]);
   const int64_t left = a.leaf_left[l];
   const int w = nzb_of(a, left) + nzb_of(a, left + 1) + a.nb;
-  block_eliminate(a.vals + a.leafA_off[l], m, w, a.vals + a.leafS_off[l], a.counts + 2 * l, lds);
+  double* M = a.vals + a.leafA_off[l];
+  const int sz = m * (m + w);
+  if (sz + 2 * m + w <= a.lds_doubles) {
+    double* Ml = lds + 2 * m + w;
+    for (int e = tid; e < sz; e += nt) Ml[e] = M[e];
+    block_eliminate(Ml, m, w, a.vals + a.leafS_off[l], a.counts + 2 * l, lds);
+    for (int e = tid; e < sz; e += nt) M[e] = Ml[e];
+  } else {
+    block_eliminate(M, m, w, a.vals + a.leafS_off[l], a.counts + 2 * l, lds);
+  }
 }
 
-// one workgroup per phase walks its chain of boundary nodes in order
+// One workgroup per phase walks its chain of boundary nodes in order -- the sequential part of the factorisation.
+// When the largest node fits (a.chain_lds), a node's [D | E | F], its Schur block and the previous node's are kept in
+// LDS: the node's own entries and the two leaves' contributions arrive in one batch of global loads and every
+// elimination step stays on chip, so a step costs one global round trip instead of one per access; the results are
+// written back for the solves and the border.  Otherwise the same steps run on the value buffer itself.
 __global__ void kkt_chain_factor(KArgs a) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
   const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  const bool in_lds = a.chain_lds != 0;
+  // LDS regions of fixed size: staging | carried Schur block | M | S
+  double* carry = lds + (2 * a.nzmax + a.wcmax);
+  double* Ml = carry + a.wcmax * a.wcmax;
+  double* Sl = Ml + a.nzmax * (a.nzmax + a.wcmax);
   for (int64_t c = c0; c < c1; ++c) {
     const int nz = nzb_of(a, c), nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb, ld = nz + wc;
-    double* M = a.vals + a.chainD_off[c];
+    double* Mg = a.vals + a.chainD_off[c];
+    double* Sg = a.vals + a.chainS_off[c];
+    double* M = in_lds ? Ml : Mg;
+    double* S = in_lds ? Sl : Sg;
+    const double* Cr = in_lds ? carry : a.vals + a.chainS_off[c > c0 ? c - 1 : c];   // previous node's Schur block
     __syncthreads();
-    // the diagonal block was assembled as a lower triangle; the contributions below are full blocks: mirror first
-    for (int e = tid; e < nz * nz; e += nt) {
-      const int i = e / nz, k = e % nz;
-      if (k > i) M[(size_t)i * ld + k] = M[(size_t)k * ld + i];
+    // own entries: the diagonal block was assembled as a lower triangle, the contributions below are full blocks
+    if (in_lds) {
+      for (int e = tid; e < nz * ld; e += nt) {
+        const int i = e / ld, k = e % ld;
+        M[e] = (k < nz && k > i) ? Mg[(size_t)k * ld + i] : Mg[e];
+      }
+    } else {
+      for (int e = tid; e < nz * nz; e += nt) {
+        const int i = e / nz, k = e % nz;
+        if (k > i) M[(size_t)i * ld + k] = M[(size_t)k * ld + i];
+      }
     }
     __syncthreads();
     if (c > c0) {   // leaf on the left (its R and border rows) and the previous node's Schur block
       const int nl = nzb_of(a, c - 1);
-      const int64_t lf = a.leaf_of_left[c - 1];
-      const double* S = a.vals + a.leafS_off[lf];
-      const int ws = nl + nz + nb;
-      const double* Cr = a.vals + a.chainS_off[c - 1];   // (nz + nb)^2
-      const int wr = nz + nb;
-      for (int e = tid; e < nz * (nz + nb); e += nt) {
-        const int i = e / (nz + nb), k = e % (nz + nb);
-        const double add = S[(size_t)(nl + i) * ws + nl + k] + Cr[(size_t)i * wr + k];
-        M[(size_t)i * ld + (k < nz ? k : nx + k)] += add;
+      const double* SL = a.vals + a.leafS_off[a.leaf_of_left[c - 1]];
+      const int ws = nl + nz + nb, wr = nz + nb;
+      for (int e = tid; e < nz * wr; e += nt) {
+        const int i = e / wr, k = e % wr;
+        M[(size_t)i * ld + (k < nz ? k : nx + k)] += SL[(size_t)(nl + i) * ws + nl + k] + Cr[(size_t)i * wr + k];
       }
     }
     __syncthreads();
     if (!a.chain_last[c]) {   // leaf on the right: its L rows reach this node, the next one and the border
-      const int64_t lf = a.leaf_of_left[c];
-      const double* S = a.vals + a.leafS_off[lf];
-      const int ws = nz + nx + nb;
-      for (int e = tid; e < nz * ws; e += nt) {
-        const int i = e / ws, k = e % ws;
-        M[(size_t)i * ld + k] += S[(size_t)i * ws + k];
-      }
+      const double* SR = a.vals + a.leafS_off[a.leaf_of_left[c]];
+      for (int e = tid; e < nz * ld; e += nt) M[e] += SR[e];
     }
     __syncthreads();
-    block_eliminate(M, nz, wc, a.vals + a.chainS_off[c], a.counts + 2 * (a.n_leaf + c), lds);
+    block_eliminate(M, nz, wc, S, a.counts + 2 * (a.n_leaf + c), lds);
+    if (in_lds) {
+      for (int e = tid; e < nz * ld; e += nt) Mg[e] = M[e];
+      for (int e = tid; e < wc * wc; e += nt) {
+        const double v = S[e];
+        Sg[e] = v;
+        carry[e] = v;
+      }
+    }
     __threadfence_block();
   }
 }
@@ -411,6 +441,8 @@ struct pc_kkt {
   int64_t nu = 0, n_dst = 0, total = 0;
   int n_leaf = 0, n_chain = 0, n_phase = 0, nb = 0;
   int lds_leaf = 0, lds_chain = 0, lds_border = 0;
+  int lds_chain_factor = 0;
+  int lds_leaf_full = 0;   // LDS of the leaf factorisation: the largest leaf block that fits, plus its staging vectors
   Dev<double> vals, r, leafG, chainG, dvec, vin, vout, src_coef, mv_coef;
   Dev<int64_t> perm, leaf_ptr, chain_ptr, chain_phase_ptr, leaf_left, leafA_off, leafS_off, chainD_off, chainS_off,
       leaf_of_left, leafG_off, chainG_off, dst, run_ptr, diag_pos, mv_ptr;
@@ -497,7 +529,24 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     k->leafG_off.upload(leafG_off.data(), leafG_off.size());
     k->chainG_off.upload(chainG_off.data(), chainG_off.size());
     k->lds_leaf = (int)(8 * (2 * mmax + wmax + 2));
+    {
+      int64_t want = 0;
+      for (int64_t l = 0; l < d->n_leaf; ++l) {
+        const int64_t left = d->leaf_left[l], m = d->leaf_ptr[l + 1] - d->leaf_ptr[l];
+        const int64_t w = (d->chain_ptr[left + 1] - d->chain_ptr[left]) + (d->chain_ptr[left + 2] - d->chain_ptr[left + 1]) + d->nb;
+        const int64_t need = 8 * (m * (m + w) + 2 * m + w + 2);
+        if (need <= 64000) want = std::max(want, need);
+      }
+      k->lds_leaf_full = (int)std::max<int64_t>(want, k->lds_leaf);
+    }
     k->lds_chain = (int)(8 * (2 * nzmax + wcmax + 2));
+    {
+      const int64_t full = 8 * (2 * nzmax + wcmax + 2 * wcmax * wcmax + nzmax * (nzmax + wcmax) + 2);
+      k->args.nzmax = (int32_t)nzmax;
+      k->args.wcmax = (int32_t)wcmax;
+      k->args.chain_lds = full <= 64000 ? 1 : 0;
+      k->lds_chain_factor = (int)(k->args.chain_lds ? full : k->lds_chain);
+    }
     k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2));
     if (k->lds_leaf > 60000 || k->lds_chain > 60000 || k->lds_border > 60000)
       throw std::runtime_error("KKT block too large for the solver's LDS staging");
@@ -552,8 +601,12 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
                          k->src_kind.p, k->src_idx.p, k->src_coef.p, k->d_G, k->d_H, use_hess, k->n_dst);
     hipLaunchKernelGGL(kkt_diag, dim3((unsigned)((k->nu + 255) / 256)), dim3(256), 0, st, k->vals.p, k->diag_pos.p, k->fixed.p,
                        k->dvec.p, k->nu);
-    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
-    hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+    if (k->n_leaf) {
+      KArgs la = k->args;
+      la.lds_doubles = k->lds_leaf_full / 8;
+      hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(128), k->lds_leaf_full, st, la);
+    }
+    hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     KHIP(hipMemcpyAsync(k->h_counts.data(), k->counts.p, k->h_counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -141,6 +141,16 @@ class MeshIteration:
         solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
                      tol=tol, max_iter=max_iter, verbose=verbose)
         res = solver.solve(self.guess_x_tilde)
+        if linear_solver == "gpu" and not res.success:
+            # The two linear solvers round differently; on a degenerate NLP (a bang-bang solution on a coarse mesh) that
+            # can send the filter line search into its restoration phase on one path and not on the other.  A failed
+            # GPU-factorised solve is repeated once with the host factorisation before the mesh iteration is given up;
+            # the result says so.
+            first = res.status
+            solver = InteriorPointSolver(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
+                                         tol=tol, max_iter=max_iter, verbose=verbose)
+            res = solver.solve(self.guess_x_tilde)
+            res.evaluations["gpu_linear_solver_gave_up"] = first
         self.result = res
         self.x_tilde = res.x
         self.objective = res.objective / self.w                                 # scaling.py:186-189

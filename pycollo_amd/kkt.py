@@ -12,12 +12,13 @@ The matrix is *quasi-definite* whenever the (1,1) block is positive definite, so
 ordering with 1 x 1 pivots, and the signs of D are the inertia IPOPT's regularisation is driven by.  That freedom is
 spent on the collocation structure (no fill-reducing heuristic, no pivot search):
 
-  leaf (p, k)     the interior nodes of mesh section k of phase p: their z, path slacks and path multipliers, and the
-                  defect multipliers of the rows that end on those nodes.  Leaves touch each other only through
-                  separators, so all K leaves are eliminated at once (one workgroup each).
-  chain node      a section boundary node (its z, path slacks / multipliers) and the defect multipliers of the section
-  (p, k)          rows that end on it.  After the leaves are gone the boundary nodes of a phase form a block-tridiagonal
-                  chain, eliminated in order by one workgroup per phase.
+  leaf (p, k)     the nodes strictly inside a run of g consecutive mesh sections of phase p: their z, path slacks and
+                  path multipliers, and the defect multipliers of the rows that end on those nodes.  Leaves touch each
+                  other only through separators, so all leaves are eliminated at once (one workgroup each, dense).
+  chain node      the section boundary node between two leaves (its z, path slacks / multipliers) and the defect
+  (p, k)          multipliers of the rows that end on it.  After the leaves are gone these nodes form a
+                  block-tridiagonal chain per phase, eliminated in order by one workgroup per phase -- the only
+                  sequential part, which is why g > 1: g sections per leaf divide its length by g.
   border          everything global: integrals q, free times, static parameters, integral and endpoint multipliers,
                   endpoint slacks, and any endpoint variable an endpoint Hessian term couples across nodes.  Dense,
                   factorised last.
@@ -79,11 +80,12 @@ class KktTables:
     mv_coef: np.ndarray
 
 
-def _node_maps(engine):
-    """Per phase: section starts, node -> (is boundary, section index)."""
+def _node_maps(engine, group):
+    """Per phase: leaf boundaries (every ``group``-th section boundary), node -> (is boundary, leaf index)."""
     out = []
-    for mesh in engine.meshes:
-        s = np.asarray(mesh.s, dtype=np.int64)
+    for mesh, g in zip(engine.meshes, group):
+        s_all = np.asarray(mesh.s, dtype=np.int64)
+        s = np.unique(np.concatenate([s_all[::g], s_all[-1:]]))
         N = int(s[-1]) + 1
         is_b = np.zeros(N, bool)
         is_b[s] = True
@@ -92,17 +94,40 @@ def _node_maps(engine):
     return out
 
 
-def build_tables(engine, ineq_rows, fixed_v, row_scale) -> KktTables:
+LEAF_TARGET = 72   # unknowns a leaf should hold: its dense [A | C] then fits the workgroup's 64 KB of LDS
+
+
+def default_group(engine, ineq_rows) -> list[int]:
+    """Sections per leaf, per phase.  The chain of separators is eliminated node after node by one workgroup per
+    phase, ~10 us a node; a leaf costs its size cubed.  Merging g sections into a leaf divides the chain by g: g is the
+    largest that keeps a typical leaf near LEAF_TARGET unknowns."""
+    ineq = set(int(r) for r in np.asarray(ineq_rows).reshape(-1))
+    out = []
+    for pl, pm, mesh in zip(engine.layout.phases, engine.model.phases, engine.meshes):
+        n_mean = float(np.mean(mesh.n))
+        slack = sum(1 for mm in range(pm.n_p) if (pl.c_path_off + mm * pl.N) in ineq)
+        per_node = pm.n_z + pm.n_p + slack + pm.n_y
+        per_section = per_node * (n_mean - 1)
+        out.append(int(max(1, min(64, LEAF_TARGET // max(1.0, per_section)))))
+    return out
+
+
+def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None) -> KktTables:
     """``ineq_rows``: constraint rows with a slack (in order); ``fixed_v`` [n + ns]: primal unknowns held fixed;
-    ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise)."""
+    ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise); ``group``: mesh sections per leaf
+    (int or one per phase; default ``default_group``)."""
     lay, model = engine.layout, engine.model
+    if group is None:
+        group = default_group(engine, ineq_rows)
+    elif np.isscalar(group):
+        group = [int(group)] * len(lay.phases)
     n, m = engine.num_x, engine.num_c
     ineq_rows = np.asarray(ineq_rows, dtype=np.int64)
     ns = len(ineq_rows)
     nv, nu = n + ns, n + ns + m
     fixed = np.zeros(nu, bool)
     fixed[:nv] = np.asarray(fixed_v, bool)
-    maps = _node_maps(engine)
+    maps = _node_maps(engine, group)
     n_phase = len(lay.phases)
     chain_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) for mp in maps])]).astype(np.int64)
     leaf_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) - 1 for mp in maps])]).astype(np.int64)
@@ -289,12 +314,12 @@ class _Desc(C.Structure):
 class GpuKkt:
     """The factorisation object: ``pc_kkt_*`` bound to one engine's device-resident G~ / H~."""
 
-    def __init__(self, engine, ineq_rows, fixed_v, row_scale):
+    def __init__(self, engine, ineq_rows, fixed_v, row_scale, group=None):
         from .engine import load_library
         if engine.device < 0:
             raise RuntimeError("the KKT solver needs a GPU engine; pycollo_amd has no CPU fallback")
         self.engine = engine
-        self.tables = T = build_tables(engine, ineq_rows, fixed_v, row_scale)
+        self.tables = T = build_tables(engine, ineq_rows, fixed_v, row_scale, group)
         self._lib = lib = load_library()
         vp = C.c_void_p
         lib.pc_kkt_last_error.restype = C.c_char_p

@@ -56,11 +56,13 @@ CASES = [("hypersensitive", dict(K=30, order=6)), ("double_pendulum", {}), ("two
          ("free_flying_robot", dict(K=5, order=5)), ("shuttle", dict(K=6, order=4))]
 
 
+@pytest.mark.parametrize("group", [1, 3, None])
 @pytest.mark.parametrize("name,kw", CASES)
-def test_block_elimination_matches_a_general_sparse_solve(built, name, kw):
+def test_block_elimination_matches_a_general_sparse_solve(built, name, kw, group):
+    """``group``: mesh sections per leaf (1: one leaf per section; None: the default by leaf size)."""
     eng, ora, x, lam, ineq, fixed, sc, dvec = kkt_case(name, kw)
     G, H = ora.G(x), ora.H(x, 1.0, lam)
-    T = kkt.build_tables(eng, ineq, fixed, sc)
+    T = kkt.build_tables(eng, ineq, fixed, sc, group)
     assert T.n_primal == eng.num_x + len(ineq) and T.n_dual == eng.num_c
     R = RefKkt(T)
     K = reference_matrix(eng, G, H, ineq, fixed, sc, dvec)
