@@ -5,11 +5,18 @@
 
 A "step" is one fused ``pc_eval_all_device`` over the whole transcribed NLP with x~ and lambda already
 resident in HBM and c~, G~, H~ left in HBM.  N = 1: BASELINE.json configs[1] -- hypersensitive problem,
-1 phase, 2000 mesh sections x 6 Lobatto nodes = 10 001 collocation nodes.  N > 1: the mesh grows to
-2000*N sections and is sharded by contiguous section ranges, one rank per GPU (weak scaling: 10 001
-nodes per GPU); every step contains the path's exchange -- one all-gather of the ranks' CSR runs and
-per-tile partial sums, after which every rank holds the complete c~, G~, H~ (pycollo_amd/sharding.py).
-``value`` counts 10 001-node shard evaluations per second over the whole job (N x sharded evals/s).
+1 phase, 2000 mesh sections x 6 Lobatto nodes = 10 001 collocation nodes.
+
+N > 1 (one rank per GPU, RCCL): the NLP's mesh is sharded by contiguous section ranges; every step contains the
+path's exchange -- one all-gather of the ranks' CSR runs and per-tile partial sums, after which every rank holds the
+complete c~, G~, H~ (``--gather-root``: gather to rank 0 only) -- pycollo_amd/sharding.py.
+``value`` is always the evaluations per second of ONE NLP, never multiplied by the rank count:
+* ``--scaling strong`` (default, what BASELINE.json's metric says: the 10 k-node NLP on 1/2/4/8 GPUs): the SAME mesh
+  (``--sections`` in total) on every N.  At 10 k nodes an evaluation is 5 us and the exchange tens of us, so this
+  series goes DOWN with N; it goes up where the north_star puts sharding, e.g. ``--problem shuttle --sections 20000
+  --order 4`` (config 4) or ``--problem delta_iii --sections 3125 --order 5`` (config 5).
+* ``--scaling weak``: ``--sections`` per GPU, the mesh grows with N; ``value`` is still evaluations of that (N times
+  larger) NLP per second, and ``shard_evals_per_s`` = N x value is the per-shard rate.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`.
 """
@@ -82,7 +89,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--sections", type=int, default=2000, help="mesh sections per GPU")
+    ap.add_argument("--sections", type=int, default=2000, help="mesh sections (in total; per GPU with --scaling weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong", help="N > 1: same NLP on every N, or N times the mesh")
+    ap.add_argument("--gather-root", action="store_true", help="N > 1: gather the shards to rank 0 only instead of all-gather")
     ap.add_argument("--order", type=int, default=6, help="nodes per section")
     ap.add_argument("--problem", default="hypersensitive")
     ap.add_argument("--tpb", type=int, default=0, help="threads per block (0 = auto)")
@@ -143,7 +152,7 @@ def main():
     from pycollo_amd import problems
     from pycollo_amd.engine import NlpEngine
 
-    K_total = args.sections * world
+    K_total = args.sections * (world if args.scaling == "weak" else 1)
     prob = problems.REGISTRY[args.problem](K=K_total, order=args.order)
     if args.ragged:
         rr = np.random.default_rng(7)
@@ -188,8 +197,10 @@ def main():
         x = torch.from_numpy(rng.uniform(-0.45, 0.45, sh.num_x)).to(dev)
         lam = torch.from_numpy(np.random.default_rng(1235).normal(size=sh.num_c)).to(dev)
 
+        root = 0 if args.gather_root else None
+
         def step():
-            sh.evaluate_all_device(x, 1.0, lam, stream)
+            sh.evaluate_all_device(x, 1.0, lam, stream, root)
 
         def bulk_only():   # this rank's tiles only
             sh.engine.launch_bulk_only(x, lam, sh.c, sh.G, sh.H, stream)
@@ -216,11 +227,15 @@ def main():
             ref.close()
         alg_bytes = sh.local_algorithmic_bytes
         nph = len(prob.phases)
-        workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {K_total} mesh sections x {args.order} Lobatto nodes sharded by "
-                    f"section over {world} GPUs ({args.sections} sections = {args.sections * (args.order - 1) + 1} "
-                    f"nodes per GPU)")
+        workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {K_total} mesh sections x {args.order} Lobatto nodes "
+                    f"= {sh.engine.layout.phases[0].N} collocation nodes{' per phase' if nph > 1 else ''}, sharded by section over "
+                    f"{world} GPUs ({args.scaling} scaling)")
         extra = {"num_x": sh.num_x, "num_c": sh.num_c, "nnz_jac": sh.nnz_jac, "nnz_hess": sh.nnz_hess,
-                 "exchange": "one all_gather_into_tensor per evaluation (CSR runs of c, G, H + per-tile partial sums)"}
+                 "exchange": ("one gather to rank 0 per evaluation" if args.gather_root else "one all_gather_into_tensor per evaluation")
+                             + " (CSR runs of c, G, H + per-tile partial sums)",
+                 "exchange_padding_fraction": round(sh.plan.padding_fraction, 4),
+                 "backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        assert dist.get_world_size() == world == args.gpus
 
     def sync():
         torch.cuda.synchronize()
@@ -263,7 +278,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    evals_per_s = args.steps * world / dt if world > 1 else args.steps / dt
+    evals_per_s = args.steps / dt   # evaluations of ONE NLP per second, whatever the number of ranks
 
     # ---- dominant kernel (bulk): K back-to-back launches between two HIP events on the launch stream
     roofline = None
@@ -335,8 +350,11 @@ def main():
         out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6),
                "device_ms_per_step": round(dev_step_ms, 6) if roofline is not None else None,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic",
                "config": {"workload": workload, **extra}}
+        if world > 1 and args.scaling == "weak":
+            out["shard_evals_per_s"] = round(evals_per_s * world, 2)
         if roofline is not None:
             out["roofline"] = roofline
         if host is not None:

@@ -64,8 +64,17 @@ class ShardPlan:
             jmask = pm.jac_mask()
             hmask = pm.hess_mask()
             tz = [any(jmask[r, b] for r in range(pm.n_fn) if not (pm.n_y <= r < pm.n_y + pm.n_p)) for b in range(pm.n_v)]
+            # Ranks get contiguous tile ranges balanced by the nodes they hold (a rank's share of c~, G~, H~ is
+            # proportional to its nodes): on a ph-refined mesh tiles hold different numbers of nodes, and the exchange
+            # is padded to the longest share.
+            tile_nodes = np.diff(np.asarray(mesh.s, dtype=np.int64)[np.asarray(k0s, dtype=np.int64)])
+            cum = np.concatenate([[0], np.cumsum(tile_nodes)])
+            cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world + 1)]
+            cuts[0], cuts[-1] = 0, n_tiles
+            for r in range(1, world + 1):
+                cuts[r] = max(cuts[r], cuts[r - 1])
             for r in range(world):
-                tb, te = (n_tiles * r) // world, (n_tiles * (r + 1)) // world
+                tb, te = cuts[r], cuts[r + 1]
                 self.tile_ranges[r][ip] = (tb, te)
                 if te <= tb:
                     continue
@@ -110,6 +119,8 @@ class ShardPlan:
                       for s in self.segments]
         self.lengths = [len(i) for i in self.index]
         self.maxlen = max(self.lengths) if self.lengths else 0
+        # share of the gathered buffer that is padding (all_gather_into_tensor moves equal-sized pieces)
+        self.padding_fraction = 1.0 - sum(self.lengths) / max(1, world * self.maxlen)
 
 
 def _chunk_table(runs, chunk: int) -> np.ndarray:
@@ -172,10 +183,26 @@ class SegmentExchange:
         if not self.lib.pc_copy_runs(src.data_ptr(), dst.data_ptr(), tab.data_ptr(), tab.shape[0], stream):
             raise RuntimeError("pc_copy_runs failed: " + self.lib.pc_last_error().decode())
 
-    def run(self, buf):
+    def run(self, buf, root=None):
+        """Exchange in place.  ``root=None``: all-gather, every rank ends with the complete buffer.  ``root=r``: gather
+        to rank r only (the rank an NLP solver lives on): the other ranks send their share and keep their own."""
         import torch.distributed as dist
         torch = self.torch
         n = self.idx_me.numel()
+        if root is not None:
+            if buf.is_cuda:
+                self._copy_runs(buf, self.send, self.pack_tab)
+            elif n:
+                torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
+            ml = self.maxlen
+            pieces = [self.recv[q * ml:(q + 1) * ml] for q in range(self.world)] if self.rank == root else None
+            dist.gather(self.send, pieces, dst=root, group=self.group)
+            if self.rank == root:
+                if buf.is_cuda:
+                    self._copy_runs(self.recv, buf, self.unpack_tab)
+                elif self.unpack_dst.numel():
+                    buf.index_copy_(0, self.unpack_dst, self.recv.index_select(0, self.unpack_src))
+            return buf
         rehearsal = buf.is_cuda and dist.get_backend(self.group) == "gloo"
         if buf.is_cuda:
             self._copy_runs(buf, self.send, self.pack_tab)
@@ -225,9 +252,10 @@ class ShardedNlp:
         # algorithmic bytes this rank's kernels move per evaluation: its share of the outputs + the inputs it reads
         self.local_algorithmic_bytes = 8 * (plan.lengths[self.rank] + (eng.num_x + eng.num_c) // self.world)
 
-    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None):
+    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None, root=None):
         """Asynchronous on the torch stream that is current when called (must not be the default stream);
-        falls back to this object's own stream."""
+        falls back to this object's own stream.  ``root``: gather to that rank only (it alone finishes the evaluation
+        and holds the complete c~, G~, H~); default: every rank does."""
         import torch
         cur = torch.cuda.current_stream()
         ts = cur if cur.cuda_stream != 0 else self.tstream
@@ -235,6 +263,7 @@ class ShardedNlp:
         with torch.cuda.stream(ts):
             eng.launch_bulk_only(d_x, d_lam, self.c, self.G, self.H, ts.cuda_stream)
             if self.world > 1:
-                self.exchange.run(self.buf)
-            eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+                self.exchange.run(self.buf, root)
+            if root is None or self.rank == root:
+                eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
         return self.c, self.G, self.H

@@ -72,7 +72,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, kw, q):
+def _ragged(prob, K, seed=7):
+    rr = np.random.default_rng(seed)
+    for ph in prob.phases:
+        ph.mesh.number_mesh_sections = K
+        ph.mesh.mesh_section_sizes = rr.uniform(0.5, 1.5, K)
+        ph.mesh.number_mesh_section_nodes = rr.integers(3, 9, K)
+    return prob
+
+
+def _worker(rank, world, port, name, kw, q, root=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -80,29 +89,42 @@ def _worker(rank, world, port, name, kw, q):
     try:
         from pycollo_amd.engine import NlpEngine
         from pycollo_amd.sharding import SegmentExchange, ShardPlan
-        eng = NlpEngine(problems.REGISTRY[name](**kw), device=None)
+        kw = dict(kw)
+        ragged = kw.pop("ragged", False)
+        prob = problems.REGISTRY[name](**kw)
+        if ragged:
+            prob = _ragged(prob, kw["K"])
+        eng = NlpEngine(prob, device=None)
         plan = ShardPlan(eng, world)
         ref = np.random.default_rng(0).normal(size=plan.total)       # stands for [c | G | H | partials]
         buf = torch.full((plan.total,), float("nan"), dtype=torch.float64)
         mine = torch.from_numpy(plan.index[rank])
         buf[mine] = torch.from_numpy(ref)[mine]                      # what this rank's bulk kernels produce
-        SegmentExchange(plan, rank, torch.device("cpu")).run(buf)
+        SegmentExchange(plan, rank, torch.device("cpu")).run(buf, root)
         allidx = np.concatenate(plan.index)
-        ok = bool(np.array_equal(buf.numpy()[allidx], ref[allidx]))
-        untouched = np.setdiff1d(np.arange(plan.total), allidx)
-        ok = ok and bool(np.all(np.isnan(buf.numpy()[untouched])))
+        if root is None or rank == root:
+            ok = bool(np.array_equal(buf.numpy()[allidx], ref[allidx]))
+            untouched = np.setdiff1d(np.arange(plan.total), allidx)
+            ok = ok and bool(np.all(np.isnan(buf.numpy()[untouched])))
+        else:   # a sender keeps its own share and nothing else
+            ok = bool(np.array_equal(buf.numpy()[plan.index[rank]], ref[plan.index[rank]]))
+            others = np.setdiff1d(np.arange(plan.total), plan.index[rank])
+            ok = ok and bool(np.all(np.isnan(buf.numpy()[others])))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,kw", [("two_phase_transfer", dict(K=40, order=4)), ("hypersensitive", dict(K=300, order=6))])
-def test_exchange_world2_gloo(built, name, kw):
+@pytest.mark.parametrize("name,kw,root", [("two_phase_transfer", dict(K=40, order=4), None),
+                                          ("hypersensitive", dict(K=300, order=6), None),
+                                          ("delta_iii", dict(K=37, order=4, ragged=True), None),      # ph-refined style mesh
+                                          ("shuttle", dict(K=90, order=4, ragged=True), 0)])          # gather to rank 0
+def test_exchange_world2_gloo(built, name, kw, root):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, kw, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, kw, q, root)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -110,3 +132,16 @@ def test_exchange_world2_gloo(built, name, kw):
         assert p.exitcode == 0
     results = dict(q.get(timeout=10) for _ in range(2))
     assert results == {0: True, 1: True}
+
+
+def test_shares_are_balanced_by_nodes_on_a_refined_mesh(built):
+    """Contiguous tile ranges cut by node count: on a mesh with 3..8 nodes per section the longest share stays within
+    a few per cent of the mean (the all-gather is padded to the longest)."""
+    from pycollo_amd.engine import NlpEngine
+    from pycollo_amd.sharding import ShardPlan
+    eng = NlpEngine(_ragged(problems.shuttle(K=4000, order=4), 4000), device=None)
+    plan = ShardPlan(eng, 8)
+    assert plan.padding_fraction < 0.03
+    for ip, (k0, _) in enumerate(plan.tiles):
+        rs = [plan.tile_ranges[r][ip] for r in range(8)]
+        assert rs[0][0] == 0 and rs[-1][1] == len(k0) - 1 and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))

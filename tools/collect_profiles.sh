@@ -21,4 +21,6 @@ run shuttle60k --problem shuttle --sections 20000 --order 4 --steps 300 --warmup
 run shuttle600k --problem shuttle --sections 200000 --order 4 --steps 50 --warmup 10 &&
 run delta_iii12k --problem delta_iii --sections 3125 --order 5 --steps 100 --warmup 10 &&
 run shuttle6k --problem shuttle --sections 2000 --order 4 --steps 1000 --warmup 100 &&
-run space_station6k --problem space_station --sections 2000 --order 4 --steps 300 --warmup 30
+run space_station6k --problem space_station --sections 2000 --order 4 --steps 300 --warmup 30 ;
+# the raw traces are tens of MB per workload: condense on the box, ship only the summaries (copy them to profiles/)
+cd $R && PROFILES_DST=$R/gpurun_out/profiles_out python3 tools/summarise_profiles.py $TAG > /dev/null && rm -rf $OUT && ls $R/gpurun_out/profiles_out

@@ -7,7 +7,8 @@ import csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"profiles_{tag}")
-dst = os.path.join(root, "profiles")
+dst = os.environ.get("PROFILES_DST") or os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
 summary = {"_about": __doc__.split("\n\n")[1].replace("\n", " ")}
 for d in sorted(glob.glob(os.path.join(src, "*/"))):
     name = os.path.basename(d.rstrip("/"))
