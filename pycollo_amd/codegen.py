@@ -309,7 +309,19 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append('  const int ntb = (wa >> 28) & 7;   // leading workgroups that run the tail')
         parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+        parts.append('#ifdef PC_STATIC_W   // one instantiation per replica: what a replica does not own is dead code in its copy')
+        parts.append('  if (((wa >> 8) & 0xf) != PC_STATIC_W) return;   // (built for exactly that many waves per tile)')
+        parts.append('  const int blk = pc::xcd_major((int)blockIdx.x - ntb, n_blocks);')
+        parts.append('  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {')
+        for wv in range(4):
+            parts.append(f'#if PC_STATIC_W > {wv}')
+            parts.append(f'    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true, PC_STATIC_W, {wv}>(a, false, 0, blk, &ld); return;')
+            parts.append('#endif')
+        parts.append('    default: return;')
+        parts.append('  }')
+        parts.append('#else')
         parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - ntb, n_blocks), &ld);')
+        parts.append('#endif')
         parts.append('}')
     else:
         np_ = len(model.phases)
@@ -479,7 +491,7 @@ def kernel_resources(model: Model, orders=None) -> dict:
             f.write(generate_source(model, orders))
         cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
                "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
-               f"-I{CSRC}", "-o", os.path.join(tmp, "m.hsaco"), src]
+               f"-I{CSRC}", "-o", os.path.join(tmp, "m.hsaco"), src] + [f"-D{d}" for d in _extra_defines()]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{res.stderr[-4000:]}")

@@ -420,7 +420,7 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 // flags and the granule tag arrive as plain values (mx .. mepoch: the members of PcMultiArgs the kernel needs --
 // handed over as a pointer to the struct, a large kernel keeps the whole struct in scratch memory), the workgroup's
 // tile from its index relative to the phase's first block.
-template <class M, int UN, bool RES = false>
+template <class M, int UN, bool RES = false, int WN = 0, int WIDX = 0>
 __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, int first_block = 0, int block = -1,
                                      const PcLead* LD = nullptr, const double* mx = nullptr, const double* mlam = nullptr,
                                      double* mc = nullptr, double* mG = nullptr, double* mH = nullptr, int mflags = 0,
@@ -470,7 +470,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   }
   const int T = n1 - n0;                 // defect rows per state in this tile; nodes n0 .. n0+T
   const int tid = threadIdx.x;
-  const int W = A.wpt;                                        // 1, 2 or 4
+  const int W = WN > 0 ? WN : A.wpt;                          // 1, 2 or 4
   const int t = W > 1 ? (tid & 63) : tid;                     // node slot of this lane inside its replica
   const bool active = t <= T;
   const int node = n0 + t;
@@ -610,7 +610,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // runs -- states, Hessian row blocks, path rows are dealt round-robin.  W > 1 only with TN = 64 (a replica is
   // exactly one wave, so its private staging region needs no workgroup barrier).
   const int TN = W > 1 ? 64 : TB;
-  const int w = W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0;   // wave-uniform: branches on it are scalar
+  // (WN > 0: the replica index is a template argument -- see the kernel entry -- and everything a replica does not
+  //  own, node-function outputs included, is dead code in its instantiation)
+  const int w = WN > 0 ? WIDX : (W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0);   // wave-uniform: branches on it are scalar
   const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
