@@ -37,11 +37,14 @@ typedef struct {
   int32_t K;                       /* mesh sections */
   const int32_t* n_k;              /* [K] nodes per section, both ends included (mesh N_K) */
   const double* h_k;               /* [K] section widths in tau (mesh h_K), sum = 2 */
-  /* structural non-zeros of d[f|p|g]/d[z|s], sorted by (row, col); rows: n_y+n_p+n_q, cols: n_z+n_s */
+  /* structural non-zeros of d[f|p|g]/d[z|w], sorted by (row, col); rows: n_y+n_p+n_q, cols: n_z+n_w.
+   * w = the parameters of the node functions, i.e. everything in f, p, g that is not a node variable: the live
+   * reference keeps q, t0, tF and s as global symbols there (pycollo/backend.py:1526-1539,1565-1570).  With n_w = 0
+   * (w_kind = NULL) the parameters are the problem's n_s static parameters. */
   int32_t n_jac;
   const int32_t* jac_row;
   const int32_t* jac_col;
-  /* structural non-zeros of the node-Lagrangian Hessian in [z|s], lower triangle, sorted by (row, col) */
+  /* structural non-zeros of the node-Lagrangian Hessian in [z|w], lower triangle, sorted by (row, col) */
   int32_t n_hess;
   const int32_t* hess_row;
   const int32_t* hess_col;
@@ -53,6 +56,12 @@ typedef struct {
   int32_t eval_ops;                /* arithmetic operations in the phase's node functions and their derivatives
                                       (0 = unknown); a launch-shape hint only: heavy models share a tile between
                                       fewer waves because every sharing wave re-evaluates the node functions */
+  /* parameters of the node functions in x order: [integral variables f/p/g depend on | free times they depend on |
+   * all static parameters]; w_kind[l] = 0 static parameter, 1 integral variable, 2 free time; w_idx[l] = index
+   * within the kind (static: global index; integral: m; time: position among the phase's free times) */
+  int32_t n_w;
+  const int32_t* w_kind;
+  const int32_t* w_idx;
 } pc_phase_desc;
 
 typedef struct {

@@ -92,12 +92,22 @@ class CPort:
         src = ['#include "colloc_cpu.c"', ""]
         phase_meta = []
         for ip, P in enumerate(o.P):
-            vin = {s: sym.Symbol(f"v[{i}]") for i, s in enumerate(P.v)}
-            jac = sorted(P.dF)                                   # (r, c)
-            h2 = sorted(k for k in P.d2F if k[2] <= k[1])        # (r, c1, c2), c2 <= c1
+            # The port's node functions take [z | s]; the oracle's argument list also carries q and the free times
+            # (ref_numpy: P.v = z + q + t + s).  Models whose f, p, g depend on q or t are outside the port.
+            nqt = P.n_q + P.n_t
+            lo, hi = P.n_z, P.n_z + nqt
+            if any(lo <= k[1] < hi for k in P.dF):
+                raise NotImplementedError("the C port covers node functions of states, controls and static parameters "
+                                          "only (this model's depend on an integral or time variable)")
+            sh = lambda c: c if c < lo else c - nqt           # oracle index -> port index
+            vin = {s: sym.Symbol(f"v[{sh(i)}]") for i, s in enumerate(P.v) if not (lo <= i < hi)}
+            jac_o = sorted(P.dF)                                 # (r, c)
+            h2_o = sorted(k for k in P.d2F if k[2] <= k[1])      # (r, c1, c2), c2 <= c1
+            jac = [(r, sh(c)) for r, c in jac_o]
+            h2 = [(r, sh(c1), sh(c2)) for r, c1, c2 in h2_o]
             outs = [(f"F[{i}]", e) for i, e in enumerate(P.F)]
-            outs += [(f"J[{i}]", P.dF[k][0]) for i, k in enumerate(jac)]
-            outs += [(f"H2[{i}]", P.d2F[k][0]) for i, k in enumerate(h2)]
+            outs += [(f"J[{i}]", P.dF[k][0]) for i, k in enumerate(jac_o)]
+            outs += [(f"H2[{i}]", P.d2F[k][0]) for i, k in enumerate(h2_o)]
             src.append(f"static void node_p{ip}(const double* v, double* F, double* J, double* H2) {{")
             src.append("  (void)v; (void)F; (void)J; (void)H2;")
             src += _block(vin, P.consts, outs, f"p{ip}")

@@ -25,10 +25,10 @@ def mesh_error(ora: OracleNlp, xt):
     out = []
     for P in ora.P:
         mesh = P.mesh
-        z, q, stretch, _, s = ora._unpack(P, xt)
+        z, q, stretch, _, w = ora._unpack(P, xt)
         N, K = mesh.N, mesh.K
         y, u = z[:P.n_y], z[P.n_y:]
-        a = ora._args(P, z, s)
+        a = ora._args(P, z, w)
         dy = np.array([P.F_fn[i](*a) for i in range(P.n_y)])
         tau = mesh.tau
         ph = OracleMesh(ora.tables, mesh.h / mesh.h.sum(), mesh.nodes + 1)
@@ -47,7 +47,7 @@ def mesh_error(ora: OracleNlp, xt):
                 upoly = np.polynomial.Polynomial.fit(t_k, u[iu, i0:i1 + 1], deg=mesh.nodes[k] - 1, window=[0, 1])
                 u_ph[iu, sl] = upoly(ph.tau[sl])
         zp = np.vstack([y_ph, u_ph])
-        ap = [zp[i] for i in range(P.n_z)] + [np.full(ph.N, s[i]) for i in range(ora.n_s)]
+        ap = [zp[i] for i in range(P.n_z)] + [np.full(ph.N, w[i]) for i in range(P.n_w)]
         dy_ph = np.array([P.F_fn[i](*ap) for i in range(P.n_y)])           # [n_y][N_ph]
         I_dy = stretch * (ph.I_mat @ dy_ph.T)                               # [N_ph - 1][n_y]
         mmax = int(ph.nodes.max()) - 1

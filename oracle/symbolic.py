@@ -78,11 +78,21 @@ def assemble(prob, tables, V_ocp, r_ocp, W_ocp, w_J, meshes=None):
         p = [low(e) for e in ph.path_constraints]
         g = [low(e) for e, k in zip(ph.integrand_functions, qk) if k]
 
+        # q, t0, tF are the same symbols at every node (backend.py:1526-1539 maps y and u only)
+        q_all, jq = {}, 0
+        for i, k in enumerate(qk):
+            q_all[ph.integral_variables[i]] = qu[jq] if k else 0.5 * sum(q_b[i])
+            jq += 1 if k else 0
+        glob = dict(s_unscaled)
+        glob.update(q_all)
+        glob[ph.initial_time_variable] = t[0]
+        glob[ph.final_time_variable] = t[1]
+
         def at_nodes(e):
             out = []
             for i in range(N):
                 m = {zs[j]: zu[j][i] for j in range(n_z)}
-                m.update(s_unscaled)
+                m.update(glob)
                 out.append(e.subs(m, simultaneous=True))
             return out
 

@@ -110,10 +110,10 @@ def edge_flags(model: Model, pm: PhaseModel) -> list[int]:
     property of the model alone.  Sites per edge, in the kernels' order: the z-z entries of the node block (rows of
     ``pm.hess`` with both indices < n_z), the t strips (j, z), the s strips (l, z).  In the resident-tail build these
     entries travel from the edge tile to the tail workgroup as records; all others are stored by the tile."""
-    nz, ns = pm.n_z, model.n_s
+    nz, ns = pm.n_z, pm.n_s
     zz = [(r, c) for r, c, _ in pm.hess if r < nz and c < nz]
-    hm, jm = pm.hess_mask(), pm.jac_mask()
-    tz = [any(jm[r, b] for r in range(pm.n_fn) if not (pm.n_y <= r < pm.n_y + pm.n_p)) for b in range(nz)]
+    hm = pm.hess_mask()
+    tz = pm.t_strip_mask()
     n_t = int(pm.t_free[0]) + int(pm.t_free[1])
     ne = len(zz) + 2 * nz + ns * nz
     flags = [0] * (2 * ne)
@@ -132,8 +132,10 @@ def edge_flags(model: Model, pm: PhaseModel) -> list[int]:
             elif v.phase == pm.index and v.kind in ("t0", "tF") and n_t > 0 and tz[u.idx]:
                 j = 0 if v.kind == "t0" else (1 if pm.t_free[0] else 0)
                 site = len(zz) + j * nz + u.idx
-            elif v.kind == "s" and hm[nz + v.idx, u.idx]:
-                site = len(zz) + 2 * nz + v.idx * nz + u.idx
+            elif v.kind == "s" or (v.phase == pm.index and v.kind == "q"):  # strips of the non-time parameters
+                l = pm.param_index(0 if v.kind == "s" else 1, v.idx)
+                if l >= 0 and hm[nz + l, u.idx]:
+                    site = len(zz) + 2 * nz + l * nz + u.idx
             if site is not None:
                 flags[edge * ne + site] = 1
     return flags
@@ -160,6 +162,9 @@ def _phase_struct(pm: PhaseModel, model: Model | None = None) -> str:
              _constexpr_table("jc", [c for _, c, _ in pm.jac]),
              _constexpr_table("hr", [r for r, _, _ in pm.hess]),
              _constexpr_table("hc", [c for _, c, _ in pm.hess]),
+             "  // what each parameter v[NZ + l] is: kind 0 static parameter, 1 integral variable, 2 free time; index within its kind",
+             _constexpr_table("wk", pm.w_kind or [0] * pm.n_s),
+             _constexpr_table("wi", pm.w_idx or list(range(pm.n_s))),
              "  // edge-node Hessian entry sites (node 0, then node N-1) whose value goes to the tail as a record",
              _constexpr_table("efl", edge_flags(model, pm) if model is not None else []),
              "  __device__ static __forceinline__ void eval(const double* __restrict__ v, const double* __restrict__ mult,",

@@ -49,14 +49,14 @@ int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, i
 }
 
 // doubles of the output staging buffer of one phase: the longest CSR run a tile emits in one piece
-int phase_lds_out(const pcp::Phase& P, int n_s, int TB) {
+int phase_lds_out(const pcp::Phase& P, int TB) {
   int nmax = 0;
   for (int k = 0; k < P.K; ++k) nmax = std::max(nmax, (int)P.n_k[k]);
   int out = 0;
   for (int a = 0; a < P.n_y; ++a) {
     int Da = 0, Ca = P.n_t + (P.dep(a, a) ? 0 : 2);
     for (int b = 0; b < P.n_z; ++b) Da += P.dep(a, b) ? 1 : 0;
-    for (int l = 0; l < n_s; ++l) Ca += P.dep(a, P.n_z + l) ? 1 : 0;
+    for (int l = 0; l < P.n_w; ++l) Ca += (!P.is_t(l) && P.dep(a, P.n_z + l)) ? 1 : 0;   // time parameters add to the t columns
     out = std::max(out, (Da * nmax + Ca) * (TB - 1));
   }
   for (int m = 0; m < P.n_p; ++m) {
@@ -68,11 +68,11 @@ int phase_lds_out(const pcp::Phase& P, int n_s, int TB) {
   return out;
 }
 
-int phase_lds_bytes(const pcp::Phase& P, int n_s, int TB, int qa_total, int qw_total) {
+int phase_lds_bytes(const pcp::Phase& P, int TB, int qa_total, int qw_total) {
   int nfs = 0;
   for (int a = 0; a < P.n_y; ++a)
-    for (int l = 0; l < n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
-  return 8 * lds_doubles(TB, qa_total, qw_total, P.n_y, nfs, P.nred, phase_lds_out(P, n_s, TB));
+    for (int l = 0; l < P.n_w; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
+  return 8 * lds_doubles(TB, qa_total, qw_total, P.n_y, nfs, P.nred, phase_lds_out(P, TB));
 }
 
 template <class T>
@@ -499,7 +499,7 @@ void upload_scaling(pc_handle* h) {
   for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
     auto& P = Q.ph[ip];
     auto& D = *h->pd[ip];
-    const int NZ = P.n_z, NQ = P.n_q, NS = Q.n_s, NY = P.n_y, NP = P.n_p;
+    const int NZ = P.n_z, NQ = P.n_q, NS = P.n_w, NY = P.n_y, NP = P.n_p;
     std::vector<double> s(2 * NZ + 2 * NQ + 4 + 2 * NS + NY + NP + NQ, 0.0);
     const double* V = h->V_ocp.data() + P.ocp_x_off;
     const double* r = h->r_ocp.data() + P.ocp_x_off;
@@ -510,8 +510,8 @@ void upload_scaling(pc_handle* h) {
     for (int m = 0; m < NQ; ++m) s[o++] = r[NZ + m];
     for (int j = 0; j < 2; ++j) s[o++] = j < P.n_t ? V[NZ + NQ + j] : 1.0;
     for (int j = 0; j < 2; ++j) s[o++] = j < P.n_t ? r[NZ + NQ + j] : 0.0;
-    for (int l = 0; l < NS; ++l) s[o++] = h->V_ocp[Q.ocp_s_off + l];
-    for (int l = 0; l < NS; ++l) s[o++] = h->r_ocp[Q.ocp_s_off + l];
+    for (int l = 0; l < NS; ++l) s[o++] = h->V_ocp[P.wocp(l, Q.ocp_s_off)];   // parameters: q, t or s (pc_pattern.hpp)
+    for (int l = 0; l < NS; ++l) s[o++] = h->r_ocp[P.wocp(l, Q.ocp_s_off)];
     const double* W = h->W_ocp.data() + P.ocp_c_off;
     for (int a = 0; a < NY + NP + NQ; ++a) s[o++] = W[a];
     D.scal_host = s;
@@ -658,6 +658,11 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       P.jac_col.assign(s.jac_col, s.jac_col + s.n_jac);
       P.hess_row.assign(s.hess_row, s.hess_row + s.n_hess);
       P.hess_col.assign(s.hess_col, s.hess_col + s.n_hess);
+      if (s.n_w > 0) {
+        if (!s.w_kind || !s.w_idx) throw std::runtime_error("phase parameter arrays missing");
+        P.wkind.assign(s.w_kind, s.w_kind + s.n_w);
+        P.widx.assign(s.w_idx, s.w_idx + s.n_w);
+      }
       P.bulk_kernel = s.bulk_kernel ? s.bulk_kernel : "";
       P.eval_ops = s.eval_ops;
       for (int k = 0; k < s.K; ++k)
@@ -708,7 +713,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     if (auto_tb) {  // largest tile whose staging fits the 64 KiB of dynamic LDS a module kernel may request
       auto fits = [&](int tb) {
         for (auto& P : Q.ph)
-          if (phase_lds_bytes(P, Q.n_s, tb, (int)h->qa.size(), (int)h->qw.size()) > h->lds_limit) return false;
+          if (phase_lds_bytes(P, tb, (int)h->qa.size(), (int)h->qw.size()) > h->lds_limit) return false;
         return true;
       };
       while (TB > 64 && !fits(TB)) TB /= 2;
@@ -756,7 +761,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.tile_end = D.n_tiles;
       int nfs = 0;
       for (int a = 0; a < P.n_y; ++a)
-        for (int l = 0; l < Q.n_s; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
+        for (int l = 0; l < P.n_w; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
       D.nfs = nfs;
       // uniform section order: index arithmetic replaces the section tables
       bool same = true;
@@ -765,7 +770,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.spt = same ? (TC - 1) / (P.n_k[0] - 1) : 0;
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
-      D.lds_out = phase_lds_out(P, Q.n_s, TB);
+      D.lds_out = phase_lds_out(P, TB);
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
       // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle
@@ -886,7 +891,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       std::vector<int32_t> rec_term;
       for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
         auto& P = Q.ph[ip];
-        const int NZ = P.n_z, NS = Q.n_s, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
+        const int NZ = P.n_z, NS = P.n_w, NHZZ = (int)P.hslot0.size(), NE = NHZZ + 2 * NZ + NS * NZ;
         h->pd[ip]->erec0 = (int32_t)rec_slot.size();
         int found[2] = {0, 0};
         for (int edge = 0; edge < 2; ++edge) {

@@ -76,6 +76,28 @@ struct S {
     return n;
   }
   static constexpr bool own_sparse(int a) { return !dep(a, a); }  // D-only block of 2 entries
+  // ---- parameters of the node functions, v[NZ + l]: everything in f, p, g that is not a node variable, in x
+  //      order [integral variables | free times | static parameters] (M::wk = 1 / 2 / 0, M::wi = index within the
+  //      kind).  The live reference keeps q, t0, tF, s global inside f, p, g (backend.py:1526-1539).  A model
+  //      without q / t dependence has static parameters only and every helper below reduces to its old form.
+  static constexpr bool is_t(int l) { return M::wk(l) == 2; }
+  static constexpr bool is_q(int l) { return M::wk(l) == 1; }
+  static constexpr int NWT = [] {
+    int n = 0;
+    for (int l = 0; l < NS; ++l) n += is_t(l) ? 1 : 0;
+    return n;
+  }();
+  static constexpr int tpar(int jt) {   // parameter index of free time jt, or -1
+    for (int l = 0; l < NS; ++l)
+      if (is_t(l) && M::wi(l) == jt) return l;
+    return -1;
+  }
+  static constexpr int qpar(int m) {    // parameter index of integral variable m, or -1
+    for (int l = 0; l < NS; ++l)
+      if (is_q(l) && M::wi(l) == m) return l;
+    return -1;
+  }
+  // all parameters a row depends on (path rows: every one of them is a column of its own)
   static constexpr int nsdep(int r) {
     int n = 0;
     for (int l = 0; l < NS; ++l) n += dep(r, NZ + l) ? 1 : 0;
@@ -86,8 +108,25 @@ struct S {
     for (int ll = 0; ll < l; ++ll) n += dep(r, NZ + ll) ? 1 : 0;
     return n;
   }
-  static constexpr int C(int a) { return (own_sparse(a) ? 2 : 0) + NT + nsdep(a); }
-  // number of df/ds entries that must be staged for the section contraction, and their slot
+  // defect rows end with [q the state equation depends on | the NT free times, always | s it depends on]; a
+  // dependence on a time parameter adds to that time's column instead of opening one
+  static constexpr int nqdep(int r) {
+    int n = 0;
+    for (int l = 0; l < NS; ++l) n += (is_q(l) && dep(r, NZ + l)) ? 1 : 0;
+    return n;
+  }
+  static constexpr int nxdep(int r) {   // columns besides the times
+    int n = 0;
+    for (int l = 0; l < NS; ++l) n += (!is_t(l) && dep(r, NZ + l)) ? 1 : 0;
+    return n;
+  }
+  static constexpr int xpos(int r, int l) {   // position of a non-time parameter's column in that tail of the row
+    int n = 0;
+    for (int ll = 0; ll < l; ++ll) n += (!is_t(ll) && dep(r, NZ + ll)) ? 1 : 0;
+    return n + (is_q(l) ? 0 : NT);
+  }
+  static constexpr int C(int a) { return (own_sparse(a) ? 2 : 0) + NT + nxdep(a); }
+  // number of df/dw entries that must be staged for the section contraction, and their slot
   static constexpr int NFS = [] {
     int n = 0;
     for (int a = 0; a < NY; ++a) n += nsdep(a);
@@ -136,15 +175,55 @@ struct S {
       if (!(r >= NY && r < NY + NP) && dep(r, c)) return true;
     return false;
   }
+  // index of the Hessian entry (row, col) in v = [z | w], or -1
+  static constexpr int hidx(int r, int c) {
+    for (int e = 0; e < NH; ++e)
+      if (M::hr(e) == r && M::hc(e) == c) return e;
+    return -1;
+  }
+  // (t, z_c) strip: through the stretch factor, or through a second partial of a time parameter
+  static constexpr bool tzx(int c) {
+    if (tz(c)) return true;
+    for (int l = 0; l < NS; ++l)
+      if (is_t(l) && hidx(NZ + l, c) >= 0) return true;
+    return false;
+  }
   // rank of an edge-node entry site among the flagged ones (M::efl), node 0's sites first
   static constexpr int erank(int i) {
     int n = 0;
     for (int k = 0; k < i; ++k) n += M::efl(k) ? 1 : 0;
     return n;
   }
-  // ---- reductions (per tile): [NQ] sum w g | [NQ*NS] sum w dg/ds | [NS] t-s | [NS*(NS+1)/2] s-s
-  static constexpr int R_Q = 0, R_QS = NQ, R_TS = NQ + NQ * NS, R_SS = NQ + NQ * NS + NS;
-  static constexpr int NRED = NQ + NQ * NS + NS + NS * (NS + 1) / 2;
+  // ---- reductions (per tile): [NQ] sum w g | [NQ*NS] sum w dg/dw | [NS] t-w | [NS*(NS+1)/2] w-w   (w: parameters)
+  //      Only the sums with structure exist (a phase with five parameters would otherwise carry 32 of them, most
+  //      identically zero, through every tile and through the tail's registers): rqs / rts / rss give a sum's index,
+  //      counted in this order; pcp::finalize_phase_tables counts the same way on the host.
+  static constexpr int R_Q = 0;
+  static constexpr bool has_rts(int l) { return NT > 0 && tz(NZ + l); }
+  static constexpr int rqs(int m, int l) {   // sum_i w_i dg_m/dw_l
+    int n = NQ;
+    for (int mm = 0; mm < NQ; ++mm)
+      for (int ll = 0; ll < NS; ++ll) {
+        if (mm == m && ll == l) return n;
+        n += dep(NY + NP + mm, NZ + ll) ? 1 : 0;
+      }
+    return n;   // (m, l) = (NQ, 0): one past the last
+  }
+  static constexpr int rts(int l) {          // sum_i (mu . dF/dw_l)(z_i), f and g rows
+    int n = rqs(NQ, 0);
+    for (int ll = 0; ll < l; ++ll) n += has_rts(ll) ? 1 : 0;
+    return n;
+  }
+  static constexpr int rss(int l, int l2) {  // sum_i d2(node Lagrangian)/dw_l dw_l2
+    int n = rts(NS);
+    for (int e = 0; e < NH; ++e)
+      if (M::hc(e) >= NZ) {
+        if (M::hr(e) == NZ + l && M::hc(e) == NZ + l2) return n;
+        ++n;
+      }
+    return n;   // not present: one past the last
+  }
+  static constexpr int NRED = rss(NS, NS);
   // ---- packed scaling offsets
   static constexpr int O_VZ = 0, O_RZ = NZ, O_VQ = 2 * NZ, O_RQ = 2 * NZ + NQ, O_VT = 2 * NZ + 2 * NQ,
                        O_RT = O_VT + 2, O_VS = O_RT + 2, O_RS = O_VS + NS, O_WD = O_RS + NS, O_WP = O_WD + NY,
@@ -176,9 +255,9 @@ struct S {
     for (int b = 0; b < NZ; ++b) {
       wt[IT_HB + b] = hrow_count(b) > 0 ? hrow_count(b) + 1 : 0;
       int ns = 0;
-      for (int e = 0; e < NH; ++e) ns += (M::hr(e) >= NZ && M::hc(e) == b) ? 1 : 0;
+      for (int e = 0; e < NH; ++e) ns += (M::hr(e) >= NZ && !is_t(M::hr(e) - NZ) && M::hc(e) == b) ? 1 : 0;
       wt[IT_HS + b] = ns;
-      wt[IT_HT + b] = tz(b) ? NT : 0;
+      wt[IT_HT + b] = tzx(b) ? NT : 0;
     }
     wt[IT_HSUM] = NS > 0 ? NS + NS * (NS + 1) / 2 : 0;
     int load[W] = {};
@@ -202,8 +281,10 @@ struct S {
   }
   // which item a partial sum belongs to
   static constexpr int red_item(int r) {
-    if (r < R_QS) return IT_Q + (r - R_Q);
-    if (r < R_TS) return IT_Q + (r - R_QS) / (NS > 0 ? NS : 1);
+    if (r < NQ) return IT_Q + r;
+    for (int m = 0; m < NQ; ++m)
+      for (int l = 0; l < NS; ++l)
+        if (dep(NY + NP + m, NZ + l) && rqs(m, l) == r) return IT_Q + m;
     return IT_HSUM;
   }
 };
@@ -686,9 +767,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   double red[NRED > 0 ? NRED : 1];
   static_for<0, NRED>([&](auto r_) { red[decltype(r_)::value] = 0.0; });
   if (active) {
-    static_for<0, NS>([&](auto l_) {
+    static_for<0, NS>([&](auto l_) {   // parameters: static (after every phase), or this phase's q / free t
       constexpr int l = decltype(l_)::value;
-      v[NZ + l] = A.x[A.s_off + l];
+      constexpr int kind = M::wk(l), idx = M::wi(l);
+      v[NZ + l] = A.x[kind == 0 ? A.s_off + idx : A.x_off + (int64_t)NZ * N + (kind == 1 ? idx : NQ + idx)];
     });
   }
   double lam_p[NP > 0 ? NP : 1], lam_q[NQ > 0 ? NQ : 1];
@@ -931,7 +1013,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
   // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
   // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
-  constexpr bool SPLIT = (NJ + NH >= PC_SPLIT_MIN);
+  constexpr bool SPLIT = (NJ + NH >= PC_SPLIT_MIN) && St::NWT == 0;   // (time parameters: the t strips need both passes' values)
   constexpr bool RED_EARLY = RES && NS == 0 && NRED > 0;
   double mult[NFN > 0 ? NFN : 1];
   if (active) {
@@ -948,7 +1030,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         red[St::R_Q + m] = w_node * F[r];
         static_for<0, NS>([&](auto l_) {
           constexpr int l = decltype(l_)::value;
-          if constexpr (PC_CE(St::dep(r, NZ + l))) red[St::R_QS + m * NS + l] = w_node * Jv[PC_CE(St::jidx(r, NZ + l))];
+          if constexpr (PC_CE(St::dep(r, NZ + l))) red[PC_CE(St::rqs(m, l))] = w_node * Jv[PC_CE(St::jidx(r, NZ + l))];
         });
       });
     }
@@ -1088,7 +1170,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       static_for<0, NH>([&](auto e_) {
         constexpr int e = decltype(e_)::value;
         constexpr int rv = M::hr(e), cv = M::hc(e);
-        if constexpr (rv >= NZ && cv < NZ) {
+        if constexpr (rv >= NZ && cv < NZ && St::is_t(rv >= NZ ? rv - NZ : 0)) {
+          // a time parameter's strip is the t strip (hess_tstrips adds this entry to the stretch term)
+        } else if constexpr (rv >= NZ && cv < NZ) {
           if (mine(PC_ITEM(St::IT_HS + cv))) {
             double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
             const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
@@ -1096,7 +1180,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
           }
         } else if constexpr (rv >= NZ) {
           constexpr int l = rv - NZ, l2 = cv - NZ;
-          red[St::R_SS + l * (l + 1) / 2 + l2] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
+          red[PC_CE(St::rss(l, l2))] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
         }
       });
     }
@@ -1107,7 +1191,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       if constexpr (NT > 0) {
         static_for<0, NV>([&](auto c_) {
           constexpr int cvar = decltype(c_)::value;
-          if constexpr (PC_CE(St::tz(cvar))) {
+          if constexpr (cvar < NZ ? PC_CE(St::tzx(cvar)) : PC_CE(St::tz(cvar))) {
             double acc = 0.0;
             static_for<0, NFN>([&](auto r_) {
               constexpr int r = decltype(r_)::value;
@@ -1117,11 +1201,17 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
               if (mine(PC_ITEM(St::IT_HT + cvar))) static_for<0, NT>([&](auto j_) {
                 constexpr int j = decltype(j_)::value;
                 double* dstp = A.H + hoff[St::HO_T + j * NZ + cvar] + node;
-                const double val = dst[j] * sc[St::O_VZ + cvar] * acc;
+                double val = dst[j] * sc[St::O_VZ + cvar] * acc;
+                // f, p or g depends on this time itself: the node Lagrangian's second partial (t_j, z) joins the strip
+                constexpr int lt = PC_CE(St::tpar(j));
+                if constexpr (lt >= 0) {
+                  constexpr int eh = PC_CE(St::hidx(NZ + (lt >= 0 ? lt : 0), cvar));
+                  if constexpr (eh >= 0) val += sc[St::O_VS + lt] * sc[St::O_VZ + cvar] * Hv[eh];
+                }
                 if (edge0 || edgeN) edge_store(ic<St::NHZZ + j * NZ + cvar>{}, dstp, val); else *dstp = val;
               });
             } else {
-              red[St::R_TS + cvar - NZ] = acc;
+              red[PC_CE(St::rts(cvar - NZ))] = acc;
             }
           }
         });
@@ -1187,23 +1277,30 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         };
         if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r, cr);
         if (has_start) write_cols(ls_s, 0, n_s, cs);
-        if constexpr (NT + PC_CE(St::nsdep(a)) > 0) {
-          if (rowthr) {   // t and s columns of this lane's own row
+        if constexpr (NT + PC_CE(St::nxdep(a)) > 0) {
+          if (rowthr) {   // q, t and s columns of this lane's own row
             const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
             const int rs = row_off(ls_r, j, n) + Da * n + (PC_CE(St::own_sparse(a)) ? 2 : 0);
+            auto dfdw = [&](auto l_) -> double {   // W stretch V_l h_k sum_i A[j][i] df_a/dw_l(z_i)
+              constexpr int l = decltype(l_)::value;
+              const double* Arow = s_qa + QAO(n) + (j - 1) * n;
+              double as = 0.0;
+#pragma unroll
+              for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
+              return Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
+            };
             static_for<0, NT>([&](auto jt_) {
               constexpr int jt = decltype(jt_)::value;
-              s_out[rs + jt] = Wd * dst[jt] * accf[a];
+              double val = Wd * dst[jt] * accf[a];
+              constexpr int lt = PC_CE(St::tpar(jt));   // f_a depends on this time itself
+              if constexpr (lt >= 0) {
+                if constexpr (PC_CE(St::dep(a, NZ + (lt >= 0 ? lt : 0)))) val += dfdw(ic<(lt >= 0 ? lt : 0)>{});
+              }
+              s_out[rs + PC_CE(St::nqdep(a)) + jt] = val;
             });
             static_for<0, NS>([&](auto l_) {
               constexpr int l = decltype(l_)::value;
-              if constexpr (PC_CE(St::dep(a, NZ + l))) {
-                const double* Arow = s_qa + QAO(n) + (j - 1) * n;
-                double as = 0.0;
-#pragma unroll
-                for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
-                s_out[rs + NT + PC_CE(St::srank(a, l))] = Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
-              }
+              if constexpr (!St::is_t(l) && PC_CE(St::dep(a, NZ + l))) s_out[rs + PC_CE(St::xpos(a, l))] = dfdw(l_);
             });
           }
         }
@@ -1473,11 +1570,39 @@ __device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, T
         }
         if (A.flags & PC_FLAG_G) {
           int64_t o = P.gq_base[m];
-          A.G[o++] = Wi * vq[m];
-          static_for<0, NT>([&](auto jt_) { A.G[o++] = -Wi * dst[decltype(jt_)::value] * s_sum[St::R_Q + m]; });
+          auto dgdw = [&](auto l_) -> double {   // -W stretch V_l sum_i w_i dg_m/dw_l(z_i)
+            constexpr int l = decltype(l_)::value;
+            return -Wi * stretch * vs[l] * s_sum[PC_CE(St::rqs(m, l))];
+          };
+          // q columns, ascending: the integrals the integrand depends on, with q_m's own 1 among them
           static_for<0, NS>([&](auto l_) {
             constexpr int l = decltype(l_)::value;
-            if constexpr (PC_CE(St::dep(r, NZ + l))) A.G[o++] = -Wi * stretch * vs[l] * s_sum[St::R_QS + m * NS + l];
+            if constexpr (St::is_q(l) && M::wi(l) < m && PC_CE(St::dep(r, NZ + l))) A.G[o++] = dgdw(l_);
+          });
+          {
+            double val = Wi * vq[m];
+            constexpr int lq = PC_CE(St::qpar(m));
+            if constexpr (lq >= 0) {
+              if constexpr (PC_CE(St::dep(r, NZ + (lq >= 0 ? lq : 0)))) val += dgdw(ic<(lq >= 0 ? lq : 0)>{});
+            }
+            A.G[o++] = val;
+          }
+          static_for<0, NS>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            if constexpr (St::is_q(l) && M::wi(l) > m && PC_CE(St::dep(r, NZ + l))) A.G[o++] = dgdw(l_);
+          });
+          static_for<0, NT>([&](auto jt_) {
+            constexpr int jt = decltype(jt_)::value;
+            double val = -Wi * dst[jt] * s_sum[St::R_Q + m];
+            constexpr int lt = PC_CE(St::tpar(jt));
+            if constexpr (lt >= 0) {
+              if constexpr (PC_CE(St::dep(r, NZ + (lt >= 0 ? lt : 0)))) val += dgdw(ic<(lt >= 0 ? lt : 0)>{});
+            }
+            A.G[o++] = val;
+          });
+          static_for<0, NS>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            if constexpr (M::wk(l) == 0 && PC_CE(St::dep(r, NZ + l))) A.G[o++] = dgdw(l_);
           });
         }
       });
@@ -1487,7 +1612,9 @@ __device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, T
           if constexpr (NT > 0 && PC_CE(St::tz(NZ + l))) {
             static_for<0, NT>([&](auto jt_) {
               constexpr int jt = decltype(jt_)::value;
-              hacc[P.hsum_local[jt * NS + l]] += dst[jt] * vs[l] * s_sum[St::R_TS + l];
+              // d2/dt_j dw_l of stretch(t) (mu . F): dstretch/dt_j d(mu . F)/dw_l -- twice when w_l is t_j itself
+              constexpr double twice = (St::is_t(l) && M::wi(l) == jt) ? 2.0 : 1.0;
+              hacc[P.hsum_local[jt * NS + l]] += twice * (dst[jt] * vs[l] * s_sum[PC_CE(St::rts(l))]);
             });
           }
         });
@@ -1495,7 +1622,7 @@ __device__ __forceinline__ void tail_phase_finish(const PcTailArgs& A, int ip, T
           constexpr int e = decltype(e_)::value;
           if constexpr (M::hc(e) >= NZ) {
             constexpr int l = M::hr(e) - NZ, l2 = M::hc(e) - NZ;
-            hacc[P.hsum_local[2 * NS + l * (l + 1) / 2 + l2]] += s_sum[St::R_SS + l * (l + 1) / 2 + l2];
+            hacc[P.hsum_local[2 * NS + l * (l + 1) / 2 + l2]] += s_sum[PC_CE(St::rss(l, l2))];
           }
         });
       }
@@ -1713,7 +1840,9 @@ __device__ __forceinline__ void mesh_error(const PcRefineArgs& A) {
     h = A.sec_h[k];
     static_for<0, NS>([&](auto l_) {
       constexpr int l = decltype(l_)::value;
-      v[NZ + l] = sc[St::O_VS + l] * A.x[A.s_off + l] + sc[St::O_RS + l];
+      constexpr int kind = M::wk(l), idx = M::wi(l);   // static parameter, or this phase's q / free t
+      const int64_t col = kind == 0 ? A.s_off + idx : A.x_off + (int64_t)NZ * A.N + (kind == 1 ? idx : St::NQ + idx);
+      v[NZ + l] = sc[St::O_VS + l] * A.x[col] + sc[St::O_RS + l];
     });
     if (j < n) {   // this lane doubles as solution node j of its section
       static_for<0, NZ>([&](auto b_) {

@@ -4,13 +4,18 @@
 // Pattern rules (the reference obtains the same sets from
 // ca.jacobian's sparsity, pycollo/backend.py:1747-1761, or by NaN-probing, pycollo/iteration.py:928-1055):
 //   G defect row (a,k,j): for every z_b with df_a/dz_b != 0 the whole section run of n_k columns;
-//                         otherwise for b == a the two D entries (s_k, s_k+j); free times; s with
-//                         df_a/ds != 0.                       (compiled.py:305-334)
-//   G path row (m,i):     (b,i) for dp_m/dz_b != 0; s.         (compiled.py:336-355)
-//   G integral row m:     (b,0..N-1) for dg_m/dz_b != 0; q_m; free times; s.   (compiled.py:357-379)
+//                         otherwise for b == a the two D entries (s_k, s_k+j); q with df_a/dq != 0; free
+//                         times; s with df_a/ds != 0.          (compiled.py:305-334)
+//   G path row (m,i):     (b,i) for dp_m/dz_b != 0; the parameters p_m depends on.   (compiled.py:336-355)
+//   G integral row m:     (b,0..N-1) for dg_m/dz_b != 0; q_m and the q it depends on; free times; s.
+//                                                              (compiled.py:357-379)
 //   G endpoint row:       the point variables b_r depends on.  (compiled.py:381-403)
-//   H (lower triangle):   node bands (flag 1), t/s strips (flag 2), (t,s)/(s,s) sums (flag 3),
+//   H (lower triangle):   node bands (flag 1), parameter strips (flag 2), parameter-parameter sums (flag 3),
 //                         endpoint block.                      (compiled.py:479-500, sparse.py:48-61)
+// "Parameters" w of a phase's node functions: everything in f, p, g that is not a node variable, in x order
+// [q | free t | s] (the live reference leaves q, t0, tF, s global inside them, backend.py:1526-1539).  The free
+// times always have columns in the defect and integral rows and strips over the z that f or g depend on (the
+// stretch factor); a dependence of f, p, g on them adds to those entries.
 // Pure C++ (no HIP): unit-testable on a CPU-only machine.
 #pragma once
 
@@ -28,7 +33,9 @@ namespace pcp {
 
 struct Phase {
   // description
-  int n_y = 0, n_u = 0, n_q = 0, n_p = 0, n_s = 0;
+  int n_y = 0, n_u = 0, n_q = 0, n_p = 0;
+  int n_w = 0;                        // parameters of the node functions
+  std::vector<int32_t> wkind, widx;   // [n_w] 0 static parameter / 1 integral / 2 free time; index within the kind
   bool t_free[2] = {false, false};
   double t_fixed[2] = {0, 0};
   int K = 0;
@@ -52,6 +59,7 @@ struct Phase {
   int nred = 0;
 
   bool dep(int r, int c) const { return jmask[(size_t)r * n_v + c] != 0; }
+  // does sum_r mu_r dF_r/dv_c (r over f and g rows, the ones the stretch factor multiplies) have structure?
   bool tz(int c) const {
     for (int r = 0; r < n_fn; ++r)
       if (!(r >= n_y && r < n_y + n_p) && dep(r, c)) return true;
@@ -61,6 +69,26 @@ struct Phase {
     for (size_t e = 0; e < hess_row.size(); ++e)
       if (hess_row[e] == r && hess_col[e] == c) return true;
     return false;
+  }
+  bool is_t(int l) const { return wkind[l] == 2; }
+  // parameter index of free time jt, or -1 when the node functions do not depend on it
+  int tpar(int jt) const {
+    for (int l = 0; l < n_w; ++l)
+      if (wkind[l] == 2 && widx[l] == jt) return l;
+    return -1;
+  }
+  // (t, z_b) strip: through the stretch factor, or through a second partial d2F/dt dz_b
+  bool tzx(int b) const {
+    if (tz(b)) return true;
+    for (int l = 0; l < n_w; ++l)
+      if (wkind[l] == 2 && hdep(n_z + l, b)) return true;
+    return false;
+  }
+  int64_t wcol(int l, int64_t s_off) const {
+    return wkind[l] == 0 ? s_off + widx[l] : (wkind[l] == 1 ? q_off + widx[l] : t_off + widx[l]);
+  }
+  int wocp(int l, int ocp_s_off) const {
+    return wkind[l] == 0 ? ocp_s_off + widx[l] : ocp_x_off + n_z + (wkind[l] == 1 ? widx[l] : n_q + widx[l]);
   }
   int hrow_count(int b) const {
     int n = 0;
@@ -90,11 +118,27 @@ struct Problem {
 inline void fail(const std::string& msg) { throw std::runtime_error(msg); }
 
 inline void finalize_phase_tables(Phase& P, int n_s) {
-  P.n_s = n_s;
   P.n_z = P.n_y + P.n_u;
   P.n_t = (P.t_free[0] ? 1 : 0) + (P.t_free[1] ? 1 : 0);
   P.n_fn = P.n_y + P.n_p + P.n_q;
-  P.n_v = P.n_z + n_s;
+  if (P.wkind.empty()) {   // the problem's static parameters, nothing else
+    P.wkind.assign(n_s, 0);
+    P.widx.resize(n_s);
+    for (int l = 0; l < n_s; ++l) P.widx[l] = l;
+  }
+  P.n_w = (int)P.wkind.size();
+  if (P.widx.size() != P.wkind.size()) fail("parameter kind / index arrays differ in length");
+  for (int l = 0; l < P.n_w; ++l) {
+    const int k = P.wkind[l], i = P.widx[l];
+    if (k < 0 || k > 2 || i < 0 || i >= (k == 0 ? n_s : (k == 1 ? P.n_q : P.n_t))) fail("parameter out of range");
+    // x order: integrals, then times, then static parameters, ascending inside a kind
+    if (l > 0) {
+      const int k0 = P.wkind[l - 1], o0 = k0 == 0 ? 2 : k0 - 1, o1 = k == 0 ? 2 : k - 1;
+      if (o0 > o1 || (o0 == o1 && P.widx[l - 1] >= i)) fail("parameters must be listed in x order");
+    }
+  }
+  P.n_v = P.n_z + P.n_w;
+  const int n_w = P.n_w;
   if (P.K < 1) fail("a phase needs at least one mesh section");
   if (P.n_q > 8) fail("at most 8 integrals per phase are supported");
   if ((int)P.n_k.size() != P.K || (int)P.h_k.size() != P.K) fail("mesh arrays must have K entries");
@@ -121,7 +165,12 @@ inline void finalize_phase_tables(Phase& P, int n_s) {
     if (e > 0 && !(P.hess_row[e - 1] < r || (P.hess_row[e - 1] == r && P.hess_col[e - 1] < c)))
       fail("hessian mask entries must be sorted by (row, col)");
   }
-  P.nred = P.n_q + P.n_q * n_s + n_s + n_s * (n_s + 1) / 2;
+  // per-tile partial sums with structure, counted as pc::S<M>::rqs / rts / rss count them
+  P.nred = P.n_q;
+  for (int m = 0; m < P.n_q; ++m)
+    for (int l = 0; l < n_w; ++l) P.nred += P.dep(P.n_y + P.n_p + m, P.n_z + l) ? 1 : 0;
+  for (int l = 0; l < n_w; ++l) P.nred += (P.n_t > 0 && P.tz(P.n_z + l)) ? 1 : 0;
+  for (size_t e = 0; e < P.hess_row.size(); ++e) P.nred += P.hess_col[e] >= P.n_z ? 1 : 0;
 }
 
 inline void build_tiles(Phase& P, int TB) {
@@ -214,8 +263,15 @@ inline void build_G(Problem& Q) {
     int len = 0;
     for (int b = 0; b < P.n_z; ++b) len += P.dep(a, b) ? n : (b == a ? 2 : 0);
     len += P.n_t;
-    for (int l = 0; l < P.n_s; ++l) len += P.dep(a, P.n_z + l) ? 1 : 0;
+    for (int l = 0; l < P.n_w; ++l) len += (!P.is_t(l) && P.dep(a, P.n_z + l)) ? 1 : 0;
     return len;
+  };
+  // q columns of integral row m: its own q_m and every integral the integrand depends on
+  auto qcols = [](const Phase& P, int m) {
+    std::set<int> c{m};
+    for (int l = 0; l < P.n_w; ++l)
+      if (P.wkind[l] == 1 && P.dep(P.n_y + P.n_p + m, P.n_z + l)) c.insert(P.widx[l]);
+    return c;
   };
   int64_t nnz = 0;
   for (auto& P : Q.ph) {
@@ -229,8 +285,8 @@ inline void build_G(Problem& Q) {
     for (int m = 0; m < P.n_q; ++m) {
       const int r = P.n_y + P.n_p + m;
       for (int b = 0; b < P.n_z; ++b) nnz += P.dep(r, b) ? P.N : 0;
-      nnz += 1 + P.n_t;
-      for (int l = 0; l < P.n_s; ++l) nnz += P.dep(r, P.n_z + l) ? 1 : 0;
+      nnz += (int64_t)qcols(P, m).size() + P.n_t;
+      for (int l = 0; l < P.n_w; ++l) nnz += (P.wkind[l] == 0 && P.dep(r, P.n_z + l)) ? 1 : 0;
     }
   }
   nnz += (int64_t)Q.bjac_row.size();
@@ -262,9 +318,11 @@ inline void build_G(Problem& Q) {
               put(row, cb + j);
             }
           }
+          for (int l = 0; l < P.n_w; ++l)
+            if (P.wkind[l] == 1 && P.dep(a, P.n_z + l)) put(row, P.wcol(l, Q.s_off));
           for (int jt = 0; jt < P.n_t; ++jt) put(row, P.t_off + jt);
-          for (int l = 0; l < P.n_s; ++l)
-            if (P.dep(a, P.n_z + l)) put(row, Q.s_off + l);
+          for (int l = 0; l < P.n_w; ++l)
+            if (P.wkind[l] == 0 && P.dep(a, P.n_z + l)) put(row, P.wcol(l, Q.s_off));
         }
       }
     }
@@ -276,8 +334,8 @@ inline void build_G(Problem& Q) {
         Q.g_indptr[row] = p;
         for (int b = 0; b < P.n_z; ++b)
           if (P.dep(r, b)) put(row, P.x_off + (int64_t)b * P.N + i);
-        for (int l = 0; l < P.n_s; ++l)
-          if (P.dep(r, P.n_z + l)) put(row, Q.s_off + l);
+        for (int l = 0; l < P.n_w; ++l)          // parameters are listed in x order
+          if (P.dep(r, P.n_z + l)) put(row, P.wcol(l, Q.s_off));
       }
     }
     for (int m = 0; m < P.n_q; ++m) {
@@ -289,10 +347,10 @@ inline void build_G(Problem& Q) {
         if (P.dep(r, b))
           for (int i = 0; i < P.N; ++i) put(row, P.x_off + (int64_t)b * P.N + i);
       P.gq_base[m] = p;
-      put(row, P.q_off + m);
+      for (int mq : qcols(P, m)) put(row, P.q_off + mq);
       for (int jt = 0; jt < P.n_t; ++jt) put(row, P.t_off + jt);
-      for (int l = 0; l < P.n_s; ++l)
-        if (P.dep(r, P.n_z + l)) put(row, Q.s_off + l);
+      for (int l = 0; l < P.n_w; ++l)
+        if (P.wkind[l] == 0 && P.dep(r, P.n_z + l)) put(row, P.wcol(l, Q.s_off));
     }
   }
   Q.g_end_base = p;
@@ -321,19 +379,21 @@ inline int64_t find_in_row(const Problem& Q, int64_t row, int64_t col) {
 }
 
 inline void build_H(Problem& Q) {
-  // irregular entries: endpoint block + (t,s)/(s,s)/(t, ...) scalars; row -> sorted columns
+  // irregular entries: endpoint block + parameter-parameter scalars; row -> sorted columns
   std::map<int64_t, std::set<int64_t>> extra;
+  auto extra_lower = [&](int64_t a, int64_t b) { extra[std::max(a, b)].insert(std::min(a, b)); };
   for (size_t e = 0; e < Q.pthess_row.size(); ++e) {
     const int r = Q.pthess_row[e], c = Q.pthess_col[e];
     if (r < 0 || r >= (int)Q.point_x.size() || c < 0 || c > r) fail("endpoint Hessian entry out of range");
     extra[Q.point_x[r]].insert(Q.point_x[c]);
   }
   for (auto& P : Q.ph) {
-    for (int l = 0; l < Q.n_s; ++l) {
-      if (P.n_t > 0 && P.tz(P.n_z + l))
-        for (int jt = 0; jt < P.n_t; ++jt) extra[Q.s_off + l].insert(P.t_off + jt);
+    for (int l = 0; l < P.n_w; ++l) {
+      const int64_t cl = P.wcol(l, Q.s_off);
+      if (P.n_t > 0 && P.tz(P.n_z + l))       // d2/dt dw of stretch(t) * (mu . F)
+        for (int jt = 0; jt < P.n_t; ++jt) extra_lower(cl, P.t_off + jt);
       for (int l2 = 0; l2 <= l; ++l2)
-        if (P.hdep(P.n_z + l, P.n_z + l2)) extra[Q.s_off + l].insert(Q.s_off + l2);
+        if (P.hdep(P.n_z + l, P.n_z + l2)) extra_lower(cl, P.wcol(l2, Q.s_off));
     }
   }
   std::vector<int32_t> rows, cols;
@@ -359,6 +419,9 @@ inline void build_H(Problem& Q) {
     }
     reg.clear();
   };
+  auto strip = [&](const Phase& P, int b) {
+    for (int i = 0; i < P.N; ++i) reg.push_back(P.x_off + (int64_t)b * P.N + i);
+  };
   for (auto& P : Q.ph) {
     const int N = P.N;
     for (int b = 0; b < P.n_z; ++b) {
@@ -370,20 +433,26 @@ inline void build_H(Problem& Q) {
         emit_row(P.x_off + (int64_t)b * N + i);
       }
     }
-    for (int m = 0; m < P.n_q; ++m) emit_row(P.q_off + m);
+    for (int m = 0; m < P.n_q; ++m) {
+      for (int l = 0; l < P.n_w; ++l)
+        if (P.wkind[l] == 1 && P.widx[l] == m)
+          for (int b = 0; b < P.n_z; ++b)
+            if (P.hdep(P.n_z + l, b)) strip(P, b);
+      emit_row(P.q_off + m);
+    }
     for (int jt = 0; jt < P.n_t; ++jt) {
       for (int b = 0; b < P.n_z; ++b)
-        if (P.tz(b))
-          for (int i = 0; i < N; ++i) reg.push_back(P.x_off + (int64_t)b * N + i);
+        if (P.tzx(b)) strip(P, b);
       emit_row(P.t_off + jt);
     }
   }
-  for (int l = 0; l < Q.n_s; ++l) {
+  for (int ls = 0; ls < Q.n_s; ++ls) {
     for (auto& P : Q.ph)
-      for (int b = 0; b < P.n_z; ++b)
-        if (P.hdep(P.n_z + l, b))
-          for (int i = 0; i < P.N; ++i) reg.push_back(P.x_off + (int64_t)b * P.N + i);
-    emit_row(Q.s_off + l);
+      for (int l = 0; l < P.n_w; ++l)
+        if (P.wkind[l] == 0 && P.widx[l] == ls)
+          for (int b = 0; b < P.n_z; ++b)
+            if (P.hdep(P.n_z + l, b)) strip(P, b);
+    emit_row(Q.s_off + ls);
   }
   Q.h_indptr[Q.num_x] = (int64_t)rows.size();
   if (rows.size() >= (size_t)INT32_MAX) fail("Hessian has too many non-zeros for 32-bit IPOPT indices");
@@ -394,8 +463,8 @@ inline void build_H(Problem& Q) {
   std::set<int64_t> bulk_edge;   // slots the bulk kernels write at nodes 0 / N-1 (or strips' ends)
   std::set<int64_t> owned;       // slots only the tail writes
   for (auto& P : Q.ph) {
-    const int N = P.N, NZ = P.n_z, NS = Q.n_s;
-    P.hoff.assign(NZ + 2 * NZ + NS * NZ, -1);
+    const int N = P.N, NZ = P.n_z, NW = P.n_w;
+    P.hoff.assign(NZ + 2 * NZ + NW * NZ, -1);
     for (int b = 0; b < NZ; ++b) {
       const int mb = P.hrow_count(b);
       if (mb > 0 && N >= 3) {
@@ -418,37 +487,33 @@ inline void build_H(Problem& Q) {
       bulk_edge.insert(P.hslot0.back());
       bulk_edge.insert(P.hslotN.back());
     }
+    auto strip_slot = [&](int64_t row, int b, const char* what) {
+      const int64_t s0 = find_in_row(Q, row, P.x_off + (int64_t)b * N);
+      if (find_in_row(Q, row, P.x_off + (int64_t)b * N + N - 1) != s0 + N - 1)
+        fail(std::string("internal error: ") + what + " strip is not contiguous");
+      bulk_edge.insert(s0);
+      bulk_edge.insert(s0 + N - 1);
+      return s0;
+    };
     for (int jt = 0; jt < P.n_t; ++jt)
       for (int b = 0; b < NZ; ++b)
-        if (P.tz(b)) {
-          const int64_t s0 = find_in_row(Q, P.t_off + jt, P.x_off + (int64_t)b * N);
-          if (find_in_row(Q, P.t_off + jt, P.x_off + (int64_t)b * N + N - 1) != s0 + N - 1)
-            fail("internal error: t strip is not contiguous");
-          P.hoff[NZ + jt * NZ + b] = s0;
-          bulk_edge.insert(s0);
-          bulk_edge.insert(s0 + N - 1);
-        }
-    for (int l = 0; l < NS; ++l)
+        if (P.tzx(b)) P.hoff[NZ + jt * NZ + b] = strip_slot(P.t_off + jt, b, "t");
+    for (int l = 0; l < NW; ++l)          // strips of the time parameters are the t strips above
       for (int b = 0; b < NZ; ++b)
-        if (P.hdep(NZ + l, b)) {
-          const int64_t s0 = find_in_row(Q, Q.s_off + l, P.x_off + (int64_t)b * N);
-          if (find_in_row(Q, Q.s_off + l, P.x_off + (int64_t)b * N + N - 1) != s0 + N - 1)
-            fail("internal error: s strip is not contiguous");
-          P.hoff[3 * NZ + l * NZ + b] = s0;
-          bulk_edge.insert(s0);
-          bulk_edge.insert(s0 + N - 1);
-        }
-    P.hsum_slot.assign(2 * NS + NS * (NS + 1) / 2, -1);
-    for (int l = 0; l < NS; ++l) {
+        if (!P.is_t(l) && P.hdep(NZ + l, b)) P.hoff[3 * NZ + l * NZ + b] = strip_slot(P.wcol(l, Q.s_off), b, "parameter");
+    P.hsum_slot.assign(2 * NW + NW * (NW + 1) / 2, -1);
+    auto lower_slot = [&](int64_t a, int64_t b) { return find_in_row(Q, std::max(a, b), std::min(a, b)); };
+    for (int l = 0; l < NW; ++l) {
+      const int64_t cl = P.wcol(l, Q.s_off);
       if (P.n_t > 0 && P.tz(NZ + l))
         for (int jt = 0; jt < P.n_t; ++jt) {
-          P.hsum_slot[jt * NS + l] = find_in_row(Q, Q.s_off + l, P.t_off + jt);
-          owned.insert(P.hsum_slot[jt * NS + l]);
+          P.hsum_slot[jt * NW + l] = lower_slot(cl, P.t_off + jt);
+          owned.insert(P.hsum_slot[jt * NW + l]);
         }
       for (int l2 = 0; l2 <= l; ++l2)
         if (P.hdep(NZ + l, NZ + l2)) {
-          P.hsum_slot[2 * NS + l * (l + 1) / 2 + l2] = find_in_row(Q, Q.s_off + l, Q.s_off + l2);
-          owned.insert(P.hsum_slot[2 * NS + l * (l + 1) / 2 + l2]);
+          P.hsum_slot[2 * NW + l * (l + 1) / 2 + l2] = lower_slot(cl, P.wcol(l2, Q.s_off));
+          owned.insert(P.hsum_slot[2 * NW + l * (l + 1) / 2 + l2]);
         }
     }
   }

@@ -43,7 +43,7 @@ class _PhaseDesc(C.Structure):
                 ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
                 ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("n_edge_rec", C.c_int32 * 2),
-                ("eval_ops", C.c_int32)]
+                ("eval_ops", C.c_int32), ("n_w", C.c_int32), ("w_kind", _i32p), ("w_idx", _i32p)]
 
 
 class _ProblemDesc(C.Structure):
@@ -214,6 +214,10 @@ class NlpEngine:
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
             d.compiled_order = self.orders[i] if self.device >= 0 else 0
             d.eval_ops = pm.eval_ops
+            if pm.w_kind:
+                wk, wi = _i32(pm.w_kind), _i32(pm.w_idx)
+                keep += [wk, wi]
+                d.n_w, d.w_kind, d.w_idx = len(wk), _ptr(wk, _i32p), _ptr(wi, _i32p)
             fl = codegen.edge_flags(m, pm)
             d.n_edge_rec[0], d.n_edge_rec[1] = sum(fl[:len(fl) // 2]), sum(fl[len(fl) // 2:])
         pt = m.point

@@ -16,9 +16,12 @@ and for the endpoint functions (objective ``J``, endpoint constraints ``b``) val
 Hessian w.r.t. the point variables (pycollo/backend.py:1439-1446, compiled.py:61-121,381-403,479-482).
 
 Derivatives are taken w.r.t. *unscaled* variables; the scaling chain rule (x = V x~ + r,
-pycollo/backend.py:263-280) is applied by the kernels.  Dynamics may depend on states, controls and
-static parameters only -- the reference's explicit Jacobian has no d(zeta,gamma,rho)/d(q,t) blocks
-besides the stretch terms (compiled.py:254,263-264,324-328,371-374).
+pycollo/backend.py:263-280) is applied by the kernels.  Dynamics, path constraints and integrands may depend on
+states, controls, static parameters and -- as in the live reference, which substitutes y and u per node and leaves
+q, t0, tF, s global (pycollo/backend.py:1526-1539,1565-1570) -- on the phase's integral variables and its free
+initial / final time variables.  (The reference's dead explicit Jacobian has no d(zeta,gamma,rho)/d(q,t) blocks besides
+the stretch terms, compiled.py:254,263-264,324-328,371-374.)  Everything that is not a node variable is a *parameter*
+of the node functions: ``s`` lists them in x order, [used q | used free t | static parameters].
 """
 from __future__ import annotations
 
@@ -46,7 +49,7 @@ class PhaseModel:
     t_free: tuple[bool, bool]
     t_fixed: tuple[float, float]
     z: list[sym.Symbol]
-    s: list[sym.Symbol]
+    s: list[sym.Symbol]          # parameters of the node functions: [used q | used free t | static parameters]
     f: list[sym.Expr]
     p: list[sym.Expr]
     g: list[sym.Expr]
@@ -65,6 +68,39 @@ class PhaseModel:
     p_bounds: list[tuple[float, float]] = field(default_factory=list)
     y_t0_bounds: list[tuple[float, float]] = field(default_factory=list)
     y_tF_bounds: list[tuple[float, float]] = field(default_factory=list)
+    # what each parameter is: kind 0 = static parameter (idx = its global index), 1 = integral variable (idx = m),
+    # 2 = free time variable (idx = position among the phase's free times); empty = all static
+    w_kind: list[int] = field(default_factory=list)
+    w_idx: list[int] = field(default_factory=list)
+
+    @property
+    def n_wq(self) -> int:
+        return sum(1 for k in self.w_kind if k == 1)
+
+    @property
+    def n_wt(self) -> int:
+        return sum(1 for k in self.w_kind if k == 2)
+
+    def param_index(self, kind: int, idx: int) -> int:
+        """Position in ``s`` of the parameter (kind, idx), or -1 when the node functions do not depend on it."""
+        if not self.w_kind:
+            return idx if kind == 0 else -1
+        for l, (k, i) in enumerate(zip(self.w_kind, self.w_idx)):
+            if k == kind and i == idx:
+                return l
+        return -1
+
+    def t_strip_mask(self) -> list[bool]:
+        """Per node variable b: does the Hessian carry a (t, z_b) strip?  Through the stretch factor when a state
+        equation or an integrand depends on z_b; through a second partial when any row depends on (t, z_b)."""
+        jm, hm = self.jac_mask(), self.hess_mask()
+        out = []
+        for b in range(self.n_z):
+            on = any(jm[r, b] for r in range(self.n_fn) if not (self.n_y <= r < self.n_y + self.n_p))
+            for l, k in enumerate(self.w_kind):
+                on = on or (k == 2 and bool(hm[self.n_z + l, b]))
+            out.append(bool(on))
+        return out
 
     @property
     def eval_ops(self) -> int:
@@ -248,7 +284,17 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
         z_canon = [sym.Symbol(f"z{i}", real=True) for i in range(len(z_user))]
         var_map = dict(zip(z_user, z_canon))
         var_map.update(s_map)
-        primitives = set(ph._y) | set(ph._u) | set(s_user)
+        # q, t0, tF inside f / p / g: needed ones become parameters, eliminated ones constants
+        q_user = list(ph.integral_variables)
+        t_user = [ph.initial_time_variable, ph.final_time_variable]
+        consts.update({q_: pool.get(str(q_), 0.5 * (lo + hi)) for q_, (lo, hi), nd in zip(q_user, q_b, q_need) if not nd})
+        consts.update({t_: pool.get(str(t_), 0.5 * (lo + hi)) for t_, (lo, hi), nd in zip(t_user, (t0_b, tF_b), t_need) if not nd})
+        q_kept = [q_ for q_, nd in zip(q_user, q_need) if nd]
+        t_kept = [t_ for t_, nd in zip(t_user, t_need) if nd]
+        qt_canon = {q_: sym.Symbol(f"wq{m}", real=True) for m, q_ in enumerate(q_kept)}
+        qt_canon.update({t_: sym.Symbol(f"wt{j}", real=True) for j, t_ in enumerate(t_kept)})
+        var_map.update(qt_canon)
+        primitives = set(ph._y) | set(ph._u) | set(s_user) | set(q_user) | set(t_user)
 
         aux = dict(prob.auxiliary_data)
         aux.update(ph.auxiliary_data)        # phase data overrides problem data
@@ -269,9 +315,20 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
         p = [lower(e, f"path constraint {i}") for i, e in enumerate(ph.path_constraints)]
         g_all = [lower(e, f"integrand {i}") for i, e in enumerate(ph.integrand_functions)]
         g = [e for e, nd in zip(g_all, q_need) if nd]
-        n_y, n_u, n_q, n_p, n_s = len(f), len(u_used), len(g), len(p), len(s_canon)
         F = f + p + g
-        v = z_canon + s_canon
+        used = set().union(*[e.free_symbols for e in F]) if F else set()
+        w_syms, w_kind, w_idx = [], [], []
+        for m, q_ in enumerate(q_kept):
+            if qt_canon[q_] in used:
+                w_syms.append(qt_canon[q_]); w_kind.append(1); w_idx.append(m)
+        for j, t_ in enumerate(t_kept):
+            if qt_canon[t_] in used:
+                w_syms.append(qt_canon[t_]); w_kind.append(2); w_idx.append(j)
+        if w_syms:
+            w_kind += [0] * len(s_canon); w_idx += list(range(len(s_canon)))
+        w_syms += s_canon
+        n_y, n_u, n_q, n_p, n_s = len(f), len(u_used), len(g), len(p), len(w_syms)
+        v = z_canon + w_syms
 
         jac = []
         for r, e in enumerate(F):
@@ -318,7 +375,8 @@ def compile_model(prob: _pb.ProblemSpec) -> Model:
         pm = PhaseModel(index=ph.i, name=ph.name, n_y=n_y, n_u=n_u, n_q=n_q, n_p=n_p, n_s=n_s,
                         t_free=(bool(t_need[0]), bool(t_need[1])),
                         t_fixed=(0.5 * sum(t0_b), 0.5 * sum(tF_b)),
-                        z=z_canon, s=s_canon, f=f, p=p, g=g, jac=jac, mf=mf, mp=mp, mg=mg, hess=hess,
+                        z=z_canon, s=w_syms, f=f, p=p, g=g, jac=jac, mf=mf, mp=mp, mg=mg, hess=hess,
+                        w_kind=w_kind, w_idx=w_idx,
                         consts=list(pool.table), x_bounds=x_bounds, p_bounds=p_bounds,
                         y_t0_bounds=[b for b, nd in zip(y0_b, y_need) if nd],
                         y_tF_bounds=[b for b, nd in zip(yF_b, y_need) if nd])
@@ -427,6 +485,8 @@ def model_digest(model: Model) -> str:
 
     for pm in model.phases:
         put("phase", pm.n_y, pm.n_u, pm.n_q, pm.n_p, pm.n_s, pm.t_free, [(str(k), v) for k, v in pm.consts])
+        if pm.w_kind:
+            put("params", pm.w_kind, pm.w_idx)
         put([sym.srepr(e) for e in pm.f + pm.p + pm.g])
         put([(r, c, sym.srepr(e)) for r, c, e in pm.jac])
         put([(r, c, sym.srepr(e)) for r, c, e in pm.hess])

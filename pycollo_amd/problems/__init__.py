@@ -341,6 +341,63 @@ def two_phase_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
     return prob
 
 
+def time_coupled_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
+    """``two_phase_transfer`` with dynamics, path constraints and integrands that also depend on the phase's
+    integral variables and on its initial / final time *variables* -- the live reference keeps q, t0, tF as global
+    symbols inside f, p, g (pycollo/backend.py:1526-1539 substitutes y and u per node only).  Covers: q / t columns
+    of defect, path and integral rows, (q, z) Hessian strips, second partials merged into the stretch strips and
+    sums, a control that meets a time variable in a path row only, an integrand that depends on its own integral.
+    (Not from the reference.)"""
+    x, v, u, w, k = sym.symbols("x v u w k")
+    prob = ProblemSpec("time-coupled transfer")
+    prob.parameter_variables = [k]
+    prob.bounds.parameter_variables = [[0.5, 2.0]]
+    A = prob.new_phase("A")
+    A.state_variables = [x, v]
+    A.control_variables = [u, w]
+    A.integrand_functions = [0, 0]          # placeholders: the integral symbols must exist before they are used
+    qA = A.integral_variables
+    tFA = A.final_time_variable
+    A.state_equations = [v * (1 + sym.Rational(1, 10) * tFA), u - k * sym.sin(x) * v + sym.Rational(1, 20) * qA[0] * x]
+    A.path_constraints = [u**2 + k * x + w * tFA + sym.Rational(1, 10) * qA[0]**2]
+    A.integrand_functions = [u**2 + k * x**2 + sym.Rational(1, 5) * qA[0] * v + sym.Rational(1, 100) * tFA**2 * x,
+                             w**2 + qA[0] * tFA * sym.Rational(1, 50)]
+    A.bounds.initial_time = 0.0
+    A.bounds.final_time = [0.5, 2.0]
+    A.bounds.state_variables = [[-2, 2], [-3, 3]]
+    A.bounds.control_variables = [[-4, 4], [-1, 1]]
+    A.bounds.integral_variables = [[0, 50], [0, 10]]
+    A.bounds.path_constraints = [[-1, 40]]
+    A.bounds.initial_state_constraints = {x: 0, v: 0}
+    B = prob.new_phase("B")
+    B.state_variables = [x, v]
+    B.control_variables = [u]
+    B.integrand_functions = [0, 0]
+    qB = B.integral_variables
+    t0B, tFB = B.initial_time_variable, B.final_time_variable
+    B.state_equations = [v * sym.cos(x) + sym.Rational(1, 10) * (tFB - t0B) * qB[1],
+                         -k * x + u * sym.exp(-v**2) * t0B]
+    B.path_constraints = [x * qB[1] + t0B * k]
+    B.integrand_functions = [sym.sqrt(1 + u**2) + sym.Rational(1, 10) * qB[1] * qB[0] * x,
+                             x * v * k + t0B * tFB * u + sym.Rational(3, 10) * qB[0]]
+    B.bounds.initial_time = [0.5, 2.0]
+    B.bounds.final_time = [2.5, 4.0]
+    B.bounds.state_variables = [[-2, 2], [-3, 3]]
+    B.bounds.control_variables = [[-4, 4]]
+    B.bounds.integral_variables = [[0, 50], [-10, 10]]
+    B.bounds.path_constraints = [[-30, 30]]
+    B.bounds.final_state_constraints = {x: 1.0, v: 0.0}
+    prob.objective_function = (qA[0] + qB[0] * tFB + k * B.final_state_variables[1]**2 * A.initial_state_variables[0])
+    prob.endpoint_constraints = [A.final_state_variables[0] - B.initial_state_variables[0],
+                                 A.final_state_variables[1] - B.initial_state_variables[1],
+                                 tFA - t0B,
+                                 qB[1] * k - sym.sin(A.final_state_variables[0]) * tFB + qA[1]]
+    prob.bounds.endpoint_constraints = [0, 0, 0, [-1, 1]]
+    _mesh(A, K, order)
+    _mesh(B, K + 1, order + 1)
+    return prob
+
+
 def sliding_mass(num_phases: int = 2, K: int = 10, order: int = 4) -> ProblemSpec:
     """Unit mass slid from x = 0 to x = 1 in minimum time, at rest at both ends, split into ``num_phases`` phases
     of equal distance with velocity / time continuity as endpoint constraints -- the problem of the reference's
@@ -511,6 +568,7 @@ REGISTRY = {
     "delta_iii": delta_iii,
     "double_pendulum": double_pendulum,
     "two_phase_transfer": two_phase_transfer,
+    "time_coupled_transfer": time_coupled_transfer,
     "sliding_mass": sliding_mass,
     "free_flying_robot": free_flying_robot,
     "tumour_anti_angiogenesis": tumour_anti_angiogenesis,

@@ -63,7 +63,9 @@ class ShardPlan:
             N = pl.N
             jmask = pm.jac_mask()
             hmask = pm.hess_mask()
-            tz = [any(jmask[r, b] for r in range(pm.n_fn) if not (pm.n_y <= r < pm.n_y + pm.n_p)) for b in range(pm.n_v)]
+            tz = pm.t_strip_mask()
+            wk = pm.w_kind or [0] * pm.n_s
+            wi = pm.w_idx or list(range(pm.n_s))
             # Ranks get contiguous tile ranges balanced by the nodes they hold (a rank's share of c~, G~, H~ is
             # proportional to its nodes): on a ph-refined mesh tiles hold different numbers of nodes, and the exchange
             # is padded to the longest share.
@@ -107,10 +109,13 @@ class ShardPlan:
                         if tz[b]:
                             base = oH + h_slot(pl.t_off + jt, pl.x_off + b * N)
                             seg.append((base + n0, base + n1o))
-                for l in range(model.n_s):                      # s strips
+                for l in range(pm.n_s):                         # strips of the parameters (s, q; a time's is its t strip)
+                    if wk[l] == 2:
+                        continue
+                    prow = lay.s_off + wi[l] if wk[l] == 0 else pl.q_off + wi[l]
                     for b in range(pm.n_z):
                         if hmask[pm.n_z + l, b]:
-                            base = oH + h_slot(lay.s_off + l, pl.x_off + b * N)
+                            base = oH + h_slot(prow, pl.x_off + b * N)
                             seg.append((base + n0, base + n1o))
                 if nred:
                     seg.append((self.part_off[ip] + tb * nred, self.part_off[ip] + te * nred))

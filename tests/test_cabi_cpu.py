@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built):
 
 CASES = [("brachistochrone", {}), ("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=50, order=4)),
          ("shuttle", dict(K=30, order=5)), ("double_pendulum", {}), ("two_phase_transfer", {}),
-         ("delta_iii", dict(K=7, order=4))]
+         ("delta_iii", dict(K=7, order=4)), ("time_coupled_transfer", {}), ("time_coupled_transfer", dict(K=40, order=6))]
 
 
 @pytest.mark.parametrize("name,kw", CASES)

@@ -59,7 +59,8 @@ def _check_all(eng, ora, seed=1, xlo=-0.45, xhi=0.45):
 CASES = [("brachistochrone", {}), ("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=500, order=4)),
          ("shuttle", dict(K=60, order=5)), ("double_pendulum", {}), ("two_phase_transfer", {}),
          ("delta_iii", dict(K=9, order=4)), ("free_flying_robot", dict(K=33, order=5)), ("sliding_mass", dict(num_phases=3, K=7, order=4)),
-         ("tumour_anti_angiogenesis", dict(K=21, order=6)), ("space_station", dict(K=12, order=4))]
+         ("tumour_anti_angiogenesis", dict(K=21, order=6)), ("space_station", dict(K=12, order=4)),
+         ("time_coupled_transfer", {}), ("time_coupled_transfer", dict(K=300, order=5))]   # q / t0 / tF inside f, p, g
 
 
 @pytest.mark.parametrize("tpb", [64, 256])
@@ -77,7 +78,7 @@ def test_parity_with_oracle(built, tab, name, kw, tpb):
 
 
 @pytest.mark.parametrize("name,kw", [("shuttle", dict(K=60, order=5)), ("delta_iii", dict(K=9, order=4)),
-                                     ("two_phase_transfer", {})])
+                                     ("two_phase_transfer", {}), ("time_coupled_transfer", dict(K=12, order=4))])
 def test_waves_per_tile_replicas(built, tab, monkeypatch, name, kw):
     """64-node tiles shared by 1, 2 or 4 waves (pc::bulk, `wpt`): every split writes the same bits, and the
     automatic choice is one of them."""
@@ -335,6 +336,7 @@ def test_full_size_properties(built, tab, name, kw):
 
 
 @pytest.mark.parametrize("name,kw,world", [("two_phase_transfer", dict(K=40, order=4), 3),
+                                           ("time_coupled_transfer", dict(K=40, order=4), 3),
                                            ("hypersensitive", dict(K=2000, order=6), 8),
                                            ("delta_iii", dict(K=40, order=4), 2),
                                            ("shuttle", dict(K=20000, order=4), 8),              # config 4 as BASELINE shards it
@@ -452,7 +454,7 @@ def test_sharded_world1_nccl(built):
 
 RES_CASES = [("hypersensitive", dict(K=2000, order=6), 0), ("hypersensitive", dict(K=700, order=6), 256),
              ("double_pendulum", {}, 0), ("delta_iii", dict(K=40, order=4), 0), ("delta_iii", dict(K=9, order=4), 128),
-             ("two_phase_transfer", {}, 0), ("space_station", dict(K=12, order=4), 0), ("shuttle", dict(K=60, order=5), 0),
+             ("two_phase_transfer", {}, 0), ("time_coupled_transfer", dict(K=30, order=4), 0), ("space_station", dict(K=12, order=4), 0), ("shuttle", dict(K=60, order=5), 0),
              ("tumour_anti_angiogenesis", dict(K=21, order=6), 64), ("sliding_mass", dict(num_phases=3, K=7, order=4), 0)]
 
 

@@ -25,6 +25,7 @@ def _ragged(prob, seed=3, K=23):
                                             ("cart_pole", dict(K=300, order=4), False),
                                             ("shuttle", dict(K=12, order=6), False),
                                             ("two_phase_transfer", dict(K=6, order=4), False),
+                                            ("time_coupled_transfer", dict(K=6, order=4), False),
                                             ("cart_pole", dict(K=10, order=4), True),
                                             ("double_pendulum", dict(K=10, order=4), True)])
 def test_mesh_error_matches_oracle(built, name, kw, ragged):

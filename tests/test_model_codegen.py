@@ -81,7 +81,7 @@ def test_generated_source_is_straight_line_fp64():
 
 
 @pytest.mark.parametrize("name,kw,orders", [("hypersensitive", dict(K=10, order=6), (6,)), ("cart_pole", dict(K=10, order=4), (4,)),
-                                            ("two_phase_transfer", {}, (0, 0)), ("double_pendulum", {}, (4,)),
+                                            ("two_phase_transfer", {}, (0, 0)), ("time_coupled_transfer", {}, (3, 4)), ("double_pendulum", {}, (4,)),
                                             ("delta_iii", dict(K=10, order=5), (5, 5, 5, 5))])
 def test_kernels_use_no_scratch_memory(name, kw, orders):
     """A run-time subscript into a register array sends the array -- and with it the dispatch -- to scratch memory

@@ -64,7 +64,8 @@ def test_scaling_vectors_known_answers(tag, prob, golden_tab, known_answers):
 
 
 SYMBOLIC_CASES = [("brachistochrone", dict(K=2, order=3)), ("hypersensitive", dict(K=3, order=3)),
-                  ("cart_pole", dict(K=2, order=3)), ("two_phase_transfer", dict(K=2, order=3))]
+                  ("cart_pole", dict(K=2, order=3)), ("two_phase_transfer", dict(K=2, order=3)),
+                  ("time_coupled_transfer", dict(K=2, order=3))]
 
 
 @pytest.mark.parametrize("name,kw", SYMBOLIC_CASES)

@@ -9,6 +9,7 @@ import pytest
 from pycollo_amd import problems
 
 CASES = [("hypersensitive", dict(K=200, order=6)), ("two_phase_transfer", dict(K=40, order=4)),
+         ("time_coupled_transfer", dict(K=40, order=4)),
          ("delta_iii", dict(K=30, order=4)), ("double_pendulum", dict(K=50, order=4))]
 
 
@@ -28,7 +29,7 @@ def _expected_bulk_positions(eng):
         zcol = (hc >= pl.x_off) & (hc < pl.q_off)
         same_node = ((hr - pl.x_off) % N) == ((hc - pl.x_off) % N)
         h_mask |= zrow & zcol & same_node                                    # node bands
-        trow = (hr >= pl.t_off) & (hr < pl.t_off + pm.n_t)
+        trow = (hr >= pl.q_off) & (hr < pl.t_off + pm.n_t)                  # q and t rows of the phase
         srow = hr >= lay.s_off
         h_mask |= (trow | srow) & zcol                                       # strips (may include endpoint overlaps)
     return np.concatenate(c_pos), np.nonzero(g_mask)[0] + eng.num_c, np.nonzero(h_mask)[0] + eng.num_c + eng.nnz_jac
