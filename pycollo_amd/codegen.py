@@ -49,6 +49,13 @@ class _Printer(C99CodePrinter):
             return f"({b}*sqrt({self._print(base)}))"
         if exp == sym.Rational(-3, 2):
             return f"(1.0/({b}*sqrt({self._print(base)})))"
+        if exp.is_Rational and exp.q == 2 and abs(exp.p) <= 15:
+            # other half-integer powers (r^-5/2, r^7/2 of gravity gradients): integer power times one square root --
+            # libm's pow() is a log and an exp, some two hundred fp64 instructions per call
+            k = (abs(int(exp.p)) - 1) // 2
+            ip = "*".join([b] * k) if k <= 4 else f"pc_powi<{k}>({self._print(base)})"
+            body = f"(({ip})*sqrt({self._print(base)}))"
+            return body if exp.p > 0 else f"(1.0/{body})"
         return f"pow({self._print(base)}, {self._print(exp)})"
 
     def parenthesize(self, item, level, strict=False):
@@ -335,10 +342,20 @@ def generate_source(model: Model, orders=None) -> str:
             out = []
             blk = "(int)blockIdx.x - tail_blocks" if res else "(int)blockIdx.x"
             out.append(f"  const int b = pc::xcd_major({blk}, fb{np_});")
+            rs = 'true' if res else 'false'
             for i, pm in enumerate(model.phases):
                 cond = f"if (b < fb{i + 1}) " if i + 1 < np_ else ""
-                out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {'true' if res else 'false'}>"
-                           f"(ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch); return; }}")
+                args = f"(ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch)"
+                out.append("#ifdef PC_STATIC_W   // one instantiation per replica (host must run PYCOLLO_AMD_WPT=PC_STATIC_W)")
+                out.append(f"  {cond}{{ switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {{")
+                for wv in range(4):
+                    out.append(f"#if PC_STATIC_W > {wv}")
+                    out.append(f"    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}, PC_STATIC_W, {wv}>{args}; return;")
+                    out.append("#endif")
+                out.append("    default: return; } }")
+                out.append("#else")
+                out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}>{args}; return; }}")
+                out.append("#endif")
             return out
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         # The members of PcMultiArgs travel as separate scalar parameters (same order, same offsets: the host still

@@ -98,6 +98,15 @@ __global__ void kkt_matvec(const int64_t* __restrict__ ptr, const int32_t* __res
 // M = [A | C], row stride ld = m + w, A's lower triangle valid.  On return: strict lower triangle of A = L, its
 // diagonal = D, the C part = X = A^-1 C; S (w x w, may be null) = -C^T A^-1 C; cnt = (positive, negative) pivots.
 // One workgroup; lds holds 2 m + w doubles.
+// WAVE: the workgroup is one wave and M, S, lds are all in LDS -- a step then only needs the wave's own LDS traffic to
+// have landed (s_waitcnt lgkmcnt(0)); __syncthreads() would also wait for every global store still in flight.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <bool WAVE>
+__device__ __forceinline__ void blk_sync() {
+  if constexpr (WAVE) wave_lds_sync();
+  else __syncthreads();
+}
+template <bool WAVE = false>
 __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, double* lds) {
   const int tid = threadIdx.x, nt = blockDim.x, ld = m + w;
   double* colL = lds;
@@ -105,7 +114,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
   double* rowC = lds + 2 * m;
   int npos = 0, nneg = 0;
   for (int j = 0; j < m; ++j) {
-    __syncthreads();
+    blk_sync<WAVE>();
     const double d = M[(size_t)j * ld + j];
     npos += d > 0.0;
     nneg += d < 0.0;
@@ -115,7 +124,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
       lcol[i] = c / d;
     }
     for (int c = tid; c < w; c += nt) rowC[c] = M[(size_t)j * ld + m + c];
-    __syncthreads();
+    blk_sync<WAVE>();
     const int rows = m - j - 1, width = rows + w;
     for (int e = tid; e < rows * width; e += nt) {
       const int i = j + 1 + e / width, k = e % width;
@@ -128,7 +137,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
     }
     for (int i = j + 1 + tid; i < m; i += nt) M[(size_t)i * ld + j] = lcol[i];
   }
-  __syncthreads();
+  blk_sync<WAVE>();
   if (S)   // Z = L^-1 C now sits in the C part
     for (int e = tid; e < w * w; e += nt) {
       const int a = e / w, b = e % w;
@@ -136,7 +145,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
       for (int j = 0; j < m; ++j) acc += M[(size_t)j * ld + m + a] * (M[(size_t)j * ld + m + b] / M[(size_t)j * ld + j]);
       S[e] = -acc;
     }
-  __syncthreads();
+  blk_sync<WAVE>();
   for (int c = tid; c < w; c += nt) {   // X = L^-T D^-1 Z, one column per thread
     for (int j = 0; j < m; ++j) M[(size_t)j * ld + m + c] /= M[(size_t)j * ld + j];
     for (int j = m - 1; j >= 0; --j) {
@@ -145,7 +154,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
       M[(size_t)j * ld + m + c] = acc;
     }
   }
-  __syncthreads();
+  blk_sync<WAVE>();
   if (tid == 0 && cnt) {
     cnt[0] = npos;
     cnt[1] = nneg;
@@ -153,21 +162,22 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
 }
 
 // t = A^-1 r for a factored block (r in lds, length m; result left there); one workgroup
+template <bool WAVE = false>
 __device__ void block_solve(const double* M, int m, int ld, double* r) {
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int j = 0; j < m; ++j) {
-    __syncthreads();
+    blk_sync<WAVE>();
     const double rj = r[j];
     for (int i = j + 1 + tid; i < m; i += nt) r[i] -= M[(size_t)i * ld + j] * rj;
   }
-  __syncthreads();
+  blk_sync<WAVE>();
   for (int i = tid; i < m; i += nt) r[i] /= M[(size_t)i * ld + i];
   for (int j = m - 1; j > 0; --j) {   // L^T x = r, column-oriented: x_j is final, rows above it lose L[j][i] x_j
-    __syncthreads();
+    blk_sync<WAVE>();
     const double rj = r[j];
     for (int i = tid; i < j; i += nt) r[i] -= M[(size_t)j * ld + i] * rj;
   }
-  __syncthreads();
+  blk_sync<WAVE>();
 }
 
 struct KArgs {
@@ -185,6 +195,12 @@ struct KArgs {
   double* leafG;                 // per leaf: X_C^T r_l, w doubles at leafG_off
   double* chainG;                // per chain node: Y^T r_c, wc doubles at chainG_off
   const int64_t *leafG_off, *chainG_off;
+  // cyclic reduction of the chain (kkt_cr_*): per chain node its separators at the level it is eliminated at
+  // (global chain ids, -1 = none), its panel / Schur block / X^T r in the cr buffer
+  int32_t cr;                    // 1: the chain was eliminated by cyclic reduction (border kernels read its layout)
+  double* crbuf;
+  const int64_t *cr_a, *cr_b, *crP_off, *crS_off, *crG_off;
+  const int64_t* cr_nodes;       // nodes by level, concatenated
 };
 
 __device__ __forceinline__ int nzb_of(const KArgs& a, int64_t c) { return (int)(a.chain_ptr[c + 1] - a.chain_ptr[c]); }
@@ -273,26 +289,493 @@ __global__ void kkt_chain_factor(KArgs a) {
   }
 }
 
+// ---- the chain as one wave -----------------------------------------------------------------------------------------
+// The walk along a phase's chain is the sequential part of the factorisation and of both triangular solves: hundreds
+// to thousands of steps on blocks of a few unknowns.  In the kernels above a step is a string of dependent global
+// round trips (table entries -> block offsets -> block values; every __syncthreads() also drains the stores of the
+// step before): 4.4 us per step in the factorisation and 2.2 us in the forward solve of a 3-unknown node.  Here one
+// wave walks the chain with (i) the per-node table entries fetched 64 nodes at a time, one node per lane, and handed
+// out by v_readlane, (ii) everything a step reads from global memory requested one step ahead and parked in
+// registers, (iii) the working panel, the carried Schur block and the right-hand side in LDS, ordered by
+// s_waitcnt lgkmcnt(0) alone, (iv) stores left to drain on their own.  Used when a node panel fits 64 x CH_PER
+// elements and the chain blocks fit LDS (pc_kkt_create decides); the kernels above remain the general path.
+#define CH_PER 8
+struct ChainMeta {   // per chain node, held by the lane that fetched it
+  int nz, nx, last;
+  long long D, S, SR, G, LG;   // chainD_off, chainS_off, leafS_off / leafG_off of the leaf on the right (-1), chainG_off
+};
+__device__ __forceinline__ int rl32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ long long rl64(long long v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ ChainMeta chain_meta_fetch(const KArgs& a, int64_t c, int64_t c1) {
+  ChainMeta m{0, 0, 1, 0, 0, -1, 0, -1};
+  if (c < c1) {
+    const int64_t p0 = a.chain_ptr[c], p1 = a.chain_ptr[c + 1];
+    m.last = a.chain_last[c];
+    m.nz = (int)(p1 - p0);
+    m.nx = m.last ? 0 : (int)(a.chain_ptr[c + 2] - p1);
+    m.D = a.chainD_off[c];
+    m.S = a.chainS_off[c];
+    m.G = a.chainG_off[c];
+    if (!m.last) {
+      const int64_t l = a.leaf_of_left[c];
+      m.SR = a.leafS_off[l];
+      m.LG = a.leafG_off[l];
+    }
+  }
+  return m;
+}
+__device__ __forceinline__ ChainMeta chain_meta_bcast(const ChainMeta& m, int lane) {
+  ChainMeta o;
+  o.nz = rl32(m.nz, lane); o.nx = rl32(m.nx, lane); o.last = rl32(m.last, lane);
+  o.D = rl64(m.D, lane); o.S = rl64(m.S, lane); o.SR = rl64(m.SR, lane); o.G = rl64(m.G, lane); o.LG = rl64(m.LG, lane);
+  return o;
+}
+
+__global__ void __launch_bounds__(64) kkt_chain_factor_w(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  double* carry = lds + (2 * a.nzmax + a.wcmax);
+  double* M = carry + a.wcmax * a.wcmax;
+  double* S = M + a.nzmax * (a.nzmax + a.wcmax);
+  double pre[CH_PER];
+  // what node `m` (left neighbour `ml`, has_left) reads from global memory: its own entries (the diagonal block was
+  // assembled as a lower triangle), the Schur block of the leaf on its left (R and border rows), the one on its right
+  auto prefetch = [&](const ChainMeta& m, const ChainMeta& ml, bool has_left) {
+    const int nz = m.nz, nx = m.nx, ld = nz + nx + nb;
+    const double* Mg = a.vals + m.D;
+    const double* SR = a.vals + (m.last ? 0 : m.SR);
+    const int nl = ml.nz, ws = nl + nz + nb;
+    const double* SL = a.vals + (has_left ? ml.SR : 0);
+#pragma unroll
+    for (int q = 0; q < CH_PER; ++q) {
+      const int e = tid + 64 * q;
+      double v = 0.0;
+      if (e < nz * ld) {
+        const int i = e / ld, k = e - i * ld;
+        v = (k < nz && k > i) ? Mg[(size_t)k * ld + i] : Mg[e];
+        if (has_left && (k < nz || k >= nz + nx)) v += SL[(size_t)(nl + i) * ws + nl + (k < nz ? k : k - nx)];
+        if (!m.last) v += SR[e];
+      }
+      pre[q] = v;
+    }
+  };
+  ChainMeta lane_meta, cur{}, left{}, nxt{};
+  for (int64_t cb = c0; cb < c1; cb += 64) {
+    lane_meta = chain_meta_fetch(a, cb + tid, c1);
+    const int steps = (int)((c1 - cb) < 64 ? (c1 - cb) : 64);
+    if (cb == c0) {
+      cur = chain_meta_bcast(lane_meta, 0);
+      prefetch(cur, left, false);
+    }
+    for (int s = 0; s < steps; ++s) {
+      const int64_t c = cb + s;
+      const bool has_left = c > c0;
+      const int nz = cur.nz, nx = cur.nx, wc = nx + nb, ld = nz + wc, wr = nz + nb;
+      // the panel goes to LDS together with the Schur block carried over from the previous node
+#pragma unroll
+      for (int q = 0; q < CH_PER; ++q) {
+        const int e = tid + 64 * q;
+        if (e < nz * ld) {
+          const int i = e / ld, k = e - i * ld;
+          double v = pre[q];
+          if (has_left && (k < nz || k >= nz + nx)) v += carry[(size_t)i * wr + (k < nz ? k : k - nx)];
+          M[e] = v;
+        }
+      }
+      // the next node's values are requested now and arrive while this one is eliminated
+      const bool more = c + 1 < c1;
+      if (more) {
+        if (s + 1 < steps) nxt = chain_meta_bcast(lane_meta, s + 1);
+        else { const ChainMeta t = chain_meta_fetch(a, c + 1, c1); nxt = chain_meta_bcast(t, 0); }   // batch boundary
+        prefetch(nxt, cur, true);
+      }
+      wave_lds_sync();
+      block_eliminate<true>(M, nz, wc, S, a.counts + 2 * (a.n_leaf + c), lds);
+      double* Mg = a.vals + cur.D;
+      double* Sg = a.vals + cur.S;
+      for (int e = tid; e < nz * ld; e += 64) Mg[e] = M[e];
+      for (int e = tid; e < wc * wc; e += 64) {
+        const double v = S[e];
+        Sg[e] = v;
+        carry[e] = v;
+      }
+      wave_lds_sync();
+      left = cur;
+      cur = nxt;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) kkt_chain_forward_w(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  double* rr = lds;                                  // [nzmax] right-hand side of the node, then its solution
+  double* gp = rr + a.nzmax;                         // [wcmax] Y^T r of the previous node
+  double* M = gp + a.wcmax;                          // [nzmax][nzmax + wcmax] the node's factored panel
+  double pre[CH_PER], rv = 0.0;
+  auto prefetch = [&](const ChainMeta& m, const ChainMeta& ml, bool has_left, int64_t c) {
+    const int nz = m.nz, ld = nz + m.nx + nb;
+    const double* Mg = a.vals + m.D;
+#pragma unroll
+    for (int q = 0; q < CH_PER; ++q) {
+      const int e = tid + 64 * q;
+      pre[q] = e < nz * ld ? Mg[e] : 0.0;
+    }
+    rv = 0.0;
+    if (tid < nz) {
+      rv = a.r[a.base_chain + a.chain_ptr[c] + tid];
+      if (has_left) rv -= a.leafG[ml.LG + ml.nz + tid];   // left leaf, R part
+      if (!m.last) rv -= a.leafG[m.LG + tid];               // right leaf, L part
+    }
+  };
+  ChainMeta lane_meta, cur{}, left{}, nxt{};
+  for (int64_t cb = c0; cb < c1; cb += 64) {
+    lane_meta = chain_meta_fetch(a, cb + tid, c1);
+    const int steps = (int)((c1 - cb) < 64 ? (c1 - cb) : 64);
+    if (cb == c0) {
+      cur = chain_meta_bcast(lane_meta, 0);
+      prefetch(cur, left, false, c0);
+    }
+    for (int s = 0; s < steps; ++s) {
+      const int64_t c = cb + s;
+      const int nz = cur.nz, nx = cur.nx, wc = nx + nb, ld = nz + wc;
+#pragma unroll
+      for (int q = 0; q < CH_PER; ++q) {
+        const int e = tid + 64 * q;
+        if (e < nz * ld) M[e] = pre[q];
+      }
+      if (tid < nz) rr[tid] = rv - (c > c0 ? gp[tid] : 0.0);   // previous node, next-node part
+      const int64_t pc = a.base_chain + a.chain_ptr[c];
+      if (c + 1 < c1) {
+        if (s + 1 < steps) nxt = chain_meta_bcast(lane_meta, s + 1);
+        else { const ChainMeta t = chain_meta_fetch(a, c + 1, c1); nxt = chain_meta_bcast(t, 0); }
+        prefetch(nxt, cur, true, c + 1);
+      }
+      wave_lds_sync();
+      double gk = 0.0;
+      if (tid < wc)
+        for (int i = 0; i < nz; ++i) gk += M[(size_t)i * ld + nz + tid] * rr[i];
+      wave_lds_sync();          // (gp is read above, by every lane, before it is overwritten)
+      if (tid < wc) {
+        a.chainG[cur.G + tid] = gk;
+        gp[tid] = gk;
+      }
+      block_solve<true>(M, nz, ld, rr);
+      if (tid < nz) a.r[pc + tid] = rr[tid];
+      wave_lds_sync();
+      left = cur;
+      cur = nxt;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) kkt_chain_backward_w(KArgs a) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nb = a.nb;
+  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
+  double* xn = lds;                                  // [nzmax] the next node's solution
+  double* xb = xn + a.nzmax;                         // [nb] the border's
+  double* M = xb + nb;                               // [nzmax][wcmax] coupling part of the node's panel
+  for (int i = tid; i < nb; i += 64) xb[i] = a.r[a.base_border + i];
+  double pre[CH_PER], xv = 0.0;
+  auto prefetch = [&](const ChainMeta& m, int64_t c) {
+    const int nz = m.nz, wc = m.nx + nb, ld = nz + wc;
+    const double* Mg = a.vals + m.D;
+#pragma unroll
+    for (int q = 0; q < CH_PER; ++q) {
+      const int e = tid + 64 * q;
+      double v = 0.0;
+      if (e < nz * wc) {
+        const int i = e / wc, k = e - i * wc;
+        v = Mg[(size_t)i * ld + nz + k];
+      }
+      pre[q] = v;
+    }
+    xv = tid < nz ? a.r[a.base_chain + a.chain_ptr[c] + tid] : 0.0;
+  };
+  // walking down the chain: batches of 64 nodes ending at c, fetched by lanes in descending order
+  ChainMeta lane_meta, cur{}, nxt{};
+  for (int64_t ce = c1; ce > c0; ce -= 64) {
+    const int64_t cbeg = ce - 64 > c0 ? ce - 64 : c0;
+    const int steps = (int)(ce - cbeg);
+    lane_meta = chain_meta_fetch(a, cbeg + tid, ce);          // lane j: node cbeg + j
+    if (ce == c1) {
+      cur = chain_meta_bcast(lane_meta, steps - 1);
+      prefetch(cur, c1 - 1);
+    }
+    for (int s = steps - 1; s >= 0; --s) {
+      const int64_t c = cbeg + s;
+      const int nz = cur.nz, nx = cur.nx, wc = nx + nb;
+#pragma unroll
+      for (int q = 0; q < CH_PER; ++q) {
+        const int e = tid + 64 * q;
+        if (e < nz * wc) M[e] = pre[q];
+      }
+      const double x0 = xv;
+      const int64_t pc = a.base_chain + a.chain_ptr[c];
+      if (c > c0) {
+        if (s > 0) nxt = chain_meta_bcast(lane_meta, s - 1);
+        else { const ChainMeta t = chain_meta_fetch(a, c - 1, c1); nxt = chain_meta_bcast(t, 0); }
+        prefetch(nxt, c - 1);
+      }
+      wave_lds_sync();
+      double v = x0;
+      if (tid < nz) {
+        for (int k = 0; k < nx; ++k) v -= M[(size_t)tid * wc + k] * xn[k];
+        for (int k = 0; k < nb; ++k) v -= M[(size_t)tid * wc + nx + k] * xb[k];
+      }
+      wave_lds_sync();          // every lane has read xn before it is replaced
+      if (tid < nz) {
+        a.r[pc + tid] = v;
+        xn[tid] = v;
+      }
+      wave_lds_sync();
+      cur = nxt;
+    }
+  }
+}
+
+// ---- the chain by cyclic reduction -------------------------------------------------------------------------------------
+// The chain of a phase is block-tridiagonal with a border.  Walking it node by node is hundreds to thousands of
+// dependent steps of a few microseconds each (4 us per 3-unknown node even with everything in LDS and registers: the
+// step is a string of LDS round trips and fp64 divisions in one wave) -- most of the factorisation and of both solves.
+// Odd-even elimination has depth log2(n): at level l the nodes at positions (2k+1) 2^(l-1) are eliminated, all at once,
+// each against its two neighbours at distance 2^(l-1); what survives is again block-tridiagonal.  Position 0 outlives
+// every level and is eliminated last, against the border alone.  A node is a small "leaf": panel
+// [D | K(c,a) | K(c,b) | F] -> L D L^T, X = D^-1 [K F], S = -[K F]^T D^-1 [K F] over [a | b | border].  Nothing is
+// accumulated in place: a node *pulls* what earlier levels owe it -- the leaves' Schur blocks, and for every level
+// below its own the Schur blocks of the two nodes eliminated next to it -- in a fixed order, so the factorisation is
+// bit-reproducible and needs one launch per level and no atomics.
+struct CrNode {
+  int nz, na, nb_, w;          // own unknowns, separators' (0 if none), border; w = na + nbr + nb
+  int nbr;
+  int64_t a, b;
+};
+__device__ __forceinline__ CrNode cr_node(const KArgs& k, int64_t c) {
+  CrNode n;
+  n.nz = nzb_of(k, c);
+  n.a = k.cr_a[c];
+  n.b = k.cr_b[c];
+  n.na = n.a >= 0 ? nzb_of(k, n.a) : 0;
+  n.nbr = n.b >= 0 ? nzb_of(k, n.b) : 0;
+  n.nb_ = k.nb;
+  n.w = n.na + n.nbr + k.nb;
+  return n;
+}
+// position of c in its phase, the phase's length, and the level c is eliminated at (position 0: one past the last)
+__device__ __forceinline__ void cr_where(const KArgs& k, int64_t c, int ph, int64_t& p, int64_t& n, int& level) {
+  const int64_t c0 = k.chain_phase_ptr[ph], c1 = k.chain_phase_ptr[ph + 1];
+  p = c - c0;
+  n = c1 - c0;
+  if (p > 0) level = __builtin_ctzll((unsigned long long)p) + 1;
+  else {
+    level = 1;
+    while (((int64_t)1 << (level - 1)) <= n - 1) ++level;   // 1 + number of levels
+  }
+}
+
+// launch: one workgroup (one wave) per node of the level; `first` = offset of the level in cr_nodes; ph_of via search
+__global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first, int n_phase) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nb = k.nb;
+  const int64_t c = k.cr_nodes[first + blockIdx.x];
+  int ph = 0;
+  while (ph + 1 < n_phase && k.chain_phase_ptr[ph + 1] <= c) ++ph;
+  int64_t p, n;
+  int level;
+  cr_where(k, c, ph, p, n, level);
+  const CrNode me = cr_node(k, c);
+  const int nz = me.nz, na = me.na, nr = me.nbr, w = me.w, ld = nz + w;
+  double* M = lds + (2 * nz + w);                 // [nz][ld] panel; block_eliminate's scratch in front
+  double* S = M + (size_t)nz * ld;                // [w][w]
+  const bool first_in_phase = p == 0, last_in_phase = p == n - 1;
+  // ---- level-0 values: own entries (assembled as a lower triangle + couplings) and the two leaves' Schur blocks
+  const int nx0 = last_in_phase ? 0 : nzb_of(k, c + 1), ld0 = nz + nx0 + nb;
+  const double* Mg = k.vals + k.chainD_off[c];
+  const int nl = first_in_phase ? 0 : nzb_of(k, c - 1), wsl = nl + nz + nb;
+  const double* SL = first_in_phase ? nullptr : k.vals + k.leafS_off[k.leaf_of_left[c - 1]];
+  const double* SR = last_in_phase ? nullptr : k.vals + k.leafS_off[k.leaf_of_left[c]];
+  for (int e = tid; e < nz * ld; e += 64) {
+    const int i = e / ld, col = e - i * ld;
+    double v = 0.0;
+    if (col < nz) {                               // D
+      const int kk = col;
+      v = kk > i ? Mg[(size_t)kk * ld0 + i] : Mg[(size_t)i * ld0 + kk];
+      if (SL) v += SL[(size_t)(nl + i) * wsl + nl + kk];
+      if (SR) v += SR[(size_t)i * ld0 + kk];
+    } else if (col >= nz + na + nr) {             // F
+      const int kk = col - nz - na - nr;
+      v = Mg[(size_t)i * ld0 + nz + nx0 + kk];
+      if (SL) v += SL[(size_t)(nl + i) * wsl + nl + nz + kk];
+      if (SR) v += SR[(size_t)i * ld0 + nz + nx0 + kk];
+    } else if (level == 1) {                      // couplings to the original neighbours
+      if (col < nz + na) {                        // K(c, a), a = c - 1: transposed E of a, and the left leaf's R-L block
+        const int kk = col - nz;
+        const int lda = na + nz + nb;             // a's own panel: [na | nz | nb]
+        v = k.vals[k.chainD_off[me.a] + (size_t)kk * lda + na + i] + SL[(size_t)(nl + i) * wsl + kk];
+      } else {                                    // K(c, b), b = c + 1
+        const int kk = col - nz - na;
+        v = Mg[(size_t)i * ld0 + nz + kk] + SR[(size_t)i * ld0 + nz + kk];
+      }
+    }
+    // ---- what the levels below owe this node: D and F from both eliminated neighbours of every level
+    if (col < nz || col >= nz + na + nr) {
+      const bool isF = col >= nz;
+      const int kk = isF ? col - nz - na - nr : col;
+      for (int l = 1; l < level; ++l) {
+        const int64_t h = (int64_t)1 << (l - 1);
+        if (p >= h) {                             // c is the right separator of e = c - h
+          const int64_t e2 = c - h;
+          const int ea = nzb_of(k, k.cr_a[e2]), ew = ea + nz + nb;
+          v += k.crbuf[k.crS_off[e2] + (size_t)(ea + i) * ew + (isF ? ea + nz + kk : ea + kk)];
+        }
+        if (p + h <= n - 1) {                     // c is the left separator of e = c + h
+          const int64_t e2 = c + h;
+          const int64_t eb = k.cr_b[e2];
+          const int ebn = eb >= 0 ? nzb_of(k, eb) : 0, ew = nz + ebn + nb;
+          v += k.crbuf[k.crS_off[e2] + (size_t)i * ew + (isF ? nz + ebn + kk : kk)];
+        }
+      }
+    } else if (level > 1) {                       // couplings created by the node eliminated in between, one level down
+      const int64_t h2 = (int64_t)1 << (level - 2);
+      if (col < nz + na) {                        // e = c - h/2: [a | c | B], K(c, a) = S.ba
+        const int kk = col - nz;
+        const int64_t e2 = c - h2;
+        const int ew = na + nz + nb;
+        v = k.crbuf[k.crS_off[e2] + (size_t)(na + i) * ew + kk];
+      } else {                                    // e = c + h/2: [c | b | B], K(c, b) = S.ab
+        const int kk = col - nz - na;
+        const int64_t e2 = c + h2;
+        const int ew = nz + nr + nb;
+        v = k.crbuf[k.crS_off[e2] + (size_t)i * ew + nz + kk];
+      }
+    }
+    M[e] = v;
+  }
+  wave_lds_sync();
+  block_eliminate<true>(M, nz, w, S, k.counts + 2 * (k.n_leaf + c), lds);
+  double* Pg = k.crbuf + k.crP_off[c];
+  double* Sg = k.crbuf + k.crS_off[c];
+  for (int e = tid; e < nz * ld; e += 64) Pg[e] = M[e];
+  for (int e = tid; e < w * w; e += 64) Sg[e] = S[e];
+}
+
+__global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first, int n_phase) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x, nb = k.nb;
+  const int64_t c = k.cr_nodes[first + blockIdx.x];
+  int ph = 0;
+  while (ph + 1 < n_phase && k.chain_phase_ptr[ph + 1] <= c) ++ph;
+  int64_t p, n;
+  int level;
+  cr_where(k, c, ph, p, n, level);
+  const CrNode me = cr_node(k, c);
+  const int nz = me.nz, w = me.w, ld = nz + w;
+  double* rr = lds;
+  double* M = lds + nz;
+  const double* Pg = k.crbuf + k.crP_off[c];
+  for (int e = tid; e < nz * ld; e += 64) M[e] = Pg[e];
+  if (tid < nz) {
+    double v = k.r[k.base_chain + k.chain_ptr[c] + tid];
+    if (p > 0) v -= k.leafG[k.leafG_off[k.leaf_of_left[c - 1]] + nzb_of(k, c - 1) + tid];   // left leaf, R part
+    if (p < n - 1) v -= k.leafG[k.leafG_off[k.leaf_of_left[c]] + tid];                      // right leaf, L part
+    for (int l = 1; l < level; ++l) {
+      const int64_t h = (int64_t)1 << (l - 1);
+      if (p >= h) v -= k.crbuf[k.crG_off[c - h] + nzb_of(k, k.cr_a[c - h]) + tid];         // as the right separator
+      if (p + h <= n - 1) v -= k.crbuf[k.crG_off[c + h] + tid];                              // as the left separator
+    }
+    rr[tid] = v;
+  }
+  wave_lds_sync();
+  if (tid < w) {
+    double g = 0.0;
+    for (int i = 0; i < nz; ++i) g += M[(size_t)i * ld + nz + tid] * rr[i];
+    k.crbuf[k.crG_off[c] + tid] = g;
+  }
+  block_solve<true>(M, nz, ld, rr);
+  if (tid < nz) k.r[k.base_chain + k.chain_ptr[c] + tid] = rr[tid];
+}
+
+__global__ void __launch_bounds__(64) kkt_cr_backward(KArgs k, int64_t first) {
+  const int tid = threadIdx.x, nb = k.nb;
+  const int64_t c = k.cr_nodes[first + blockIdx.x];
+  const CrNode me = cr_node(k, c);
+  const int nz = me.nz, na = me.na, nr = me.nbr, ld = nz + me.w;
+  const double* Pg = k.crbuf + k.crP_off[c];
+  if (tid < nz) {
+    double v = k.r[k.base_chain + k.chain_ptr[c] + tid];
+    const double* row = Pg + (size_t)tid * ld + nz;
+    if (me.a >= 0) { const double* xa = k.r + k.base_chain + k.chain_ptr[me.a]; for (int q = 0; q < na; ++q) v -= row[q] * xa[q]; }
+    if (me.b >= 0) { const double* xb = k.r + k.base_chain + k.chain_ptr[me.b]; for (int q = 0; q < nr; ++q) v -= row[na + q] * xb[q]; }
+    const double* xB = k.r + k.base_border;
+    for (int q = 0; q < nb; ++q) v -= row[na + nr + q] * xB[q];
+    k.r[k.base_chain + k.chain_ptr[c] + tid] = v;
+  }
+}
+
 // border = its own entries + the border corner of every Schur block, then its factorisation (one workgroup)
+// Every leaf and every chain node owes the border a term: 2 x (number of sections / group) of them.  A thread per border
+// entry walking all of them is a thousand dependent-address loads in a row (0.27 ms at 10 k nodes); the walk is cut
+// into `ns` interleaved slices per entry, one thread each, whose partial sums are added in slice order -- fixed order,
+// same bits every run.  term(j, i, k) = contribution of leaf j (j < n_leaf) or chain node j - n_leaf.
+template <class Term>
+__device__ __forceinline__ void border_accumulate(const KArgs& a, int n_entries, double* part, Term term) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ns = n_entries >= nt ? 1 : nt / (n_entries > 0 ? n_entries : 1);
+  const int64_t n_terms = (int64_t)a.n_leaf + a.n_chain;
+  for (int base = 0; base < n_entries; base += nt / ns) {   // entries in rounds of nt / ns
+    const int e = base + tid / ns, sl = tid % ns;
+    double acc = 0.0;
+    if (e < n_entries)
+      for (int64_t j = sl; j < n_terms; j += ns) acc += term(j, e);
+    part[tid] = acc;
+    __syncthreads();
+    if (sl == 0 && e < n_entries) {
+      double tot = 0.0;
+      for (int q = 0; q < ns; ++q) tot += part[tid + q];
+      part[tid] = tot;
+    }
+    __syncthreads();
+    // the caller's consume step reads part[(e - base) * ns] -- done through the callback below
+    if (sl == 0 && e < n_entries) term(-1 - (int64_t)e, tid);   // hand the total over: term(-1 - e, index into part)
+    __syncthreads();
+  }
+}
+
 __global__ void kkt_border_factor(KArgs a) {
   extern __shared__ double lds[];
-  const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
+  const int nb = a.nb;
   double* B = a.vals + a.border_off;
-  for (int e = tid; e < nb * nb; e += nt) {
+  double* part = lds + (2 * nb + 2);               // [blockDim.x] partial sums, behind block_eliminate's scratch
+  auto term = [&](int64_t j, int e) -> double {
+    if (j < 0) {                                    // total of entry -1 - j sits in part[e]
+      const int ent = (int)(-1 - j);
+      const int i = ent / nb, k = ent % nb;
+      if (k <= i) B[ent] += part[e];
+      return 0.0;
+    }
     const int i = e / nb, k = e % nb;
-    if (k > i) continue;
-    double acc = B[e];
-    for (int64_t l = 0; l < a.n_leaf; ++l) {
-      const int64_t left = a.leaf_left[l];
+    if (k > i) return 0.0;
+    if (j < a.n_leaf) {
+      const int64_t left = a.leaf_left[j];
       const int ws = nzb_of(a, left) + nzb_of(a, left + 1) + nb, o = ws - nb;
-      acc += a.vals[a.leafS_off[l] + (size_t)(o + i) * ws + o + k];
+      return a.vals[a.leafS_off[j] + (size_t)(o + i) * ws + o + k];
     }
-    for (int64_t c = 0; c < a.n_chain; ++c) {
-      const int nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb;
-      acc += a.vals[a.chainS_off[c] + (size_t)(nx + i) * wc + nx + k];
+    const int64_t c = j - a.n_leaf;
+    if (a.cr) {
+      const int o = (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0), wc = o + nb;
+      return a.crbuf[a.crS_off[c] + (size_t)(o + i) * wc + o + k];
     }
-    B[e] = acc;
-  }
+    const int nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb;
+    return a.vals[a.chainS_off[c] + (size_t)(nx + i) * wc + nx + k];
+  };
+  border_accumulate(a, nb * nb, part, term);
   __syncthreads();
   block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
 }
@@ -365,15 +848,23 @@ __global__ void kkt_border_solve(KArgs a) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
   double* rb = a.r + a.base_border;
-  for (int i = tid; i < nb; i += nt) {
-    double v = rb[i];
-    for (int64_t l = 0; l < a.n_leaf; ++l) {
-      const int64_t left = a.leaf_left[l];
-      v -= a.leafG[a.leafG_off[l] + nzb_of(a, left) + nzb_of(a, left + 1) + i];
+  double* part = lds + (nb + 2);
+  for (int i = tid; i < nb; i += nt) lds[i] = rb[i];
+  __syncthreads();
+  auto term = [&](int64_t j, int e) -> double {
+    if (j < 0) {
+      lds[(int)(-1 - j)] -= part[e];
+      return 0.0;
     }
-    for (int64_t c = 0; c < a.n_chain; ++c) v -= a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + i];
-    lds[i] = v;
-  }
+    if (j < a.n_leaf) {
+      const int64_t left = a.leaf_left[j];
+      return a.leafG[a.leafG_off[j] + nzb_of(a, left) + nzb_of(a, left + 1) + e];
+    }
+    const int64_t c = j - a.n_leaf;
+    if (a.cr) return a.crbuf[a.crG_off[c] + (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0) + e];
+    return a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + e];
+  };
+  border_accumulate(a, nb, part, term);
   __syncthreads();
   block_solve(a.vals + a.border_off, nb, nb, lds);
   for (int i = tid; i < nb; i += nt) rb[i] = lds[i];
@@ -442,6 +933,12 @@ struct pc_kkt {
   int n_leaf = 0, n_chain = 0, n_phase = 0, nb = 0;
   int lds_leaf = 0, lds_chain = 0, lds_border = 0;
   int lds_chain_factor = 0;
+  bool chain_wave = false;   // the chain kernels that run as one wave with everything a step reads prefetched
+  bool chain_cr = false;     // the chain by cyclic reduction: one launch per level
+  std::vector<int64_t> cr_lvl_ptr;   // nodes of level l: cr_nodes[cr_lvl_ptr[l-1] .. cr_lvl_ptr[l])
+  int lds_cr = 0;
+  Dev<double> crbuf;
+  Dev<int64_t> cr_a, cr_b, crP_off, crS_off, crG_off, cr_nodes;
   int lds_leaf_full = 0;   // LDS of the leaf factorisation: the largest leaf block that fits, plus its staging vectors
   Dev<double> vals, r, leafG, chainG, dvec, vin, vout, src_coef, mv_coef;
   Dev<int64_t> perm, leaf_ptr, chain_ptr, chain_phase_ptr, leaf_left, leafA_off, leafS_off, chainD_off, chainS_off,
@@ -546,8 +1043,57 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       k->args.wcmax = (int32_t)wcmax;
       k->args.chain_lds = full <= 64000 ? 1 : 0;
       k->lds_chain_factor = (int)(k->args.chain_lds ? full : k->lds_chain);
+      // one-wave chain kernels: a node's panel is held by 64 lanes x CH_PER registers between steps
+      k->chain_wave = k->args.chain_lds && nzmax <= 64 && wcmax <= 64 && nzmax * (nzmax + wcmax) <= 64 * CH_PER;
+      if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CHAIN_WAVE")) k->chain_wave = k->chain_wave && std::atoi(env) != 0;
     }
-    k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2));
+    {   // cyclic reduction of the chain: levels, separators, buffer offsets
+      const int64_t nc = d->n_chain;
+      std::vector<int64_t> ca(nc, -1), cb(nc, -1), oP(nc), oS(nc), oG(nc);
+      std::vector<int> lvl(nc, 1);
+      int lmax = 1;
+      for (int64_t ph = 0; ph < d->n_phase; ++ph) {
+        const int64_t c0 = d->chain_phase_ptr[ph], n = d->chain_phase_ptr[ph + 1] - c0;
+        int levels = 0;
+        while (((int64_t)1 << levels) <= n - 1) ++levels;      // number of odd-even levels
+        for (int64_t p = 0; p < n; ++p) {
+          if (p == 0) { lvl[c0] = levels + 1; continue; }
+          const int l = __builtin_ctzll((unsigned long long)p) + 1;
+          const int64_t h = (int64_t)1 << (l - 1);
+          lvl[c0 + p] = l;
+          ca[c0 + p] = c0 + p - h;
+          if (p + h <= n - 1) cb[c0 + p] = c0 + p + h;
+        }
+        lmax = std::max(lmax, levels + 1);
+      }
+      int64_t off = 0, ldsmax = 0;
+      auto nzof = [&](int64_t c) { return d->chain_ptr[c + 1] - d->chain_ptr[c]; };
+      for (int64_t c = 0; c < nc; ++c) {
+        const int64_t nz = nzof(c), w = (ca[c] >= 0 ? nzof(ca[c]) : 0) + (cb[c] >= 0 ? nzof(cb[c]) : 0) + d->nb;
+        oP[c] = off; off += nz * (nz + w);
+        oS[c] = off; off += w * w;
+        oG[c] = off; off += w;
+        ldsmax = std::max(ldsmax, 8 * (2 * nz + w + nz * (nz + w) + w * w + 2));
+        if (nz > 64 || w > 64) ldsmax = 1 << 30;
+      }
+      k->chain_cr = ldsmax <= 64000;
+      if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CR")) k->chain_cr = k->chain_cr && std::atoi(env) != 0;
+      if (k->chain_cr) {
+        std::vector<int64_t> nodes;
+        k->cr_lvl_ptr.assign(1, 0);
+        for (int l = 1; l <= lmax; ++l) {
+          for (int64_t c = 0; c < nc; ++c)
+            if (lvl[c] == l) nodes.push_back(c);
+          k->cr_lvl_ptr.push_back((int64_t)nodes.size());
+        }
+        k->lds_cr = (int)ldsmax;
+        k->crbuf.alloc((size_t)std::max<int64_t>(1, off));
+        k->cr_a.upload(ca.data(), ca.size()); k->cr_b.upload(cb.data(), cb.size());
+        k->crP_off.upload(oP.data(), oP.size()); k->crS_off.upload(oS.data(), oS.size()); k->crG_off.upload(oG.data(), oG.size());
+        k->cr_nodes.upload(nodes.data(), nodes.size());
+      }
+    }
+    k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2 + 256));
     if (k->lds_leaf > 60000 || k->lds_chain > 60000 || k->lds_border > 60000)
       throw std::runtime_error("KKT block too large for the solver's LDS staging");
     k->vals.alloc((size_t)d->total_vals);
@@ -570,6 +1116,13 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     a.counts = k->counts.p;
     a.r = k->r.p; a.leafG = k->leafG.p; a.chainG = k->chainG.p;
     a.leafG_off = k->leafG_off.p; a.chainG_off = k->chainG_off.p;
+    a.cr = k->chain_cr ? 1 : 0;
+    if (k->chain_cr) {
+      a.crbuf = k->crbuf.p;
+      a.cr_a = k->cr_a.p; a.cr_b = k->cr_b.p;
+      a.crP_off = k->crP_off.p; a.crS_off = k->crS_off.p; a.crG_off = k->crG_off.p;
+      a.cr_nodes = k->cr_nodes.p;
+    }
   });
   if (!ok) {
     delete k;
@@ -606,7 +1159,13 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
       la.lds_doubles = k->lds_leaf_full / 8;
       hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(128), k->lds_leaf_full, st, la);
     }
-    hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    if (k->chain_cr) {
+      for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
+        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
+      }
+    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_factor_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    else hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     KHIP(hipMemcpyAsync(k->h_counts.data(), k->counts.p, k->h_counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -632,9 +1191,21 @@ int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
     KHIP(hipMemcpyAsync(k->vin.p, rhs, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, k->vin.p, k->perm.p, k->fixed.p, k->r.p, k->nu);
     if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
-    hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
-    hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(64), k->lds_border, st, k->args);
-    hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+    if (k->chain_cr) {
+      for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
+        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
+      }
+    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_forward_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+    hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(256), k->lds_border, st, k->args);
+    if (k->chain_cr) {
+      for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
+        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
+      }
+    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_backward_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
     if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
     hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, k->vout.p, k->nu);
     KHIP(hipGetLastError());

@@ -482,13 +482,17 @@ class GpuInteriorPointSolver(InteriorPointSolver):
         t0 = time.perf_counter()
         sol = k.solve(rhs)
         res = rhs - k.matvec(dvec_true, sol, use_hess)
+        n_solves = 1
         for _ in range(3):
             trial = sol + k.solve(res)
             res_t = rhs - k.matvec(dvec_true, trial, use_hess)
+            n_solves += 1
             if not np.all(np.isfinite(trial)) or np.linalg.norm(res_t) >= 0.5 * np.linalg.norm(res):
                 break
             sol, res = trial, res_t
         self.times["solve"] += time.perf_counter() - t0
+        self.counts["kkt_solves"] = self.counts.get("kkt_solves", 0) + n_solves
+        self.counts["refined_solves"] = self.counts.get("refined_solves", 0) + 1
         return sol
 
     def _solve_kkt(self, W, Sigma, J, r1, r2, dw_last):

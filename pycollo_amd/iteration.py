@@ -140,7 +140,16 @@ class MeshIteration:
         cls = {"gpu": GpuInteriorPointSolver, "host": InteriorPointSolver}[linear_solver]
         solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
                      tol=tol, max_iter=max_iter, verbose=verbose)
-        res = solver.solve(self.guess_x_tilde)
+        # The model's SymPy graphs are millions of long-lived objects: a full collection walking them takes ~80 ms and
+        # strikes in the middle of whichever 2 ms linear solve allocates the unlucky array (measured: 8 such stalls in
+        # an 18-iteration solve, more than all factorisations together).  They are parked for the duration.
+        import gc
+        gc.collect()
+        gc.freeze()
+        try:
+            res = solver.solve(self.guess_x_tilde)
+        finally:
+            gc.unfreeze()
         if linear_solver == "gpu" and not res.success:
             # The two linear solvers round differently; on a degenerate NLP (a bang-bang solution on a coarse mesh) that
             # can send the filter line search into its restoration phase on one path and not on the other.  A failed

@@ -1,12 +1,14 @@
 """Development aid: wall time of pc_kkt_factor / pc_kkt_solve / pc_kkt_matvec at config-2 size for several leaf groupings."""
-import sys, time
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import os, sys, time
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
 import numpy as np
 from test_kkt_cpu import kkt_case
 from pycollo_amd.kkt import GpuKkt
 eng, ora, x, lam, ineq, fixed, sc, dvec = kkt_case("hypersensitive", dict(K=2000, order=6), device=0)
 eng.evaluate_resident(x, 1.0, lam)
-for g in (None, 8, 16):
+groups = [None if a == 'auto' else int(a) for a in sys.argv[1:]] or [None, 8, 16]
+for g in groups:
     t0=time.perf_counter(); k = GpuKkt(eng, ineq, fixed, sc, group=g); t1=time.perf_counter()
     rhs=np.random.default_rng(0).normal(size=k.nu)
     for name,fn in (("factor",lambda: k.factor(dvec)),("solve",lambda: k.solve(rhs)),("matvec",lambda: k.matvec(dvec,rhs))):

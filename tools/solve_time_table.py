@@ -30,6 +30,9 @@ for ls in ("gpu", "host"):
            "objective": float(it.objective), "nlp_iterations": int(res.iterations), "factorisations": ev["factorisations"],
            "wall_s": round(wall, 3), "ms_per_iteration": round(1e3 * wall / max(1, res.iterations), 2),
            "kkt_s": round(ev["kkt_seconds"], 3), "kkt_ms_per_iteration": round(1e3 * ev["kkt_seconds"] / max(1, res.iterations), 2)}
+    for key in ("kkt_solves", "refined_solves", "jacobian", "hessian", "constraints"):
+        if key in ev:
+            row["n_" + key] = ev[key]
     if "gpu_seconds" in ev:
         row["gpu_seconds"] = {k: round(v, 4) for k, v in ev["gpu_seconds"].items()}
         row["ms_per_factorisation"] = round(1e3 * ev["gpu_seconds"]["factor"] / max(1, ev["factorisations"]), 3)
