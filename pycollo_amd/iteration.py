@@ -141,14 +141,18 @@ class MeshIteration:
         solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
                      tol=tol, max_iter=max_iter, verbose=verbose)
         # The model's SymPy graphs are millions of long-lived objects: a full collection walking them takes ~80 ms and
-        # strikes in the middle of whichever 2 ms linear solve allocates the unlucky array (measured: 8 such stalls in
-        # an 18-iteration solve, more than all factorisations together).  They are parked for the duration.
+        # strikes in the middle of whichever linear solve allocates the unlucky array (measured: 8 such stalls in
+        # an 18-iteration solve, more than all factorisations together).  Collection is off for the duration.
         import gc
+        was_enabled = gc.isenabled()
         gc.collect()
         gc.freeze()
+        gc.disable()      # (what the solve allocates is arrays: reference counting frees them)
         try:
             res = solver.solve(self.guess_x_tilde)
         finally:
+            if was_enabled:
+                gc.enable()
             gc.unfreeze()
         if linear_solver == "gpu" and not res.success:
             # The two linear solvers round differently; on a degenerate NLP (a bang-bang solution on a coarse mesh) that
