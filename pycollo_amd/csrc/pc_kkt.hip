@@ -138,20 +138,30 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
     for (int i = j + 1 + tid; i < m; i += nt) M[(size_t)i * ld + j] = lcol[i];
   }
   blk_sync<WAVE>();
-  if (S)   // Z = L^-1 C now sits in the C part
+  // Z = L^-1 C now sits in the C part.  1 / D once (the scratch vectors are free again), then S = -Z^T D^-1 Z,
+  // Y = D^-1 Z and the back-substitution L^T X = Y column-oriented: once row j is final every row above it loses
+  // L[j][i] X[j][:] -- all (i, c) pairs of a step in parallel, one barrier per row.  (A thread per column walking all
+  // of L serially, as this was first written, left 8 of a leaf's 128 threads busy for ~100 us of a 300 us leaf.)
+  double* dinv = lds;
+  for (int j = tid; j < m; j += nt) dinv[j] = 1.0 / M[(size_t)j * ld + j];
+  blk_sync<WAVE>();
+  if (S)
     for (int e = tid; e < w * w; e += nt) {
       const int a = e / w, b = e % w;
       double acc = 0.0;
-      for (int j = 0; j < m; ++j) acc += M[(size_t)j * ld + m + a] * (M[(size_t)j * ld + m + b] / M[(size_t)j * ld + j]);
+      for (int j = 0; j < m; ++j) acc += M[(size_t)j * ld + m + a] * (M[(size_t)j * ld + m + b] * dinv[j]);
       S[e] = -acc;
     }
   blk_sync<WAVE>();
-  for (int c = tid; c < w; c += nt) {   // X = L^-T D^-1 Z, one column per thread
-    for (int j = 0; j < m; ++j) M[(size_t)j * ld + m + c] /= M[(size_t)j * ld + j];
-    for (int j = m - 1; j >= 0; --j) {
-      double acc = M[(size_t)j * ld + m + c];
-      for (int i = j + 1; i < m; ++i) acc -= M[(size_t)i * ld + j] * M[(size_t)i * ld + m + c];
-      M[(size_t)j * ld + m + c] = acc;
+  for (int e = tid; e < m * w; e += nt) {
+    const int j = e / w, c = e - j * w;
+    M[(size_t)j * ld + m + c] *= dinv[j];
+  }
+  for (int j = m - 1; j > 0; --j) {
+    blk_sync<WAVE>();
+    for (int e = tid; e < j * w; e += nt) {
+      const int i = e / w, c = e - i * w;
+      M[(size_t)i * ld + m + c] -= M[(size_t)j * ld + i] * M[(size_t)j * ld + m + c];
     }
   }
   blk_sync<WAVE>();

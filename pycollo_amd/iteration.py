@@ -14,6 +14,8 @@ answers act as end-to-end checks on small meshes.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .engine import NlpEngine, interp_linear
@@ -148,9 +150,19 @@ class MeshIteration:
         gc.collect()
         gc.freeze()
         gc.disable()      # (what the solve allocates is arrays: reference counting frees them)
+        # The other source of ~80-100 ms stalls anywhere in the process: numpy's BLAS starts one spinning thread per
+        # hardware thread (256 on the MI355X host) for a dot product of 30 k doubles; inside a CPU-quota cgroup they
+        # burn the period's budget and the whole process is throttled until the next period.
+        try:
+            from threadpoolctl import threadpool_limits
+            blas_limit = threadpool_limits(limits=min(8, os.cpu_count() or 8))
+        except Exception:        # threadpoolctl not installed: nothing to limit with
+            blas_limit = None
         try:
             res = solver.solve(self.guess_x_tilde)
         finally:
+            if blas_limit is not None:
+                blas_limit.restore_original_limits()
             if was_enabled:
                 gc.enable()
             gc.unfreeze()
