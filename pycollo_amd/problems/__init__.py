@@ -398,6 +398,39 @@ def time_coupled_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
     return prob
 
 
+def time_scaled_transfer(K: int = 10, order: int = 4) -> ProblemSpec:
+    """Rest-to-rest transfer of a unit mass over unit distance whose actuator weakens with the manoeuvre's duration:
+    ``dv/dt = u / tF`` -- the final-time *variable* inside a state equation -- with objective ``q + tF``, ``q`` the
+    integral of ``u**2``, and an (inactive) path constraint that involves ``q``.  With a = u / tF the minimum of
+    int a^2 over rest-to-rest transfers in time T is 12 / T^3, so q = 12 / T and J = 12 / T + T: T* = sqrt(12),
+    J* = 2 sqrt(12) = 6.92820323...  (Not from the reference: it exists to solve an NLP whose node functions depend on
+    tF and q end to end; the live reference allows both, pycollo/backend.py:1526-1539.)"""
+    x, v, u = sym.symbols("x v u")
+    prob = ProblemSpec("time-scaled transfer")
+    ph = prob.new_phase("A")
+    ph.state_variables = [x, v]
+    ph.control_variables = [u]
+    ph.integrand_functions = [u**2]
+    q0, tF = ph.integral_variables[0], ph.final_time_variable
+    ph.state_equations = [v, u / tF]
+    ph.path_constraints = [x - q0 / 200]
+    prob.objective_function = q0 + tF
+    ph.bounds.initial_time = 0.0
+    ph.bounds.final_time = [1.0, 8.0]
+    ph.bounds.state_variables = [[-1, 2], [-5, 5]]
+    ph.bounds.control_variables = [[-20, 20]]
+    ph.bounds.integral_variables = [[0, 100]]
+    ph.bounds.path_constraints = [[-5, 1.5]]
+    ph.bounds.initial_state_constraints = {x: 0, v: 0}
+    ph.bounds.final_state_constraints = {x: 1, v: 0}
+    ph.guess.time = np.array([0.0, 3.0])
+    ph.guess.state_variables = np.array([[0.0, 1.0], [0.0, 0.0]])
+    ph.guess.control_variables = np.array([[0.0, 0.0]])
+    ph.guess.integral_variables = np.array([4.0])
+    _mesh(ph, K, order)
+    return prob
+
+
 def sliding_mass(num_phases: int = 2, K: int = 10, order: int = 4) -> ProblemSpec:
     """Unit mass slid from x = 0 to x = 1 in minimum time, at rest at both ends, split into ``num_phases`` phases
     of equal distance with velocity / time continuity as endpoint constraints -- the problem of the reference's
@@ -569,6 +602,7 @@ REGISTRY = {
     "double_pendulum": double_pendulum,
     "two_phase_transfer": two_phase_transfer,
     "time_coupled_transfer": time_coupled_transfer,
+    "time_scaled_transfer": time_scaled_transfer,
     "sliding_mass": sliding_mass,
     "free_flying_robot": free_flying_robot,
     "tumour_anti_angiogenesis": tumour_anti_angiogenesis,

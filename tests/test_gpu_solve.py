@@ -90,3 +90,14 @@ def test_callback_counts_are_reported(built):
     ev = res.evaluations
     assert ev["hessian"] >= res.iterations and ev["jacobian"] >= res.iterations and ev["objective"] >= res.iterations
     assert res.inf_pr < 1e-8
+
+
+def test_time_scaled_transfer_solution(built):
+    """An NLP whose state equations contain the final-time variable and whose path constraint contains an integral
+    variable (pycollo/backend.py:1526-1539 keeps both global inside f, p, g), solved end to end on both linear-algebra
+    paths: analytic optimum J = 2 sqrt(12), tF = sqrt(12) (problems.time_scaled_transfer)."""
+    from pycollo_amd.solve import solve_ocp
+    for ls in ("gpu", "host"):
+        res = solve_ocp(problems.time_scaled_transfer(), mesh_tolerance=1e-7, linear_solver=ls)
+        np.testing.assert_allclose(res.objective, 2.0 * np.sqrt(12.0), rtol=1e-7)
+        assert res.mesh_tolerance_met is True
