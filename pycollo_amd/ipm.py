@@ -55,8 +55,12 @@ class IpmResult:
 
 class InteriorPointSolver:
     def __init__(self, problem_obj, n: int, m: int, lb, ub, cl, cu, tol: float = 1e-8, acceptable_tol: float = 1e-6,
-                 max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0):
+                 max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0, warm_start: bool = False):
         self.p, self.n, self.m = problem_obj, int(n), int(m)
+        # IPOPT's warm_start_init_point (the one thing pycollo's warm_start setting switches, backend.py:1703-1709):
+        # the starting point is kept closer to where it was given -- bound push / fraction 1e-3 instead of 1e-2
+        # (warm_start_bound_push, warm_start_bound_frac).  No multipliers are handed over: the reference passes none.
+        self.warm_start = bool(warm_start)
         self.lb, self.ub = np.asarray(lb, float).copy(), np.asarray(ub, float).copy()
         self.cl, self.cu = np.asarray(cl, float).copy(), np.asarray(cu, float).copy()
         self.tol, self.acceptable_tol, self.max_iter, self.mu_init, self.verbose = tol, acceptable_tol, max_iter, mu_init, verbose
@@ -266,7 +270,7 @@ class InteriorPointSolver:
         v = np.concatenate([x0, np.zeros(self.ns)])
         if self.ns:
             v[n:] = (self.sc * np.asarray(self.p.constraints(x0), float))[self.ineq]
-        v = self._push_interior(v)
+        v = self._push_interior(v, 1e-3, 1e-3) if self.warm_start else self._push_interior(v)
         v[self.fixed] = self.vl[self.fixed]
         mu = self.mu_init
         zl = np.where(self.hasl, 1.0, 0.0)

@@ -29,9 +29,10 @@ class OcpResult:
 
 def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float = MESH_TOLERANCE, device: int = 0,
               nlp_tol: float = 1e-8, nlp_max_iter: int = 1000, verbose: int = 0, update_scaling: bool = False,
-              scaling_weight: float = 0.8, linear_solver: str = "gpu") -> OcpResult:
+              scaling_weight: float = 0.8, linear_solver: str = "gpu", warm_start: bool = False) -> OcpResult:
     """Solve ``problem`` (a :class:`pycollo_amd.problem.ProblemSpec`) on its initial mesh, refine, repeat.
-    ``update_scaling`` / ``scaling_weight``: pycollo/settings.py:272-296 (scalings averaged over the mesh iterations)."""
+    ``update_scaling`` / ``scaling_weight``: pycollo/settings.py:272-296 (scalings averaged over the mesh iterations);
+    ``warm_start``: pycollo/settings.py:228 (IPOPT's ``warm_start_init_point``, every mesh iteration)."""
     prob = copy.deepcopy(problem)
     prev = None
     log = []
@@ -42,7 +43,8 @@ def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float =
         it = MeshIteration(prob, device=device, prev=prev, number=k + 1, update_scaling=update_scaling,
                            scaling_weight=scaling_weight, history=history)
         history.append(it.scaling_record)
-        res = it.solve_with_ipm(max_iter=nlp_max_iter, tol=nlp_tol, verbose=max(0, verbose - 1), linear_solver=linear_solver)
+        res = it.solve_with_ipm(max_iter=nlp_max_iter, tol=nlp_tol, verbose=max(0, verbose - 1), linear_solver=linear_solver,
+                                warm_start=warm_start)
         errs = mesh_error(it.engine, it.x_tilde)
         worst = max(float(np.max(rel)) for rel, _ in errs)
         log.append({"K": [int(m.K) for m in it.meshes], "N": [int(pl.N) for pl in it.layout.phases],

@@ -43,6 +43,23 @@ def test_hs071():
     assert res.inf_pr < 1e-8
 
 
+def test_warm_start_keeps_the_starting_point_closer():
+    """pycollo's ``warm_start`` setting = IPOPT's warm_start_init_point (backend.py:1703-1709): the bound push of the
+    initial point drops from 1e-2 to 1e-3; same optimum, and a start on a bound moves a tenth as far."""
+    from pycollo_amd.ipm import InteriorPointSolver
+    p = HS071()
+    args = (p, 4, 2, np.ones(4), 5 * np.ones(4), np.array([25.0, 40.0]), np.array([2e19, 40.0]))
+    x0 = np.array([1.0, 4.743, 3.821, 1.379])
+    cold, warm = InteriorPointSolver(*args), InteriorPointSolver(*args, warm_start=True)
+    v = np.concatenate([x0, [30.0]])
+    assert abs(cold._push_interior(v)[0] - 1.0 - 1e-2) < 1e-12
+    assert abs(warm._push_interior(v, 1e-3, 1e-3)[0] - 1.0 - 1e-3) < 1e-12
+    rc, rw = cold.solve(x0), warm.solve(x0)
+    assert rc.success and rw.success
+    np.testing.assert_allclose(rw.objective, 17.0140173, rtol=1e-7)
+    np.testing.assert_allclose(rw.x, rc.x, rtol=1e-6)
+
+
 class Rosenbrock:
     """Unconstrained in c (m = 0) with one fixed variable and one active bound."""
     n, m = 3, 0
