@@ -387,11 +387,14 @@ def time_coupled_transfer(K: int = 4, order: int = 3) -> ProblemSpec:
     B.bounds.integral_variables = [[0, 50], [-10, 10]]
     B.bounds.path_constraints = [[-30, 30]]
     B.bounds.final_state_constraints = {x: 1.0, v: 0.0}
-    prob.objective_function = (qA[0] + qB[0] * tFB + k * B.final_state_variables[1]**2 * A.initial_state_variables[0])
+    # (the q x y(tF) and t x y(t0) products put endpoint terms on the ends of a q strip and of a t strip)
+    prob.objective_function = (qA[0] + qB[0] * tFB + k * B.final_state_variables[1]**2 * A.initial_state_variables[0]
+                               + sym.Rational(1, 10) * qA[0] * A.final_state_variables[1])
     prob.endpoint_constraints = [A.final_state_variables[0] - B.initial_state_variables[0],
                                  A.final_state_variables[1] - B.initial_state_variables[1],
                                  tFA - t0B,
-                                 qB[1] * k - sym.sin(A.final_state_variables[0]) * tFB + qA[1]]
+                                 qB[1] * k - sym.sin(A.final_state_variables[0]) * tFB + qA[1]
+                                 + t0B * B.initial_state_variables[0] * qB[1]]
     prob.bounds.endpoint_constraints = [0, 0, 0, [-1, 1]]
     _mesh(A, K, order)
     _mesh(B, K + 1, order + 1)
