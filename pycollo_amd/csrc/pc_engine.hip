@@ -782,6 +782,11 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         const bool heavy = P.eval_ops > 4000;
         if (P.n_y >= 2 && D.n_tiles <= (heavy ? 512 : 1024)) D.wpt = 2;
         if (P.n_y >= 3 && D.n_tiles <= 400) D.wpt = 4;
+        // One state, one launch per evaluation: the last tile's store phase is what the launch waits for once the tail
+        // runs beside the tiles, and four waves get a tile's runs out sooner than one (hypersensitive, W = 1 / 2 / 4:
+        // 42 tiles 4.69 / 4.34 / 4.25 us, 167 tiles 4.78-4.99 / 4.59-4.87 / 4.46-4.69, 334 tiles 5.94 / 5.00 / 4.94,
+        // 500 tiles 5.92 / 5.29 / 5.44; with a separate tail launch W = 2 measured no gain, 5.58 vs 5.49 us)
+        if (P.n_y == 1 && !heavy && h->resident) D.wpt = D.n_tiles <= 400 ? 4 : (D.n_tiles <= 1024 ? 2 : 1);
         if (const char* env = std::getenv("PYCOLLO_AMD_WPT")) {
           const int v = std::atoi(env);
           if (v == 1 || v == 2 || v == 4) D.wpt = v;
