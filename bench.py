@@ -344,7 +344,10 @@ def main():
     # ---- what a host-side caller (IPOPT) sees: pc_eval_all with host pointers in and out, one call at a time ----
     host = None
     if world == 1 and not args.no_host:
-        host = host_leg(eng, x.cpu().numpy(), lam.cpu().numpy(), args.host_calls)
+        # (eight timed loops of `calls` evaluations each: bounded to ~32 GB over the bus in total for large meshes; config 2 keeps its 2000)
+        per_call = 8.0 * (eng.num_x + 2 * eng.num_c + eng.nnz_jac + eng.nnz_hess)
+        calls = int(max(20, min(args.host_calls, 4e9 / per_call)))
+        host = host_leg(eng, x.cpu().numpy(), lam.cpu().numpy(), calls)
 
     if rank == 0:
         out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",

@@ -707,7 +707,15 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         h->lds_limit = v;
     }
     const bool auto_tb = (TB == 0);
-    if (auto_tb) TB = Nmax >= 262144 ? 256 : (Nmax >= 65536 ? 128 : 64);
+    if (auto_tb) {
+      TB = Nmax >= 262144 ? 256 : (Nmax >= 65536 ? 128 : 64);
+      // a one-state model has so little per node that the widest workgroup pays much earlier (hypersensitive, TB =
+      // 64 / 128 / 256: 20 k nodes 5.11 / 4.94-5.21 / 5.0-5.2 us, 30 k 5.46 / 5.41 / 5.18, 50 k 6.67 / 5.81 / 5.70,
+      // 65 k 8.92 / 6.76 / 5.90, 150 k 14.5 / 9.05 / 8.27, 250 k 22.1 / 12.1 / 9.97)
+      bool one_state = true;
+      for (int ip = 0; ip < d->n_phases; ++ip) one_state = one_state && d->phases[ip].n_y == 1 && d->phases[ip].eval_ops <= 4000;
+      if (one_state && Nmax >= 25000) TB = 256;
+    }
     if (TB != 64 && TB != 128 && TB != 256) throw std::runtime_error("threads_per_block must be 64, 128 or 256");
     for (auto& P : Q.ph) pcp::finalize_phase_tables(P, Q.n_s);
     if (auto_tb) {  // largest tile whose staging fits the 64 KiB of dynamic LDS a module kernel may request
