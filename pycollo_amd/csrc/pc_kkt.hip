@@ -299,258 +299,6 @@ __global__ void kkt_chain_factor(KArgs a) {
   }
 }
 
-// ---- the chain as one wave -----------------------------------------------------------------------------------------
-// The walk along a phase's chain is the sequential part of the factorisation and of both triangular solves: hundreds
-// to thousands of steps on blocks of a few unknowns.  In the kernels above a step is a string of dependent global
-// round trips (table entries -> block offsets -> block values; every __syncthreads() also drains the stores of the
-// step before): 4.4 us per step in the factorisation and 2.2 us in the forward solve of a 3-unknown node.  Here one
-// wave walks the chain with (i) the per-node table entries fetched 64 nodes at a time, one node per lane, and handed
-// out by v_readlane, (ii) everything a step reads from global memory requested one step ahead and parked in
-// registers, (iii) the working panel, the carried Schur block and the right-hand side in LDS, ordered by
-// s_waitcnt lgkmcnt(0) alone, (iv) stores left to drain on their own.  Used when a node panel fits 64 x CH_PER
-// elements and the chain blocks fit LDS (pc_kkt_create decides); the kernels above remain the general path.
-#define CH_PER 8
-struct ChainMeta {   // per chain node, held by the lane that fetched it
-  int nz, nx, last;
-  long long D, S, SR, G, LG;   // chainD_off, chainS_off, leafS_off / leafG_off of the leaf on the right (-1), chainG_off
-};
-__device__ __forceinline__ int rl32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ long long rl64(long long v, int lane) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane);
-  return (long long)(((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ ChainMeta chain_meta_fetch(const KArgs& a, int64_t c, int64_t c1) {
-  ChainMeta m{0, 0, 1, 0, 0, -1, 0, -1};
-  if (c < c1) {
-    const int64_t p0 = a.chain_ptr[c], p1 = a.chain_ptr[c + 1];
-    m.last = a.chain_last[c];
-    m.nz = (int)(p1 - p0);
-    m.nx = m.last ? 0 : (int)(a.chain_ptr[c + 2] - p1);
-    m.D = a.chainD_off[c];
-    m.S = a.chainS_off[c];
-    m.G = a.chainG_off[c];
-    if (!m.last) {
-      const int64_t l = a.leaf_of_left[c];
-      m.SR = a.leafS_off[l];
-      m.LG = a.leafG_off[l];
-    }
-  }
-  return m;
-}
-__device__ __forceinline__ ChainMeta chain_meta_bcast(const ChainMeta& m, int lane) {
-  ChainMeta o;
-  o.nz = rl32(m.nz, lane); o.nx = rl32(m.nx, lane); o.last = rl32(m.last, lane);
-  o.D = rl64(m.D, lane); o.S = rl64(m.S, lane); o.SR = rl64(m.SR, lane); o.G = rl64(m.G, lane); o.LG = rl64(m.LG, lane);
-  return o;
-}
-
-__global__ void __launch_bounds__(64) kkt_chain_factor_w(KArgs a) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, nb = a.nb;
-  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
-  double* carry = lds + (2 * a.nzmax + a.wcmax);
-  double* M = carry + a.wcmax * a.wcmax;
-  double* S = M + a.nzmax * (a.nzmax + a.wcmax);
-  double pre[CH_PER];
-  // what node `m` (left neighbour `ml`, has_left) reads from global memory: its own entries (the diagonal block was
-  // assembled as a lower triangle), the Schur block of the leaf on its left (R and border rows), the one on its right
-  auto prefetch = [&](const ChainMeta& m, const ChainMeta& ml, bool has_left) {
-    const int nz = m.nz, nx = m.nx, ld = nz + nx + nb;
-    const double* Mg = a.vals + m.D;
-    const double* SR = a.vals + (m.last ? 0 : m.SR);
-    const int nl = ml.nz, ws = nl + nz + nb;
-    const double* SL = a.vals + (has_left ? ml.SR : 0);
-#pragma unroll
-    for (int q = 0; q < CH_PER; ++q) {
-      const int e = tid + 64 * q;
-      double v = 0.0;
-      if (e < nz * ld) {
-        const int i = e / ld, k = e - i * ld;
-        v = (k < nz && k > i) ? Mg[(size_t)k * ld + i] : Mg[e];
-        if (has_left && (k < nz || k >= nz + nx)) v += SL[(size_t)(nl + i) * ws + nl + (k < nz ? k : k - nx)];
-        if (!m.last) v += SR[e];
-      }
-      pre[q] = v;
-    }
-  };
-  ChainMeta lane_meta, cur{}, left{}, nxt{};
-  for (int64_t cb = c0; cb < c1; cb += 64) {
-    lane_meta = chain_meta_fetch(a, cb + tid, c1);
-    const int steps = (int)((c1 - cb) < 64 ? (c1 - cb) : 64);
-    if (cb == c0) {
-      cur = chain_meta_bcast(lane_meta, 0);
-      prefetch(cur, left, false);
-    }
-    for (int s = 0; s < steps; ++s) {
-      const int64_t c = cb + s;
-      const bool has_left = c > c0;
-      const int nz = cur.nz, nx = cur.nx, wc = nx + nb, ld = nz + wc, wr = nz + nb;
-      // the panel goes to LDS together with the Schur block carried over from the previous node
-#pragma unroll
-      for (int q = 0; q < CH_PER; ++q) {
-        const int e = tid + 64 * q;
-        if (e < nz * ld) {
-          const int i = e / ld, k = e - i * ld;
-          double v = pre[q];
-          if (has_left && (k < nz || k >= nz + nx)) v += carry[(size_t)i * wr + (k < nz ? k : k - nx)];
-          M[e] = v;
-        }
-      }
-      // the next node's values are requested now and arrive while this one is eliminated
-      const bool more = c + 1 < c1;
-      if (more) {
-        if (s + 1 < steps) nxt = chain_meta_bcast(lane_meta, s + 1);
-        else { const ChainMeta t = chain_meta_fetch(a, c + 1, c1); nxt = chain_meta_bcast(t, 0); }   // batch boundary
-        prefetch(nxt, cur, true);
-      }
-      wave_lds_sync();
-      block_eliminate<true>(M, nz, wc, S, a.counts + 2 * (a.n_leaf + c), lds);
-      double* Mg = a.vals + cur.D;
-      double* Sg = a.vals + cur.S;
-      for (int e = tid; e < nz * ld; e += 64) Mg[e] = M[e];
-      for (int e = tid; e < wc * wc; e += 64) {
-        const double v = S[e];
-        Sg[e] = v;
-        carry[e] = v;
-      }
-      wave_lds_sync();
-      left = cur;
-      cur = nxt;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(64) kkt_chain_forward_w(KArgs a) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, nb = a.nb;
-  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
-  double* rr = lds;                                  // [nzmax] right-hand side of the node, then its solution
-  double* gp = rr + a.nzmax;                         // [wcmax] Y^T r of the previous node
-  double* M = gp + a.wcmax;                          // [nzmax][nzmax + wcmax] the node's factored panel
-  double pre[CH_PER], rv = 0.0;
-  auto prefetch = [&](const ChainMeta& m, const ChainMeta& ml, bool has_left, int64_t c) {
-    const int nz = m.nz, ld = nz + m.nx + nb;
-    const double* Mg = a.vals + m.D;
-#pragma unroll
-    for (int q = 0; q < CH_PER; ++q) {
-      const int e = tid + 64 * q;
-      pre[q] = e < nz * ld ? Mg[e] : 0.0;
-    }
-    rv = 0.0;
-    if (tid < nz) {
-      rv = a.r[a.base_chain + a.chain_ptr[c] + tid];
-      if (has_left) rv -= a.leafG[ml.LG + ml.nz + tid];   // left leaf, R part
-      if (!m.last) rv -= a.leafG[m.LG + tid];               // right leaf, L part
-    }
-  };
-  ChainMeta lane_meta, cur{}, left{}, nxt{};
-  for (int64_t cb = c0; cb < c1; cb += 64) {
-    lane_meta = chain_meta_fetch(a, cb + tid, c1);
-    const int steps = (int)((c1 - cb) < 64 ? (c1 - cb) : 64);
-    if (cb == c0) {
-      cur = chain_meta_bcast(lane_meta, 0);
-      prefetch(cur, left, false, c0);
-    }
-    for (int s = 0; s < steps; ++s) {
-      const int64_t c = cb + s;
-      const int nz = cur.nz, nx = cur.nx, wc = nx + nb, ld = nz + wc;
-#pragma unroll
-      for (int q = 0; q < CH_PER; ++q) {
-        const int e = tid + 64 * q;
-        if (e < nz * ld) M[e] = pre[q];
-      }
-      if (tid < nz) rr[tid] = rv - (c > c0 ? gp[tid] : 0.0);   // previous node, next-node part
-      const int64_t pc = a.base_chain + a.chain_ptr[c];
-      if (c + 1 < c1) {
-        if (s + 1 < steps) nxt = chain_meta_bcast(lane_meta, s + 1);
-        else { const ChainMeta t = chain_meta_fetch(a, c + 1, c1); nxt = chain_meta_bcast(t, 0); }
-        prefetch(nxt, cur, true, c + 1);
-      }
-      wave_lds_sync();
-      double gk = 0.0;
-      if (tid < wc)
-        for (int i = 0; i < nz; ++i) gk += M[(size_t)i * ld + nz + tid] * rr[i];
-      wave_lds_sync();          // (gp is read above, by every lane, before it is overwritten)
-      if (tid < wc) {
-        a.chainG[cur.G + tid] = gk;
-        gp[tid] = gk;
-      }
-      block_solve<true>(M, nz, ld, rr);
-      if (tid < nz) a.r[pc + tid] = rr[tid];
-      wave_lds_sync();
-      left = cur;
-      cur = nxt;
-    }
-  }
-}
-
-__global__ void __launch_bounds__(64) kkt_chain_backward_w(KArgs a) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, nb = a.nb;
-  const int64_t c0 = a.chain_phase_ptr[blockIdx.x], c1 = a.chain_phase_ptr[blockIdx.x + 1];
-  double* xn = lds;                                  // [nzmax] the next node's solution
-  double* xb = xn + a.nzmax;                         // [nb] the border's
-  double* M = xb + nb;                               // [nzmax][wcmax] coupling part of the node's panel
-  for (int i = tid; i < nb; i += 64) xb[i] = a.r[a.base_border + i];
-  double pre[CH_PER], xv = 0.0;
-  auto prefetch = [&](const ChainMeta& m, int64_t c) {
-    const int nz = m.nz, wc = m.nx + nb, ld = nz + wc;
-    const double* Mg = a.vals + m.D;
-#pragma unroll
-    for (int q = 0; q < CH_PER; ++q) {
-      const int e = tid + 64 * q;
-      double v = 0.0;
-      if (e < nz * wc) {
-        const int i = e / wc, k = e - i * wc;
-        v = Mg[(size_t)i * ld + nz + k];
-      }
-      pre[q] = v;
-    }
-    xv = tid < nz ? a.r[a.base_chain + a.chain_ptr[c] + tid] : 0.0;
-  };
-  // walking down the chain: batches of 64 nodes ending at c, fetched by lanes in descending order
-  ChainMeta lane_meta, cur{}, nxt{};
-  for (int64_t ce = c1; ce > c0; ce -= 64) {
-    const int64_t cbeg = ce - 64 > c0 ? ce - 64 : c0;
-    const int steps = (int)(ce - cbeg);
-    lane_meta = chain_meta_fetch(a, cbeg + tid, ce);          // lane j: node cbeg + j
-    if (ce == c1) {
-      cur = chain_meta_bcast(lane_meta, steps - 1);
-      prefetch(cur, c1 - 1);
-    }
-    for (int s = steps - 1; s >= 0; --s) {
-      const int64_t c = cbeg + s;
-      const int nz = cur.nz, nx = cur.nx, wc = nx + nb;
-#pragma unroll
-      for (int q = 0; q < CH_PER; ++q) {
-        const int e = tid + 64 * q;
-        if (e < nz * wc) M[e] = pre[q];
-      }
-      const double x0 = xv;
-      const int64_t pc = a.base_chain + a.chain_ptr[c];
-      if (c > c0) {
-        if (s > 0) nxt = chain_meta_bcast(lane_meta, s - 1);
-        else { const ChainMeta t = chain_meta_fetch(a, c - 1, c1); nxt = chain_meta_bcast(t, 0); }
-        prefetch(nxt, c - 1);
-      }
-      wave_lds_sync();
-      double v = x0;
-      if (tid < nz) {
-        for (int k = 0; k < nx; ++k) v -= M[(size_t)tid * wc + k] * xn[k];
-        for (int k = 0; k < nb; ++k) v -= M[(size_t)tid * wc + nx + k] * xb[k];
-      }
-      wave_lds_sync();          // every lane has read xn before it is replaced
-      if (tid < nz) {
-        a.r[pc + tid] = v;
-        xn[tid] = v;
-      }
-      wave_lds_sync();
-      cur = nxt;
-    }
-  }
-}
-
 // ---- the chain by cyclic reduction -------------------------------------------------------------------------------------
 // The chain of a phase is block-tridiagonal with a border.  Walking it node by node is hundreds to thousands of
 // dependent steps of a few microseconds each (4 us per 3-unknown node even with everything in LDS and registers: the
@@ -943,7 +691,6 @@ struct pc_kkt {
   int n_leaf = 0, n_chain = 0, n_phase = 0, nb = 0;
   int lds_leaf = 0, lds_chain = 0, lds_border = 0;
   int lds_chain_factor = 0;
-  bool chain_wave = false;   // the chain kernels that run as one wave with everything a step reads prefetched
   bool chain_cr = false;     // the chain by cyclic reduction: one launch per level
   std::vector<int64_t> cr_lvl_ptr;   // nodes of level l: cr_nodes[cr_lvl_ptr[l-1] .. cr_lvl_ptr[l])
   int lds_cr = 0;
@@ -1053,9 +800,6 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       k->args.wcmax = (int32_t)wcmax;
       k->args.chain_lds = full <= 64000 ? 1 : 0;
       k->lds_chain_factor = (int)(k->args.chain_lds ? full : k->lds_chain);
-      // one-wave chain kernels: a node's panel is held by 64 lanes x CH_PER registers between steps
-      k->chain_wave = k->args.chain_lds && nzmax <= 64 && wcmax <= 64 && nzmax * (nzmax + wcmax) <= 64 * CH_PER;
-      if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CHAIN_WAVE")) k->chain_wave = k->chain_wave && std::atoi(env) != 0;
     }
     {   // cyclic reduction of the chain: levels, separators, buffer offsets
       const int64_t nc = d->n_chain;
@@ -1174,8 +918,7 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
         const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
         if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
       }
-    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_factor_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
-    else hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    } else hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     KHIP(hipMemcpyAsync(k->h_counts.data(), k->counts.p, k->h_counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1206,16 +949,14 @@ int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
         const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
         if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
       }
-    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_forward_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
-    else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+    } else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
     hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(256), k->lds_border, st, k->args);
     if (k->chain_cr) {
       for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
         const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
         if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
       }
-    } else if (k->chain_wave) hipLaunchKernelGGL(kkt_chain_backward_w, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
-    else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+    } else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
     if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
     hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, k->vout.p, k->nu);
     KHIP(hipGetLastError());
