@@ -47,6 +47,8 @@ class IpmResult:
     seconds: float
     evaluations: dict = field(default_factory=dict)
     history: list = field(default_factory=list)
+    zl: np.ndarray | None = None       # multipliers of the variables' lower / upper bounds (of the unscaled problem)
+    zu: np.ndarray | None = None
 
     @property
     def success(self) -> bool:
@@ -55,12 +57,14 @@ class IpmResult:
 
 class InteriorPointSolver:
     def __init__(self, problem_obj, n: int, m: int, lb, ub, cl, cu, tol: float = 1e-8, acceptable_tol: float = 1e-6,
-                 max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0, warm_start: bool = False):
+                 max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0, warm_start: bool = False,
+                 gradient_scaling: bool = True):
         self.p, self.n, self.m = problem_obj, int(n), int(m)
         # IPOPT's warm_start_init_point (the one thing pycollo's warm_start setting switches, backend.py:1703-1709):
         # the starting point is kept closer to where it was given -- bound push / fraction 1e-3 instead of 1e-2
         # (warm_start_bound_push, warm_start_bound_frac).  No multipliers are handed over: the reference passes none.
         self.warm_start = bool(warm_start)
+        self.gradient_scaling = bool(gradient_scaling)   # IPOPT's nlp_scaling_method: gradient-based (default) or none
         self.lb, self.ub = np.asarray(lb, float).copy(), np.asarray(ub, float).copy()
         self.cl, self.cu = np.asarray(cl, float).copy(), np.asarray(cu, float).copy()
         self.tol, self.acceptable_tol, self.max_iter, self.mu_init, self.verbose = tol, acceptable_tol, max_iter, mu_init, verbose
@@ -256,9 +260,9 @@ class InteriorPointSolver:
         x0c = np.clip(x0, np.where(self.lb > -INF, self.lb, x0), np.where(self.ub < INF, self.ub, x0))
         g0 = np.asarray(self.p.gradient(x0c), float)
         gmax = float(np.max(np.abs(g0))) if n else 0.0
-        if gmax > 100.0:
+        if gmax > 100.0 and self.gradient_scaling:
             self.sf = max(100.0 / gmax, 1e-8)
-        if m:
+        if m and self.gradient_scaling:
             jv = np.abs(np.asarray(self.p.jacobian(x0c), float))
             rowmax = np.zeros(m)
             np.maximum.at(rowmax, self.jr, jv)
@@ -428,7 +432,8 @@ class InteriorPointSolver:
         ev = dict(self.counts)
         ev["kkt_seconds"] = self.kkt_seconds
         return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
-                         inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist)
+                         inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist,
+                         zl=(zl[:n] / self.sf).copy(), zu=(zu[:n] / self.sf).copy())
 
 
 class GpuInteriorPointSolver(InteriorPointSolver):

@@ -101,3 +101,26 @@ def test_time_scaled_transfer_solution(built):
         res = solve_ocp(problems.time_scaled_transfer(), mesh_tolerance=1e-7, linear_solver=ls)
         np.testing.assert_allclose(res.objective, 2.0 * np.sqrt(12.0), rtol=1e-7)
         assert res.mesh_tolerance_met is True
+
+
+def test_reference_ipopt_hookup_lines_against_the_adapter(built):
+    """``initialise_nlp_backend`` of the reference (pycollo/nlp.py:84-115) line for line -- ``ipopt.problem(n, m,
+    problem_obj, lb, ub, cl, cu)``, ``addOption`` x 4, ``solve(x0)`` -- with ``pycollo_amd.ipopt_api`` standing where
+    ``import ipopt`` would and the GPU callbacks object as ``problem_obj``; the default brachistochrone mesh must come
+    out at the reference's known answer (tests/unit/test_iteration.py:305-318)."""
+    from pycollo_amd import ipopt_api as ipopt
+    from pycollo_amd.engine import PycolloGpuProblem
+    from pycollo_amd.iteration import MeshIteration
+    it = MeshIteration(problems.brachistochrone(), device=0)
+    nlp_problem = PycolloGpuProblem(it.engine)
+    nlp_backend = ipopt.problem(n=nlp_problem.n, m=nlp_problem.m, problem_obj=nlp_problem,
+                                lb=it.x_bnd_l, ub=it.x_bnd_u, cl=it.c_bnd_l, cu=it.c_bnd_u)
+    nlp_backend.addOption('mu_strategy', 'adaptive')
+    nlp_backend.addOption('tol', 1e-10)
+    nlp_backend.addOption('max_iter', 2000)
+    nlp_backend.addOption('print_level', 0)
+    x, info = nlp_backend.solve(it.guess_x_tilde)
+    assert info["status"] == 0, info["status_msg"]
+    np.testing.assert_allclose(info["obj_val"] / it.w, 0.8243386694458454, rtol=1e-8)
+    assert len(info["mult_g"]) == nlp_problem.m and len(info["mult_x_L"]) == nlp_problem.n
+    it.engine.close()

@@ -94,3 +94,34 @@ def test_bounds_and_fixed_variables():
     assert res.x[2] == 1.0                                  # fixed variable untouched
     np.testing.assert_allclose(res.x[:2], [0.5, 0.25], atol=1e-6)   # x0 at its upper bound
     np.testing.assert_allclose(res.objective, 0.25 + 4.0, atol=1e-6)
+
+
+def test_cyipopt_shaped_interface_with_user_scaling():
+    """The four calls the reference makes on ``ipopt.problem`` (pycollo/nlp.py:84-115) against the adapter: options,
+    user scaling, solve -> (x, info).  Scaling must not move the solution, and the multipliers it reports are those of
+    the unscaled problem (stationarity checked with the unscaled derivatives)."""
+    from pycollo_amd import ipopt_api as ipopt
+    p = HS071()
+    x0 = np.array([1.0, 5.0, 5.0, 1.0])
+    out = []
+    for scaled in (False, True):
+        nlp = ipopt.problem(n=4, m=2, problem_obj=p, lb=np.ones(4), ub=5 * np.ones(4), cl=np.array([25.0, 40.0]), cu=np.array([2e19, 40.0]))
+        nlp.addOption('mu_strategy', 'adaptive')
+        nlp.addOption('tol', 1e-9)
+        nlp.addOption('max_iter', 500)
+        nlp.addOption('print_level', 0)
+        if scaled:
+            nlp.addOption('nlp_scaling_method', 'user-scaling')
+            nlp.setProblemScaling(0.05, np.array([2.0, 0.5, 1.0, 4.0]), np.array([0.1, 3.0]))
+        x, info = nlp.solve(x0)
+        assert info["status"] == 0, info["status_msg"]
+        np.testing.assert_allclose(info["obj_val"], 17.0140173, rtol=1e-7)
+        np.testing.assert_allclose(x, [1.0, 4.74299963, 3.82114998, 1.37940829], rtol=1e-6)
+        np.testing.assert_allclose(info["g"], p.constraints(x))
+        jr, jc = p.jacobianstructure()
+        J = np.zeros((2, 4)); J[jr, jc] = p.jacobian(x)
+        stat = p.gradient(x) + J.T @ info["mult_g"] - info["mult_x_L"] + info["mult_x_U"]
+        assert np.max(np.abs(stat)) < 1e-6
+        out.append(info)
+    np.testing.assert_allclose(out[0]["mult_g"], out[1]["mult_g"], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(out[0]["mult_x_L"], out[1]["mult_x_L"], rtol=1e-4, atol=1e-7)
