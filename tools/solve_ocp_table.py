@@ -1,0 +1,27 @@
+"""End-to-end solve() of the reference's integration-test problems on the GPU path, KKT systems on the GPU and on the
+host: wall time, mesh iterations, final mesh size, objective.  One JSON line per (problem, linear solver).
+
+    python tools/solve_ocp_table.py [problem ...]        (GPU box)
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pycollo_amd import problems  # noqa: E402
+from pycollo_amd.solve import solve_ocp  # noqa: E402
+
+CASES = {"brachistochrone": {}, "hypersensitive": {}, "shuttle": {}, "tumour_anti_angiogenesis": {},
+         "free_flying_robot": dict(mesh_tolerance=1e-5, max_mesh_iterations=15), "space_station": {},
+         "time_scaled_transfer": dict(mesh_tolerance=1e-7)}
+names = sys.argv[1:] or list(CASES)
+for name in names:
+    for ls in ("gpu", "host"):
+        t0 = time.perf_counter()
+        res = solve_ocp(problems.REGISTRY[name](), linear_solver=ls, **CASES.get(name, {}))
+        wall = time.perf_counter() - t0
+        print(json.dumps({"problem": name, "linear_solver": ls, "objective": float(res.objective), "mesh_iterations": int(res.mesh_iterations),
+                          "mesh_tolerance_met": bool(res.mesh_tolerance_met), "wall_s": round(wall, 3),
+                          "final_nodes": res.iterations[-1].get("N") if res.iterations else None,
+                          "nlp_iterations_total": int(sum(int(i.get("nlp_iterations", 0)) for i in res.iterations))}), flush=True)
