@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 CASES = [("hypersensitive", dict(K=2000, order=6)), ("double_pendulum", {}), ("two_phase_transfer", {}),
          ("hypersensitive", dict(K=7, order=2)), ("sliding_mass", dict(num_phases=3, K=4, order=4)),
          ("free_flying_robot", dict(K=33, order=5)), ("shuttle", dict(K=60, order=4)), ("cart_pole", dict(K=500, order=4)),
-         ("time_coupled_transfer", dict(K=9, order=4))]
+         ("time_coupled_transfer", dict(K=9, order=4)),
+         ("hypersensitive", dict(K=1, order=4)), ("hypersensitive", dict(K=2, order=3)), ("two_phase_transfer", dict(K=1, order=3))]
 
 
 @pytest.mark.parametrize("name,kw", CASES)

@@ -53,7 +53,8 @@ def reference_matrix(eng, G, H, ineq, fixed, sc, dvec):
 
 CASES = [("hypersensitive", dict(K=30, order=6)), ("double_pendulum", {}), ("two_phase_transfer", {}),
          ("hypersensitive", dict(K=7, order=2)), ("brachistochrone", {}), ("sliding_mass", dict(num_phases=3, K=4, order=4)),
-         ("free_flying_robot", dict(K=5, order=5)), ("shuttle", dict(K=6, order=4)), ("time_coupled_transfer", dict(K=9, order=4))]
+         ("free_flying_robot", dict(K=5, order=5)), ("shuttle", dict(K=6, order=4)), ("time_coupled_transfer", dict(K=9, order=4)),
+         ("hypersensitive", dict(K=1, order=4)), ("hypersensitive", dict(K=2, order=3)), ("two_phase_transfer", dict(K=1, order=3))]
 
 
 @pytest.mark.parametrize("group", [1, 3, None])
