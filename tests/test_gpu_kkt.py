@@ -51,6 +51,29 @@ def test_factor_and_solve_match_superlu(built, name, kw):
     eng.close()
 
 
+@pytest.mark.parametrize("name,kw", [("hypersensitive", dict(K=300, order=6)), ("two_phase_transfer", {}), ("shuttle", dict(K=60, order=4))])
+def test_cyclic_reduction_and_sequential_chain_agree(built, monkeypatch, name, kw):
+    """The chain eliminated level by level (default) and node by node (PYCOLLO_AMD_KKT_CR=0, the fallback for blocks
+    too large for the level kernels' LDS): same inertia, same solution to rounding."""
+    from pycollo_amd.kkt import GpuKkt
+    eng, ora, x, lam, ineq, fixed, sc, dvec = kkt_case(name, kw, device=0)
+    eng.evaluate_resident(x, 1.0, lam)
+    rhs = np.random.default_rng(2).normal(size=eng.num_x + len(ineq) + eng.num_c)
+    rhs[np.nonzero(fixed)[0]] = 0.0
+    out = []
+    for cr in ("1", "0"):
+        monkeypatch.setenv("PYCOLLO_AMD_KKT_CR", cr)
+        k = GpuKkt(eng, ineq, fixed, sc)
+        inertia = k.factor(dvec)
+        xs = k.solve(rhs)
+        xs = xs + k.solve(rhs - k.matvec(dvec, xs))
+        out.append((inertia, xs))
+        k.close()
+    assert out[0][0] == out[1][0]
+    assert np.max(np.abs(out[0][1] - out[1][1])) <= 1e-9 * np.max(np.abs(out[1][1]))
+    eng.close()
+
+
 @pytest.mark.parametrize("name,kw", [("brachistochrone", {}), ("hypersensitive", dict(K=40, order=5)),
                                      ("free_flying_robot", dict(K=10, order=5))])
 def test_gpu_linear_algebra_reproduces_the_host_solve(built, name, kw):
