@@ -149,8 +149,7 @@ class MeshIteration:
         # an 18-iteration solve, more than all factorisations together).  Collection is off for the duration.
         import gc
         was_enabled = gc.isenabled()
-        gc.collect()
-        gc.freeze()
+        gc.freeze()       # (no collection first: walking those graphs is a quarter of a second, twice the solve at config 2)
         gc.disable()      # (what the solve allocates is arrays: reference counting frees them)
         # The other source of ~80-100 ms stalls anywhere in the process: numpy's BLAS starts one spinning thread per
         # hardware thread (256 on the MI355X host) for a dot product of 30 k doubles; inside a CPU-quota cgroup they
