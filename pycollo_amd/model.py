@@ -106,8 +106,11 @@ class PhaseModel:
     def eval_ops(self) -> int:
         """Arithmetic operations in the node functions and their derivatives (before common-subexpression
         elimination): a size measure of the model, used as a launch-shape hint only."""
-        exprs = list(self.f) + list(self.p) + list(self.g) + [e for _, _, e in self.jac] + [e for _, _, e in self.hess]
-        return int(sum(int(sym.count_ops(e)) for e in exprs))
+        cached = self.__dict__.get("_eval_ops")
+        if cached is None:
+            exprs = list(self.f) + list(self.p) + list(self.g) + [e for _, _, e in self.jac] + [e for _, _, e in self.hess]
+            cached = self.__dict__["_eval_ops"] = int(sum(int(sym.count_ops(e)) for e in exprs))
+        return cached
 
     @property
     def n_z(self) -> int:
@@ -246,11 +249,49 @@ def _nz(e: sym.Expr) -> bool:
     return e != 0
 
 
+_MODEL_CACHE: dict = {}    # per process: everything below depends on the equations and bounds, never on the mesh
+
+
+def _problem_key(prob: _pb.ProblemSpec):
+    """What ``compile_model`` reads of a problem, cheaply: structural hashes of the expressions (SymPy caches them per
+    object) and the text of the bounds.  A mesh iteration re-creates the engine for the same equations on a new mesh;
+    differentiating, hashing and counting a heavy model again each time was most of its host time (space station:
+    4 s of symbolic work per mesh iteration, twice, for a 0.2 s NLP solve)."""
+    def ex(seq):
+        return tuple(hash(sym.sympify(e)) for e in (seq or ()))
+
+    def aux(d):
+        return tuple(sorted((str(k), hash(sym.sympify(v))) for k, v in (d or {}).items()))
+
+    def bnd(b):
+        return tuple((k, repr(v)) for k, v in sorted(vars(b).items()))
+
+    key = [prob.name, prob.scaling_method, prob.quadrature_method, ex(prob.parameter_variables), aux(prob.auxiliary_data),
+           hash(sym.sympify(prob.objective_function)), ex(prob.endpoint_constraints), bnd(prob.bounds)]
+    for ph in prob.phases:
+        key += [ph.name, ph.i, ex(ph.state_variables), ex(ph.control_variables), ex(ph.state_equations), ex(ph.path_constraints),
+                ex(ph.integrand_functions), aux(ph.auxiliary_data), bnd(ph.bounds)]
+    return tuple(key)
+
+
 def compile_model(prob: _pb.ProblemSpec) -> Model:
     if not prob.phases:
         raise ValueError("a problem needs at least one phase")
     if prob.objective_function is None:
         raise ValueError("objective_function is required")
+    try:
+        key = _problem_key(prob)
+    except Exception:           # an unhashable oddity in a user's problem: compile without the cache
+        key = None
+    if key is not None and key in _MODEL_CACHE:
+        return _MODEL_CACHE[key]
+    model = _compile_model(prob)
+    if key is not None:
+        _MODEL_CACHE[key] = model
+    return model
+
+
+def _compile_model(prob: _pb.ProblemSpec) -> Model:
 
     # ---- static parameters --------------------------------------------------------------------
     s_user = list(prob.parameter_variables)
