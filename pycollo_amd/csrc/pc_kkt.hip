@@ -49,6 +49,24 @@ struct Dev {
   }
 };
 
+// pinned host staging: the vectors of a call cross the bus from / to page-locked memory (a pageable hipMemcpyAsync is
+// staged by the runtime through its own bounce buffer, synchronously: ~0.1 ms per 240 KB vector at config 2, more than
+// the solve's kernels)
+template <class T>
+struct Pin {
+  T* p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = count;
+    if (count) KHIP(hipHostMalloc(&p, count * sizeof(T), hipHostMallocDefault));
+  }
+  ~Pin() {
+    if (p) (void)hipHostFree(p);
+  }
+};
+
 enum { SRC_G = 0, SRC_H = 1, SRC_ONE = 2 };
 
 // ---- assembly -------------------------------------------------------------------------------------------------
@@ -703,7 +721,8 @@ struct pc_kkt {
   Dev<int32_t> src_kind, src_idx, mv_col, mv_kind, mv_idx;
   Dev<uint8_t> fixed, chain_last;
   Dev<int> counts;
-  std::vector<int> h_counts;
+  Pin<int> h_counts;
+  Pin<double> h_a, h_b;      // two vectors in, or one in and one out
   KArgs args{};
   bool factored = false;
 };
@@ -856,7 +875,9 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     k->vin.alloc((size_t)d->nu);
     k->vout.alloc((size_t)d->nu);
     k->counts.alloc((size_t)2 * (d->n_leaf + d->n_chain + 1));
-    k->h_counts.resize((size_t)2 * (d->n_leaf + d->n_chain + 1));
+    k->h_counts.alloc((size_t)2 * (d->n_leaf + d->n_chain + 1));
+    k->h_a.alloc((size_t)d->nu);
+    k->h_b.alloc((size_t)d->nu);
     KArgs& a = k->args;
     a.vals = k->vals.p;
     a.leaf_ptr = k->leaf_ptr.p; a.chain_ptr = k->chain_ptr.p; a.chain_phase_ptr = k->chain_phase_ptr.p;
@@ -901,7 +922,8 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
     if (!k || !dvec) throw std::runtime_error("null argument");
     KHIP(hipSetDevice(k->device));
     hipStream_t st = k->stream;
-    KHIP(hipMemcpyAsync(k->dvec.p, dvec, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     KHIP(hipMemsetAsync(k->vals.p, 0, (size_t)k->total * sizeof(double), st));
     if (k->n_dst)
       hipLaunchKernelGGL(kkt_scatter, dim3((unsigned)((k->n_dst + 255) / 256)), dim3(256), 0, st, k->vals.p, k->dst.p, k->run_ptr.p,
@@ -921,12 +943,12 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
     } else hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
-    KHIP(hipMemcpyAsync(k->h_counts.data(), k->counts.p, k->h_counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    KHIP(hipMemcpyAsync(k->h_counts.p, k->counts.p, k->h_counts.n * sizeof(int), hipMemcpyDeviceToHost, st));
     KHIP(hipStreamSynchronize(st));
     int64_t p = 0, q = 0;
-    for (size_t i = 0; i < k->h_counts.size(); i += 2) {
-      p += k->h_counts[i];
-      q += k->h_counts[i + 1];
+    for (size_t i = 0; i < k->h_counts.n; i += 2) {
+      p += k->h_counts.p[i];
+      q += k->h_counts.p[i + 1];
     }
     if (n_pos) *n_pos = (int32_t)p;
     if (n_neg) *n_neg = (int32_t)q;
@@ -941,7 +963,8 @@ int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
     KHIP(hipSetDevice(k->device));
     hipStream_t st = k->stream;
     const unsigned nbk = (unsigned)((k->nu + 255) / 256);
-    KHIP(hipMemcpyAsync(k->vin.p, rhs, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    std::memcpy(k->h_a.p, rhs, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->vin.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, k->vin.p, k->perm.p, k->fixed.p, k->r.p, k->nu);
     if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
     if (k->chain_cr) {
@@ -960,8 +983,9 @@ int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
     if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
     hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, k->vout.p, k->nu);
     KHIP(hipGetLastError());
-    KHIP(hipMemcpyAsync(x, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipMemcpyAsync(k->h_b.p, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
     KHIP(hipStreamSynchronize(st));
+    std::memcpy(x, k->h_b.p, k->nu * sizeof(double));
   });
 }
 
@@ -970,14 +994,17 @@ int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, 
     if (!k || !dvec || !x || !y) throw std::runtime_error("null argument");
     KHIP(hipSetDevice(k->device));
     hipStream_t st = k->stream;
-    KHIP(hipMemcpyAsync(k->dvec.p, dvec, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
-    KHIP(hipMemcpyAsync(k->vin.p, x, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
+    std::memcpy(k->h_b.p, x, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(k->vin.p, k->h_b.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     const int64_t threads = k->nu * 64;
     hipLaunchKernelGGL(kkt_matvec, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k->mv_ptr.p, k->mv_col.p, k->mv_kind.p,
                        k->mv_idx.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, k->dvec.p, k->vin.p, k->vout.p, k->nu);
     KHIP(hipGetLastError());
-    KHIP(hipMemcpyAsync(y, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipMemcpyAsync(k->h_a.p, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));   // (queued behind the kernel that read dvec)
     KHIP(hipStreamSynchronize(st));
+    std::memcpy(y, k->h_a.p, k->nu * sizeof(double));
   });
 }
 
