@@ -257,13 +257,18 @@ class InteriorPointSolver:
         # on, pycollo/backend.py:1704-1710): objective and every constraint row are scaled down so that no
         # gradient entry exceeds nlp_scaling_max_gradient = 100
         self.sf, self.sc = 1.0, np.ones(m)
-        x0c = np.clip(x0, np.where(self.lb > -INF, self.lb, x0), np.where(self.ub < INF, self.ub, x0))
-        g0 = np.asarray(self.p.gradient(x0c), float)
+        # (evaluated at the starting point as the algorithm will use it, i.e. pushed off its bounds: a guess that sits
+        #  exactly where a model is not differentiable -- Delta III on the pad, zero air speed under a square root --
+        #  gives NaN partials at the raw guess; entries that are not finite anyway take no part in the maxima)
+        push = (1e-3, 1e-3) if self.warm_start else (1e-2, 1e-2)
+        x0c = self._push_interior(np.concatenate([x0, np.zeros(self.ns)]), *push)[:n]
+        x0c[self.fixed[:n]] = self.vl[:n][self.fixed[:n]]
+        g0 = np.nan_to_num(np.asarray(self.p.gradient(x0c), float), nan=0.0, posinf=0.0, neginf=0.0)
         gmax = float(np.max(np.abs(g0))) if n else 0.0
         if gmax > 100.0 and self.gradient_scaling:
             self.sf = max(100.0 / gmax, 1e-8)
         if m and self.gradient_scaling:
-            jv = np.abs(np.asarray(self.p.jacobian(x0c), float))
+            jv = np.abs(np.nan_to_num(np.asarray(self.p.jacobian(x0c), float), nan=0.0, posinf=0.0, neginf=0.0))
             rowmax = np.zeros(m)
             np.maximum.at(rowmax, self.jr, jv)
             big = rowmax > 100.0
