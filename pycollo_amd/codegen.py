@@ -105,6 +105,15 @@ def _emit_block(inputs: dict, outputs: list[tuple[str, sym.Expr]], tmp: str) -> 
     return lines
 
 
+STATIC_W_MAX_OPS = 4000    # models up to this many operations get per-replica kernels (pc_engine's "heavy" threshold)
+
+
+def _static_w_list(pm: PhaseModel) -> list[int]:
+    if os.environ.get("PYCOLLO_AMD_STATIC_W", "1") == "0" or pm.eval_ops > STATIC_W_MAX_OPS:
+        return []
+    return [2, 4]
+
+
 def _constexpr_table(name: str, values: list[int]) -> str:
     if not values:
         return f"  static constexpr int {name}(int) {{ return 0; }}"
@@ -321,20 +330,27 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append('  const int ntb = (wa >> 28) & 7;   // leading workgroups that run the tail')
         parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append('#ifdef PC_STATIC_W   // one instantiation per replica: what a replica does not own is dead code in its copy')
-        parts.append('  if (((wa >> 8) & 0xf) != PC_STATIC_W) return;   // (built for exactly that many waves per tile)')
-        parts.append('  const int blk = pc::xcd_major((int)blockIdx.x - ntb, n_blocks);')
-        parts.append('  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {')
-        for wv in range(4):
-            parts.append(f'#if PC_STATIC_W > {wv}')
-            parts.append(f'    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true, PC_STATIC_W, {wv}>(a, false, 0, blk, &ld); return;')
-            parts.append('#endif')
-        parts.append('    default: return;')
-        parts.append('  }')
-        parts.append('#else')
         parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - ntb, n_blocks), &ld);')
-        parts.append('#endif')
         parts.append('}')
+        # The same launch with the replica index as a template argument, one kernel per waves-per-tile count: a
+        # replica's copy of the tile body then holds only the items dealt to it (everything else is dead code in that
+        # copy) -- 6-8 % on every workload that shares tiles (config 2, W = 4: 4.45-4.7 -> 4.14-4.32 us).  pc_create
+        # picks pc_bulk_p0_r_w<W> when the code object has it.  Light and medium models only: a heavy model's tile
+        # body takes long to compile once, and such models rarely share tiles.
+        static_ws = _static_w_list(pm)
+        for wn in static_ws:
+            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
+            parts.append('  const int ntb = (wa >> 28) & 7;')
+            parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
+            parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+            parts.append(f'  if (((wa >> 8) & 0xf) != {wn}) return;   // (built for exactly that many waves per tile; the host checks too)')
+            parts.append('  const int blk = pc::xcd_major((int)blockIdx.x - ntb, n_blocks);')
+            parts.append('  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {')
+            for wv in range(wn):
+                parts.append(f'    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true, {wn}, {wv}>(a, false, 0, blk, &ld); return;')
+            parts.append('    default: return;')
+            parts.append('  }')
+            parts.append('}')
     else:
         np_ = len(model.phases)
 
@@ -430,6 +446,8 @@ def _kernels_stamp() -> str:
     for fn in ("pc_kernels.hpp", "pc_args.h"):
         with open(os.path.join(CSRC, fn), "rb") as f:
             h.update(f.read())
+    with open(os.path.abspath(__file__), "rb") as f:   # the generator itself: printer rules, kernel entry points
+        h.update(f.read())
     h.update(b"flags:-O3 -ffp-contract=off")
     return h.hexdigest()[:12]
 

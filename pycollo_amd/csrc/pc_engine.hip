@@ -876,6 +876,13 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
       if (Q.ph.size() == 1 && hipModuleGetFunction(&D.fn_res, h->module, (P.bulk_kernel + "_r").c_str()) != hipSuccess)
         D.fn_res = nullptr;   // code object without the resident-tail variant: two launches per evaluation
+      if (D.fn_res && D.wpt > 1) {   // the same kernel with the replica index compiled in (codegen: light / medium models)
+        hipFunction_t fw = nullptr;
+        if (hipModuleGetFunction(&fw, h->module, (P.bulk_kernel + "_r_w" + std::to_string(D.wpt)).c_str()) == hipSuccess && fw)
+          D.fn_res = fw;
+        else
+          (void)hipGetLastError();
+      }
       D.tile_k0.upload(P.tile_k0);
       {
         std::vector<int32_t> tn(P.tile_k0.size());

@@ -77,7 +77,10 @@ def test_generated_source_is_straight_line_fp64():
     src = codegen.generate_source(compile_model(problems.shuttle()))
     assert "pow(" not in src            # integer powers expanded to multiplications
     assert "float " not in src
-    assert src.count("__global__") == 5      # bulk, bulk with the tail folded in, mesh error, tail, tail for many tiles
+    # bulk, bulk with the resident tail (replica index at run time, and compiled in for 2 and 4 waves per tile),
+    # mesh error, tail, tail for many tiles
+    assert src.count("__global__") == 7
+    assert "pc_bulk_p0_r_w2(" in src and "pc_bulk_p0_r_w4(" in src
 
 
 @pytest.mark.parametrize("name,kw,orders", [("hypersensitive", dict(K=10, order=6), (6,)), ("cart_pole", dict(K=10, order=4), (4,)),
