@@ -314,6 +314,11 @@ def main():
         # and its launch time is the device time per step; the tile-only kernel is reported beside it.
         one_launch = world == 1 and extra.get("launches_per_eval") == 1
         kname = ("pc_bulk_all" if len(prob.phases) > 1 else "pc_bulk_p0") + ("_r" if one_launch else "")
+        if one_launch and len(prob.phases) == 1:   # the per-replica variant pc_create picks when tiles are shared
+            from pycollo_amd import codegen as _cg
+            wpt = int(extra.get("waves_per_tile", 1))
+            if wpt > 1 and wpt in _cg._static_w_list(eng.model.phases[0]):
+                kname += f"_w{wpt}"
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process); only quoted when the workload is the one those passes profiled
         traffic = None
