@@ -778,7 +778,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.spt = same ? (TC - 1) / (P.n_k[0] - 1) : 0;
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
-      D.lds_out = phase_lds_out(P, TB);
+      D.lds_out = phase_lds_out(P, TC);   // runs of a tile: at most TC - 1 defect rows, TC nodes
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
       // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle

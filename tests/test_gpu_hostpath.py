@@ -4,7 +4,7 @@ blocks, the zero-copy hand-over and the three data-movement modes.  Reference su
 import numpy as np
 import pytest
 
-from conftest import rel_err, golden_tables
+from conftest import assert_matches_oracle, golden_tables, vec_err
 from oracle.ref_numpy import OracleNlp
 from pycollo_amd import problems
 from pycollo_amd.quadrature import QuadratureTables
@@ -29,24 +29,20 @@ def test_new_x_protocol(built, name, kw):
     x0, x1, x2, x3 = (rng.uniform(-0.4, 0.4, eng.num_x) for _ in range(4))
     lam = rng.normal(size=eng.num_c)
     c0 = eng.evaluate_c(x0)                        # caches c~, G~ at x0
-    assert rel_err(c0, ora.c(x0)) < TOL
+    assert_matches_oracle(ora, x0, c=c0)
     J1 = eng.evaluate_J(x1, new_x=True)            # new point announced to eval_f
     assert abs(J1 - ora.J(x1)) <= TOL * max(1.0, abs(J1))
-    assert rel_err(eng.evaluate_c(x1, new_x=False), ora.c(x1)) < TOL
-    assert rel_err(eng.evaluate_G_nonzeros(x1, new_x=False), ora.G(x1)) < TOL
-    assert rel_err(eng.evaluate_g(x1, new_x=False), ora.grad_J(x1)) < TOL
+    assert_matches_oracle(ora, x1, c=eng.evaluate_c(x1, new_x=False), G=eng.evaluate_G_nonzeros(x1, new_x=False),
+                          g=eng.evaluate_g(x1, new_x=False))
     g2 = eng.evaluate_g(x2, new_x=True)            # ... to eval_grad_f
-    assert rel_err(g2, ora.grad_J(x2)) < TOL
-    assert rel_err(eng.evaluate_G_nonzeros(x2, new_x=False), ora.G(x2)) < TOL
-    assert rel_err(eng.evaluate_c(x2, new_x=False), ora.c(x2)) < TOL
+    assert_matches_oracle(ora, x2, g=g2, G=eng.evaluate_G_nonzeros(x2, new_x=False), c=eng.evaluate_c(x2, new_x=False))
     H3 = eng.evaluate_H_nonzeros(x3, 0.7, lam, new_x=True)   # ... to eval_h
-    assert rel_err(H3, ora.H(x3, 0.7, lam)) < TOL
-    assert rel_err(eng.evaluate_c(x3, new_x=False), ora.c(x3)) < TOL
+    assert_matches_oracle(ora, x3, H=H3, sigma=0.7, lam=lam, c=eng.evaluate_c(x3, new_x=False))
     assert abs(eng.evaluate_J(x3, new_x=False) - ora.J(x3)) <= TOL * max(1.0, abs(ora.J(x3)))
     # a change of scaling invalidates the cache even if the caller says the point is old
     W = eng.W_ocp * 2.0
     eng.set_scaling(eng.V_ocp, eng.r_ocp, W, 1.0)
-    assert rel_err(eng.evaluate_c(x3, new_x=False), 2.0 * ora.c(x3)) < TOL
+    assert_matches_oracle(ora, x3, c=eng.evaluate_c(x3, new_x=False), c_scale=2.0)
     eng.close()
 
 
@@ -62,10 +58,8 @@ def test_cyipopt_object_recovers_new_x(built):
     for _ in range(3):
         x = rng.uniform(-0.4, 0.4, eng.num_x)
         assert abs(p.objective(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
-        assert rel_err(p.gradient(x), ora.grad_J(x)) < TOL
-        assert rel_err(p.constraints(x), ora.c(x)) < TOL
-        assert rel_err(p.jacobian(x), ora.G(x)) < TOL
-        assert rel_err(p.hessian(x, lam, 0.5), ora.H(x, 0.5, lam)) < TOL
+        assert_matches_oracle(ora, x, g=p.gradient(x), c=p.constraints(x), G=p.jacobian(x), H=p.hessian(x, lam, 0.5),
+                              sigma=0.5, lam=lam)
     eng.close()
 
 
@@ -104,7 +98,11 @@ def test_host_modes_and_inplace_views_write_the_same_bits(built, name, kw):
         np.testing.assert_array_equal(eng.evaluate_G_nonzeros(x, new_x=False), ref[1])
         np.testing.assert_array_equal(eng.evaluate_H_nonzeros(x, 0.8, lam, new_x=False), ref[2])
     eng.set_host_mode(0)
-    assert rel_err(eng.G_row_norms(x), np.sqrt(np.add.reduceat(ref[1] ** 2, _indptr(eng)[:-1]))) < 1e-13
+    # row by row; at Delta III's random point some entries exceed 1e154 and their squares overflow on both sides: the
+    # row norm is then +inf on the device and here alike (vec_err requires the same non-finite value)
+    with np.errstate(over="ignore"):
+        ref_norms = np.sqrt(np.add.reduceat(ref[1] ** 2, _indptr(eng)[:-1]))
+    assert vec_err(eng.G_row_norms(x), ref_norms, rtol=1e-13) <= 1.0
     eng.close()
 
 
