@@ -92,6 +92,12 @@ typedef struct {
   const char* tail_kernel;
   int32_t device;                  /* HIP device ordinal; -1 = structure only, no evaluation possible */
   int32_t threads_per_block;       /* 0 = choose from the mesh size; else 64, 128 or 256 */
+  int32_t two_wave_occupancy;      /* waves per SIMD the compiler reported for the code object's two-wave launch kernel
+                                      (pc_bulk_all_r_w2 / pc_bulk_p<i>_r_w2 of a model with a heavy phase; codegen's
+                                      resource sidecar); 0 = none.  >= 2: pc_create shares every 64-node tile between
+                                      two waves and sizes the tiles so that a CU holds eight of them.  A launch-shape
+                                      hint only: results do not depend on it beyond summation order of the integrals */
+  int32_t reserved;
 } pc_problem_desc;
 
 typedef struct {
@@ -179,9 +185,19 @@ int pc_set_host_mode(pc_handle* h, int mode);
  * GPU, pc_kkt_*, never asks) */
 int pc_set_prefetch_jac(pc_handle* h, int on);
 /* same with every vector resident in device memory; asynchronous on `stream` (hipStream_t, NULL =
- * the handle's stream).  No host synchronisation is performed. */
+ * the handle's stream).  No host synchronisation is performed.
+ * AT MOST ONE evaluation per handle may be in flight: a handle owns one set of hand-over buffers (per-tile partial
+ * sums, edge-node records) tagged with one launch counter, so evaluations of one handle must be queued on ONE stream
+ * (or ordered by events); two streams running them concurrently overwrite each other's hand-over values and the
+ * earlier evaluation's tail gives up after its bounded wait.  Use one handle per concurrent stream (IPOPT is serial:
+ * pycollo/nlp.py:84-115 has one problem object per solve).  A tail that gave up is reported by the next
+ * pc_eval_all_device, by pc_synchronize and by pc_check. */
 int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda,
                        double* d_g, double* d_jac, double* d_hess, void* stream);
+/* After the CALLER has synchronised its own stream: 1 if every evaluation queued so far completed, 0 (and
+ * pc_last_error) if a resident tail gave up waiting for values of the same launch -- the results of that evaluation
+ * are invalid.  (pc_synchronize does the same for the handle's own stream.)  No reference counterpart. */
+int pc_check(pc_handle* h);
 /* profiling aid: launches only the per-phase bulk kernels of pc_eval_all_device (no tail kernel),
  * so that bench.py can time the dominant kernel between two HIP events */
 int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,

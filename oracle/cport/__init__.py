@@ -268,19 +268,63 @@ def build_all():
     return cp.lib._name
 
 
-def time_hypersensitive(K: int, order: int, budget_s: float = 15.0) -> dict:
-    """Time cp_eval_all (direct CSR writes, preallocated workspace, OpenMP over nodes and sections) on the bench
-    workload with 1 thread, 16 threads (one GPU's share of the GPU box's host) and every host core."""
+def host_cpu_facts() -> dict:
+    """What the timing ran on: CPU model, hardware threads visible to the process, and the CPU-time quota of the
+    container (cgroup v2 ``cpu.max`` / v1 ``cpu.cfs_quota_us``) -- with a quota of q CPUs, q spinning threads are all
+    the process can run, whatever ``nproc`` says."""
+    facts = {"model": None, "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
+             "cgroup_cpu_max": None, "quota_cpus": None}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    facts["model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.max"):
+        try:
+            with open(path) as f:
+                txt = f.read().strip()
+            facts["cgroup_cpu_max"] = txt
+            q, per = txt.split()[:2]
+            if q != "max":
+                facts["quota_cpus"] = round(float(q) / float(per), 2)
+            break
+        except (OSError, ValueError):
+            continue
+    if facts["cgroup_cpu_max"] is None:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            facts["cgroup_cpu_max"] = f"{q} {per}"
+            if q > 0:
+                facts["quota_cpus"] = round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    return facts
+
+
+def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
+    """Time cp_eval_all (direct CSR writes, preallocated workspace, one OpenMP region per evaluation with static
+    section ranges) on the bench workload over a thread sweep 1, 2, 4, ... up to the host's CPUs (SURVEY 8d timing
+    protocol, items 1-2).  ``value`` is the single-thread figure (``cores`` = 1); ``best_value`` / ``best_threads`` the
+    best of the sweep; the host facts (CPU model, cgroup quota) say what the sweep could use."""
     from pycollo_amd import problems
     from pycollo_amd.quadrature import QuadratureTables
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    facts = host_cpu_facts()
+    ncpu = facts["affinity_cpus"]
     os.environ["OMP_NUM_THREADS"] = str(ncpu)    # read when libgomp starts: the ceiling for cp_set_threads
     os.environ.setdefault("OMP_PROC_BIND", "close")
+    # passive waiting: inside a CPU-quota cgroup, threads spinning at the barriers burn the quota the working threads need
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive" if facts["quota_cpus"] and facts["quota_cpus"] < ncpu else "active")
     cp = CPort(problems.hypersensitive(K=K, order=order), QuadratureTables("lobatto"))
     x = np.random.default_rng(1234).uniform(-0.45, 0.45, cp.num_x)
     lam = np.random.default_rng(1235).normal(size=cp.num_c)
     out = {}
-    counts = sorted({1, min(16, ncpu), ncpu})
+    counts = sorted({t for t in (1, 2, 4, 8, 16, 32, 64) if t <= ncpu})
     for thr in counts:
         cp.set_threads(thr)
         for _ in range(20):
@@ -299,6 +343,9 @@ def time_hypersensitive(K: int, order: int, budget_s: float = 15.0) -> dict:
     return {"value": round(one[0], 2), "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"{one[1]} fused c+G+H evaluations of the same {K}x{order} hypersensitive NLP in {one[2]:.1f} s; oracle C "
                       f"port (gcc -O3 -march=native -fopenmp), values written straight into the CSR arrays, no "
-                      f"allocation per call",
-            "by_threads": {str(t): {"value": round(v[0], 2), "evals": v[1], "seconds": round(v[2], 2)} for t, v in out.items()},
-            "host_cpus": ncpu, "best_value": round(out[best_thr][0], 2), "best_threads": best_thr}
+                      f"allocation per call, one parallel region per evaluation (static section ranges)",
+            "by_threads": {str(t): {"value": round(v[0], 2), "evals": v[1], "seconds": round(v[2], 2),
+                                    "speedup_over_1": round(v[0] / one[0], 2)} for t, v in out.items()},
+            "host_cpus": ncpu, "cpu_model": facts["model"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
+            "quota_cpus": facts["quota_cpus"], "omp_wait_policy": os.environ.get("OMP_WAIT_POLICY"),
+            "best_value": round(out[best_thr][0], 2), "best_threads": best_thr}

@@ -108,10 +108,19 @@ def _emit_block(inputs: dict, outputs: list[tuple[str, sym.Expr]], tmp: str) -> 
 STATIC_W_MAX_OPS = 4000    # models up to this many operations get per-replica kernels (pc_engine's "heavy" threshold)
 
 
+def is_heavy(pm: PhaseModel) -> bool:
+    """Models past this size run in the two-wave build (pc::bulk SPLIT rule, pc_create's tile choice)."""
+    return pm.eval_ops > STATIC_W_MAX_OPS
+
+
 def _static_w_list(pm: PhaseModel) -> list[int]:
-    if os.environ.get("PYCOLLO_AMD_STATIC_W", "1") == "0" or pm.eval_ops > STATIC_W_MAX_OPS:
+    """Waves-per-tile counts that get a kernel with the replica index compiled in.  Light and medium models: 2 and 4
+    (6-8 % over the run-time replica index).  Heavy models: 2 only -- the *two-wave build*: each replica's copy holds
+    its own items only and evaluates the node functions in two passes (M::HEAVY), which is what brings a Delta III
+    tile body from 308 to <= 256 registers, i.e. two resident waves per SIMD instead of one."""
+    if os.environ.get("PYCOLLO_AMD_STATIC_W", "1") == "0":
         return []
-    return [2, 4]
+    return [2] if is_heavy(pm) else [2, 4]
 
 
 def _constexpr_table(name: str, values: list[int]) -> str:
@@ -174,6 +183,7 @@ def _phase_struct(pm: PhaseModel, model: Model | None = None) -> str:
              f"  static constexpr bool T0_FREE = {'true' if pm.t_free[0] else 'false'}, "
              f"TF_FREE = {'true' if pm.t_free[1] else 'false'};",
              f"  static constexpr int NJ = {len(pm.jac)}, NH = {len(pm.hess)};",
+             f"  static constexpr bool HEAVY = {'true' if is_heavy(pm) else 'false'};   // two-wave build: node functions in two passes",
              _constexpr_table("jr", [r for r, _, _ in pm.jac]),
              _constexpr_table("jc", [c for _, c, _ in pm.jac]),
              _constexpr_table("hr", [r for r, _, _ in pm.hess]),
@@ -339,7 +349,7 @@ def generate_source(model: Model, orders=None) -> str:
         # body takes long to compile once, and such models rarely share tiles.
         static_ws = _static_w_list(pm)
         for wn in static_ws:
-            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
+            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{_w2_attr(is_heavy(pm) and wn == 2)}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
             parts.append('  const int ntb = (wa >> 28) & 7;')
             parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
             parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
@@ -354,7 +364,9 @@ def generate_source(model: Model, orders=None) -> str:
     else:
         np_ = len(model.phases)
 
-        def all_body(res: bool):
+        def all_body(res: bool, wn: int = 0):
+            """wn = 0: replica index at run time (any waves-per-tile count); wn > 0: one instantiation of the tile body
+            per replica, for launches with exactly wn waves per tile."""
             out = []
             blk = "(int)blockIdx.x - tail_blocks" if res else "(int)blockIdx.x"
             out.append(f"  const int b = pc::xcd_major({blk}, fb{np_});")
@@ -362,16 +374,13 @@ def generate_source(model: Model, orders=None) -> str:
             for i, pm in enumerate(model.phases):
                 cond = f"if (b < fb{i + 1}) " if i + 1 < np_ else ""
                 args = f"(ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch)"
-                out.append("#ifdef PC_STATIC_W   // one instantiation per replica (host must run PYCOLLO_AMD_WPT=PC_STATIC_W)")
-                out.append(f"  {cond}{{ switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {{")
-                for wv in range(4):
-                    out.append(f"#if PC_STATIC_W > {wv}")
-                    out.append(f"    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}, PC_STATIC_W, {wv}>{args}; return;")
-                    out.append("#endif")
-                out.append("    default: return; } }")
-                out.append("#else")
-                out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}>{args}; return; }}")
-                out.append("#endif")
+                if wn > 0:
+                    out.append(f"  {cond}{{ switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {{")
+                    for wv in range(wn):
+                        out.append(f"    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}, {wn}, {wv}>{args}; return;")
+                    out.append("    default: return; } }")
+                else:
+                    out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}>{args}; return; }}")
             return out
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         # The members of PcMultiArgs travel as separate scalar parameters (same order, same offsets: the host still
@@ -388,6 +397,15 @@ def generate_source(model: Model, orders=None) -> str:
         parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
         parts += all_body(True)
         parts.append("}")
+        # replica index compiled in (see pc_bulk_p<i>_r_w<W> above): W = 2 always -- for heavy models this is the two-wave
+        # build --, W = 4 when every phase is light or medium
+        multi_ws = sorted(set.intersection(*[set(_static_w_list(pm)) for pm in model.phases]))
+        for wn in multi_ws:
+            heavy_any = any(is_heavy(pm) for pm in model.phases)
+            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{_w2_attr(heavy_any and wn == 2)}pc_bulk_all_r_w{wn}(' + multi_sig + ', PcTailArgs t) {')
+            parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
+            parts += all_body(True, wn)
+            parts.append("}")
     parts.append("")
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
@@ -419,6 +437,17 @@ def _waves_per_eu() -> int:
 def _extra_defines() -> list[str]:
     """Experiment knob: PYCOLLO_AMD_DEFINES="PC_FLUSH_DEPTH=8 PC_PIN_BUDGET=0" adds -D flags to the code-object build."""
     return [d for d in os.environ.get("PYCOLLO_AMD_DEFINES", "").split() if d]
+
+
+def _two_wave_cap() -> bool:
+    """PYCOLLO_AMD_W2_CAP=1: the two-wave kernels of heavy models are compiled with ``amdgpu_waves_per_eu(2)`` -- the
+    register allocator must then fit 256 registers and spills what does not (A/B knob: a few spilled dwords against
+    one wave per SIMD)."""
+    return os.environ.get("PYCOLLO_AMD_W2_CAP", "0") == "1"
+
+
+def _w2_attr(heavy: bool) -> str:
+    return "__attribute__((amdgpu_waves_per_eu(2))) " if (heavy and _two_wave_cap() and _waves_per_eu() == 0) else ""
 
 
 def _occupancy_attr() -> str:
@@ -472,6 +501,8 @@ def code_object_path(model: Model, orders=None) -> str:
         occ += "_fc" + _fp_contract()
     if _preload_count() != 10:
         occ += f"_pl{_preload_count()}"
+    if _two_wave_cap():
+        occ += "_cap2"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
@@ -502,17 +533,65 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
     # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
     cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
-           "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}",
+           "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
            f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
     if verbose:
         print(res.stderr)
+    # what the compiler made of every kernel travels with the object: pc_create's launch shape depends on it (a
+    # two-wave build that did not fit 256 registers must not be launched as one)
+    import json
+    with open(resources_path(out) + ".tmp", "w") as f:
+        json.dump(_parse_resources(res.stderr), f, indent=1, sort_keys=True)
+    os.replace(resources_path(out) + ".tmp", resources_path(out))
     os.replace(out + ".tmp", out)
     return out
+
+
+def resources_path(code_object: str) -> str:
+    return code_object[:-6] + ".json" if code_object.endswith(".hsaco") else code_object + ".json"
+
+
+def _parse_resources(remarks: str) -> dict:
+    """{kernel: {"vgprs", "agprs", "sgprs", "scratch", "occupancy"}} from -Rpass-analysis=kernel-resource-usage."""
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("agprs", r" AGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"),
+                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def code_object_resources(code_object: str) -> dict:
+    """The sidecar written by :func:`build_code_object` ({} when absent: an object built by an older generator)."""
+    import json
+    try:
+        with open(resources_path(code_object)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def two_wave_occupancy(model: Model, code_object: str) -> int:
+    """Waves per SIMD (by registers) of the code object's two-wave launch kernel -- ``pc_bulk_all_r_w2`` /
+    ``pc_bulk_p<i>_r_w2`` of a model with a heavy phase --, 0 when the object has none or the model is not heavy."""
+    if not any(is_heavy(pm) for pm in model.phases):
+        return 0
+    res = code_object_resources(code_object)
+    name = "pc_bulk_all_r_w2" if len(model.phases) > 1 else f"pc_bulk_p{model.phases[0].index}_r_w2"
+    k = res.get(name)
+    if not k or (k.get("scratch", 1) != 0 and not _two_wave_cap()):
+        return 0
+    return int(k.get("occupancy", 0))
 
 
 def kernel_resources(model: Model, orders=None) -> dict:
@@ -535,15 +614,4 @@ def kernel_resources(model: Model, orders=None) -> dict:
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{res.stderr[-4000:]}")
-    out, cur = {}, None
-    for line in res.stderr.splitlines():
-        m = re.search(r"Function Name: (\S+)", line)
-        if m:
-            cur = out.setdefault(m.group(1), {})
-            continue
-        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
-                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
-            m = re.search(pat, line)
-            if m and cur is not None:
-                cur[key] = int(m.group(1))
-    return out
+    return _parse_resources(res.stderr)

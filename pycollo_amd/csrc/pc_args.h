@@ -67,6 +67,47 @@ struct PcPhaseArgs {
   int64_t hoff[PC_MAX_HOFF];  // [NZ] hz_base | [2*NZ] ht_base | [NS*NZ] hs_base  (-1 where absent)
 };
 
+// LDS carve-up of the bulk kernel, shared by the host (size query, launch) and the device.  All offsets in doubles.
+//   tab_doubles  entries of the packed scal | goff | hoff table of the phase's model (NSCAL + NFN + 3 NZ + NS NZ):
+//                staged by the kernels of models whose tables do not fit the scalar register file
+//   mesh_tables  the kernel handles any mesh (compiled order 0) and stages the tile's section tables and the
+//                per-order table offsets; an order-specialised kernel does index arithmetic instead
+// LDS per tile is what bounds the waves a CU holds for the multi-state models: nothing is reserved that the
+// kernel at hand does not use.
+struct LdsPlan {
+  int qa, qw, off, tab, h, E, s, kr, f, yu, fs, lam, red, out, total;
+};
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out, int tab_doubles,
+                        bool mesh_tables) {
+  LdsPlan p;
+  int o = 0;
+  p.qa = o; o += qa_total;
+  p.qw = o; o += qw_total;
+  p.off = o; o += mesh_tables ? PC_MAX_ORDER + 1 : 0;   // int32 x 2 x (PC_MAX_ORDER+1): table offsets by order
+  p.tab = o; o += tab_doubles;
+  p.h = o; o += TB + 2;
+  p.E = o; o += mesh_tables ? TB + 2 : 0;                 // int64 entries
+  p.s = o; o += mesh_tables ? (TB + 4) / 2 + 1 : 0;       // int32 entries, (TB+3) of them
+  p.kr = o; o += mesh_tables ? (TB + 1) / 2 + 1 : 0;      // int32 entries
+  p.fs = o; o += NFS * TB;
+  p.red = o; o += (NRED > 0 ? NRED : 1) * 16;
+  // f, y and the staged multipliers are dead once the defect values are formed; the output staging buffer
+  // (CSR runs are written to HBM fully coalesced) is laid over them
+  p.f = o;
+  p.yu = p.f + NY * TB;
+  p.lam = p.yu + NY * TB;
+  p.out = o;
+  {
+    const int node_arrays = 2 * NY * TB + NY * (TB + PC_MAX_ORDER);
+    o += node_arrays > lds_out ? node_arrays : lds_out;
+  }
+  p.total = o;
+  return p;
+}
+
 // The first 14 dwords of pc_bulk_p<i>'s argument block, passed as leading scalar kernel parameters: the command
 // processor preloads them into SGPRs with the dispatch (kernarg preload), so a wave can address its node loads
 // without waiting for a scalar load of the block first.  Copies of the PcPhaseArgs fields of the same name.

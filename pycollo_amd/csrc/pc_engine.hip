@@ -15,6 +15,7 @@
 #include "../../include/pycollo_amd.h"
 #include "pc_args.h"
 #include "pc_pattern.hpp"
+#include "pc_desc.hpp"
 
 namespace {
 
@@ -29,51 +30,10 @@ void set_err(const std::string& s) { g_err = s; }
       throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_));              \
   } while (0)
 
-// LDS plan must match pc_kernels.hpp::lds_plan (kept in one place there; mirrored here because this
-// TU does not include device templates).
-int lds_doubles(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
-  int o = 0;
-  o += qa_total;
-  o += qw_total;
-  o += PC_MAX_ORDER + 1;
-  o += PC_MAX_SCAL + PC_MAX_GOFF + PC_MAX_HOFF;
-  o += TB + 2;
-  o += TB + 2;
-  o += (TB + 4) / 2 + 1;
-  o += (TB + 1) / 2 + 1;
-  o += NFS * TB;
-  o += (NRED > 0 ? NRED : 1) * 16;
-  const int node_arrays = 2 * NY * TB + NY * (TB + PC_MAX_ORDER);
-  o += std::max(node_arrays, lds_out);   // the staging buffer overlays f / y / lambda
-  return o;
-}
-
-// doubles of the output staging buffer of one phase: the longest CSR run a tile emits in one piece
-int phase_lds_out(const pcp::Phase& P, int TB) {
-  int nmax = 0;
-  for (int k = 0; k < P.K; ++k) nmax = std::max(nmax, (int)P.n_k[k]);
-  int out = 0;
-  for (int a = 0; a < P.n_y; ++a) {
-    int Da = 0, Ca = P.n_t + (P.dep(a, a) ? 0 : 2);
-    for (int b = 0; b < P.n_z; ++b) Da += P.dep(a, b) ? 1 : 0;
-    for (int l = 0; l < P.n_w; ++l) Ca += (!P.is_t(l) && P.dep(a, P.n_z + l)) ? 1 : 0;   // time parameters add to the t columns
-    out = std::max(out, (Da * nmax + Ca) * (TB - 1));
-  }
-  for (int m = 0; m < P.n_p; ++m) {
-    int R = 0;
-    for (int c = 0; c < P.n_v; ++c) R += P.dep(P.n_y + m, c) ? 1 : 0;
-    out = std::max(out, R * TB);
-  }
-  for (int b = 0; b < P.n_z; ++b) out = std::max(out, P.hrow_count(b) * TB);
-  return out;
-}
-
-int phase_lds_bytes(const pcp::Phase& P, int TB, int qa_total, int qw_total) {
-  int nfs = 0;
-  for (int a = 0; a < P.n_y; ++a)
-    for (int l = 0; l < P.n_w; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
-  return 8 * lds_doubles(TB, qa_total, qw_total, P.n_y, nfs, P.nred, phase_lds_out(P, TB));
-}
+using pcp::phase_nfs;
+using pcp::phase_lds_bytes;
+using pcp::phase_lds_out;
+using pcp::phase_max_tile_rows;
 
 template <class T>
 struct DevBuf {
@@ -184,6 +144,7 @@ struct pc_handle {
   int device = -1;
   int TB = 64;
   int TC = 64;   // nodes a tile may hold (<= TB)
+  bool two_wave = false;   // heavy model in the two-wave build: W = 2, tiles sized for four workgroups per CU
   bool scaling_set = false;
   double w_J = 1.0;
   // quadrature
@@ -641,42 +602,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     if (d->n_phases < 1 || d->n_phases > PC_MAX_PHASES) throw std::runtime_error("n_phases must be in [1, 8]");
     h.reset(new pc_handle());
     auto& Q = h->Q;
-    Q.n_s = d->n_s;
-    Q.n_b = d->n_b;
-    Q.ph.resize(d->n_phases);
-    for (int ip = 0; ip < d->n_phases; ++ip) {
-      const pc_phase_desc& s = d->phases[ip];
-      auto& P = Q.ph[ip];
-      P.n_y = s.n_y; P.n_u = s.n_u; P.n_q = s.n_q; P.n_p = s.n_p;
-      P.t_free[0] = s.t0_free != 0; P.t_free[1] = s.tF_free != 0;
-      P.t_fixed[0] = s.t0_fixed; P.t_fixed[1] = s.tF_fixed;
-      P.K = s.K;
-      if (s.K < 1 || !s.n_k || !s.h_k) throw std::runtime_error("phase mesh arrays missing");
-      P.n_k.assign(s.n_k, s.n_k + s.K);
-      P.h_k.assign(s.h_k, s.h_k + s.K);
-      P.jac_row.assign(s.jac_row, s.jac_row + s.n_jac);
-      P.jac_col.assign(s.jac_col, s.jac_col + s.n_jac);
-      P.hess_row.assign(s.hess_row, s.hess_row + s.n_hess);
-      P.hess_col.assign(s.hess_col, s.hess_col + s.n_hess);
-      if (s.n_w > 0) {
-        if (!s.w_kind || !s.w_idx) throw std::runtime_error("phase parameter arrays missing");
-        P.wkind.assign(s.w_kind, s.w_kind + s.n_w);
-        P.widx.assign(s.w_idx, s.w_idx + s.n_w);
-      }
-      P.bulk_kernel = s.bulk_kernel ? s.bulk_kernel : "";
-      P.eval_ops = s.eval_ops;
-      for (int k = 0; k < s.K; ++k)
-        if (s.compiled_order > 0 && s.n_k[k] != s.compiled_order)
-          throw std::runtime_error("phase kernel was compiled for a fixed section order that the mesh does not have");
-    }
-    Q.point_phase.assign(d->point_phase, d->point_phase + d->n_point);
-    Q.point_kind.assign(d->point_kind, d->point_kind + d->n_point);
-    Q.point_idx.assign(d->point_idx, d->point_idx + d->n_point);
-    Q.jgrad_col.assign(d->jgrad_col, d->jgrad_col + d->n_jgrad);
-    Q.bjac_row.assign(d->bjac_row, d->bjac_row + d->n_bjac);
-    Q.bjac_col.assign(d->bjac_col, d->bjac_col + d->n_bjac);
-    Q.pthess_row.assign(d->pthess_row, d->pthess_row + d->n_pthess);
-    Q.pthess_col.assign(d->pthess_col, d->pthess_col + d->n_pthess);
+    pcp::from_desc(*d, Q);   // pc_desc.hpp: plain C++, also compiled (with sanitizers) by the CPU test harness
     // quadrature tables
     for (int i = 0; i <= PC_MAX_ORDER; ++i) h->qa_off[i] = h->qw_off[i] = -1;
     {
@@ -718,20 +644,49 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     }
     if (TB != 64 && TB != 128 && TB != 256) throw std::runtime_error("threads_per_block must be 64, 128 or 256");
     for (auto& P : Q.ph) pcp::finalize_phase_tables(P, Q.n_s);
-    if (auto_tb) {  // largest tile whose staging fits the 64 KiB of dynamic LDS a module kernel may request
-      auto fits = [&](int tb) {
-        for (auto& P : Q.ph)
-          if (phase_lds_bytes(P, tb, (int)h->qa.size(), (int)h->qw.size()) > h->lds_limit) return false;
-        return true;
-      };
-      while (TB > 64 && !fits(TB)) TB /= 2;
-    }
+    const int qa_n = (int)h->qa.size(), qw_n = (int)h->qw.size();
+    // bytes of LDS a workgroup of W waves needs when tiles hold at most `tc` nodes (worst phase; before the tiles exist:
+    // a tile of tc nodes has at most tc - 1 defect rows per state)
+    auto lds_need = [&](int tb, int tc, int W) {
+      int mx = 0;
+      for (auto& P : Q.ph)
+        mx = std::max(mx, phase_lds_bytes(P, W > 1 ? 64 : tb, qa_n, qw_n, W * phase_lds_out(P, tc - 1, tc), P.compiled_order == 0));
+      return mx;
+    };
+    if (auto_tb)   // largest tile whose staging fits the 64 KiB of dynamic LDS a module kernel may request
+      while (TB > 64 && lds_need(TB, TB, 1) > h->lds_limit) TB /= 2;
     h->TB = TB;
     // Tile capacity in nodes (<= TB): a tile smaller than its workgroup leaves lanes idle but shortens every
     // wave's store phase and puts more waves on the chip -- what a problem with far fewer tiles than SIMDs wants.
     int TC = TB, max_nk = 2;
     for (auto& P : Q.ph)
       for (int k = 0; k < P.K; ++k) max_nk = std::max(max_nk, P.n_k[k]);
+    // The two-wave build of a heavy model (codegen: pc_bulk_all_r_w2 / pc_bulk_p<i>_r_w2, <= 256 registers): two waves
+    // share every 64-node tile, each with its own staging region, and a SIMD holds two of them -- if the CU's 160 KiB of
+    // LDS hold four tiles.  The tile capacity is the largest that allows it (Delta III, order 5: 60 rows of 40 doubles per
+    // replica; 4 x 12.5 k nodes 30.6 -> 23.2 us).  PYCOLLO_AMD_TWO_WAVE=0 turns the mode off; an explicit
+    // PYCOLLO_AMD_WPT / PYCOLLO_AMD_TILE_NODES leaves the choice to the caller.
+    h->two_wave = d->two_wave_occupancy >= 2 && TB == 64 && !std::getenv("PYCOLLO_AMD_WPT") &&
+                  !std::getenv("PYCOLLO_AMD_TILE_NODES");
+    if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE")) h->two_wave = h->two_wave && std::atoi(env) != 0;
+    {   // with few tiles (a rank's share of a sharded mesh, a coarse mesh) four waves per tile serve better: one wave
+        // per SIMD either way, and the shorter one wins
+      int64_t tiles64 = 0;
+      for (auto& P : Q.ph) {
+        int64_t N = 1;
+        for (int k = 0; k < P.K; ++k) N += P.n_k[k] - 1;
+        tiles64 += (N + 62) / 63;
+        h->two_wave = h->two_wave && P.n_y >= 2;
+      }
+      h->two_wave = h->two_wave && tiles64 > 400;
+    }
+    if (h->two_wave) {
+      constexpr int kQuarterCu = (160 * 1024) / 4 - 512;   // four workgroups per CU, one allocation granule to spare
+      int tc = 64;
+      while (tc > std::max(max_nk, 32) && lds_need(64, tc, 2) > kQuarterCu) --tc;
+      if (lds_need(64, tc, 2) <= kQuarterCu) TC = tc;
+      else h->two_wave = false;
+    }
     if (const char* env = std::getenv("PYCOLLO_AMD_TILE_NODES")) {
       const int v = std::atoi(env);
       if (v >= max_nk && v <= TB) TC = v;
@@ -767,10 +722,9 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.n_tiles = (int)P.tile_k0.size() - 1;
       D.tile_begin = 0;
       D.tile_end = D.n_tiles;
-      int nfs = 0;
-      for (int a = 0; a < P.n_y; ++a)
-        for (int l = 0; l < P.n_w; ++l) nfs += P.dep(a, P.n_z + l) ? 1 : 0;
+      const int nfs = phase_nfs(P);
       D.nfs = nfs;
+      const bool mesh_tables = P.compiled_order == 0;
       // uniform section order: index arithmetic replaces the section tables
       bool same = true;
       for (int k = 0; k < P.K; ++k) same = same && P.n_k[k] == P.n_k[0];
@@ -778,7 +732,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       D.spt = same ? (TC - 1) / (P.n_k[0] - 1) : 0;
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
-      D.lds_out = phase_lds_out(P, TC);   // runs of a tile: at most TC - 1 defect rows, TC nodes
+      D.lds_out = phase_lds_out(P, phase_max_tile_rows(P), std::min(TC, phase_max_tile_rows(P) + 1));   // the largest tile's runs
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
       // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle
@@ -799,11 +753,10 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
           const int v = std::atoi(env);
           if (v == 1 || v == 2 || v == 4) D.wpt = v;
         }
-        while (D.wpt > 1 && 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred,
-                                            D.lds_out * D.wpt) > h->lds_limit)
-          D.wpt /= 2;
+        if (h->two_wave) D.wpt = 2;
+        while (D.wpt > 1 && phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * D.wpt, mesh_tables) > h->lds_limit) D.wpt /= 2;
       }
-      D.lds_bytes = 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, nfs, P.nred, D.lds_out * D.wpt);
+      D.lds_bytes = phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * D.wpt, mesh_tables);
       h->lds_max = std::max(h->lds_max, D.lds_bytes);
       if (D.lds_bytes > h->lds_limit)
         throw std::runtime_error("tile needs more dynamic LDS than a workgroup may request; use a smaller "
@@ -827,7 +780,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
           auto& P = Q.ph[ip];
           auto& D = *h->pd[ip];
-          mx = std::max(mx, 8 * lds_doubles(TB, (int)h->qa.size(), (int)h->qw.size(), P.n_y, D.nfs, P.nred, D.lds_out * w));
+          mx = std::max(mx, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, P.compiled_order == 0));
         }
         return mx;
       };
@@ -838,6 +791,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
           const int v = std::atoi(env);
           if (v == 1 || v == 2 || v == 4) h->wpt_all = v;
         }
+        if (h->two_wave) h->wpt_all = 2;
         while (h->wpt_all > 1 && lds_for(h->wpt_all) > h->lds_limit) h->wpt_all /= 2;
       }
       h->lds_all = lds_for(h->wpt_all);
@@ -863,6 +817,13 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         h->d_phase_args.alloc(Q.ph.size() * sizeof(PcPhaseArgs));
         h->n_launches = 2;
         if (hipModuleGetFunction(&h->bulk_all_res_fn, h->module, "pc_bulk_all_r") != hipSuccess) h->bulk_all_res_fn = nullptr;
+        if (h->bulk_all_res_fn && h->wpt_all > 1) {   // the same launch with the replica index compiled in
+          hipFunction_t fw = nullptr;
+          if (hipModuleGetFunction(&fw, h->module, ("pc_bulk_all_r_w" + std::to_string(h->wpt_all)).c_str()) == hipSuccess && fw)
+            h->bulk_all_res_fn = fw;
+          else
+            (void)hipGetLastError();
+        }
       }
     }
     {   // one buffer: the weight tables right behind the A tables (the kernels address both from `qa`)
@@ -1067,9 +1028,17 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
                        double* d_jac, double* d_hess, void* stream) {
   return guarded([&] {
     require_device(h);
+    check_timeout(h);   // a previous device-API evaluation whose tail gave up: say so before queueing more work
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
                obj_factor);
+  });
+}
+
+int pc_check(pc_handle* h) {
+  return guarded([&] {
+    require_device(h);
+    check_timeout(h);
   });
 }
 
@@ -1278,7 +1247,10 @@ int pc_eval_h(pc_handle* h, const double* x, int new_x, double obj_factor, const
                obj_factor);
     copy_down(h, h->o_H, h->o_H + Q.h_row.size());
     wait_stream(h);
-    h->small_synced = h->G_synced = h->fc_valid;   // the stream has drained: earlier copies are complete too
+    // the stream has drained: earlier copies are complete too -- G~'s only if it was ever issued (prefetch off and
+    // kernels not writing host memory: G~ is still on the device and wait_G must fetch it)
+    h->small_synced = h->fc_valid;
+    h->G_synced = h->fc_valid && h->G_copied;
     if (values != h->h_out.p + h->o_H) std::memcpy(values, h->h_out.p + h->o_H, Q.h_row.size() * sizeof(double));
   });
 }
@@ -1394,7 +1366,8 @@ int pc_row_norms_jac(pc_handle* h, const double* x, double* norms) {
     HIP_OK(hipStreamSynchronize(h->stream));
     std::memcpy(norms, h->h_norms.p, m * sizeof(double));
     h->x_valid = h->fc_valid = (mode == 0);   // the cache describes the device mirror only
-    h->small_synced = h->G_synced = h->fc_valid;
+    h->small_synced = h->fc_valid;
+    h->G_synced = h->fc_valid && h->G_copied;   // (see pc_eval_h)
   });
 }
 

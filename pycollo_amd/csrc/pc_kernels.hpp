@@ -289,36 +289,7 @@ struct S {
   }
 };
 
-// LDS carve-up, shared by host (size query) and device.  All offsets in doubles.
-struct LdsPlan {
-  int qa, qw, off, tab, h, E, s, kr, f, yu, fs, lam, red, out, total;
-};
-__host__ __device__ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out) {
-  LdsPlan p;
-  int o = 0;
-  p.qa = o; o += qa_total;
-  p.qw = o; o += qw_total;
-  p.off = o; o += PC_MAX_ORDER + 1;     // int32 x 2 x (PC_MAX_ORDER+1): table offsets by order
-  p.tab = o; o += PC_MAX_SCAL + PC_MAX_GOFF + PC_MAX_HOFF;   // scal | goff | hoff when they do not fit in SGPRs
-  p.h = o; o += TB + 2;
-  p.E = o; o += TB + 2;                 // int64 entries
-  p.s = o; o += (TB + 4) / 2 + 1;       // int32 entries, (TB+3) of them
-  p.kr = o; o += (TB + 1) / 2 + 1;      // int32 entries
-  p.fs = o; o += NFS * TB;
-  p.red = o; o += (NRED > 0 ? NRED : 1) * 16;
-  // f, y and the staged multipliers are dead once the defect values are formed; the output staging buffer
-  // (CSR runs are written to HBM fully coalesced) is laid over them -- LDS per tile is what bounds occupancy
-  p.f = o;
-  p.yu = p.f + NY * TB;
-  p.lam = p.yu + NY * TB;
-  p.out = o;
-  {
-    const int node_arrays = 2 * NY * TB + NY * (TB + PC_MAX_ORDER);
-    o += node_arrays > lds_out ? node_arrays : lds_out;
-  }
-  p.total = o;
-  return p;
-}
+// (LDS carve-up: LdsPlan / lds_plan live in pc_args.h, shared with the host's size query)
 
 // Sum over the 64 lanes of a wave in a fixed order; the result is valid in lane 0.
 // Steps 1..16 use DPP row shifts / a row mirror-free butterfly inside 16-lane rows (VALU speed), the last
@@ -694,7 +665,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // (WN > 0: the replica index is a template argument -- see the kernel entry -- and everything a replica does not
   //  own, node-function outputs included, is dead code in its instantiation)
   const int w = WN > 0 ? WIDX : (W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0);   // wave-uniform: branches on it are scalar
-  const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W);
+  // (tables only some kernels stage -- the scal | goff | hoff copy sized by the model, the section tables of the
+  //  any-order kernels -- take no LDS in the others: LDS per tile is what bounds the waves a CU holds)
+  const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W, St::NSCAL + NFN + 3 * NZ + NS * NZ, UN == 0);
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
   int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off (any-mesh kernels)
@@ -1013,7 +986,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
   // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
   // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
-  constexpr bool SPLIT = (NJ + NH >= PC_SPLIT_MIN) && St::NWT == 0;   // (time parameters: the t strips need both passes' values)
+  // A heavy model whose tiles are shared by two waves with the replica index compiled in (WN = 2, codegen's two-wave
+  // build) is split as well: there the point is not the spill but the register count itself -- at <= 256 VGPRs a SIMD
+  // holds two such waves, each with half a tile's outputs, and one wave issues while the other waits (Delta III:
+  // 308 -> 256 VGPRs, one -> two waves per SIMD, 30.6 -> 23.2 us at 4 x 12.5 k nodes).
+  constexpr bool SPLIT = ((NJ + NH >= PC_SPLIT_MIN) || (WN >= 2 && M::HEAVY)) && St::NWT == 0;   // (time parameters: the t strips need both passes' values)
   constexpr bool RED_EARLY = RES && NS == 0 && NRED > 0;
   double mult[NFN > 0 ? NFN : 1];
   if (active) {

@@ -44,6 +44,7 @@ struct Phase {
   std::vector<int32_t> jac_row, jac_col, hess_row, hess_col;
   std::string bulk_kernel;
   int eval_ops = 0;             // launch-shape hint (pc_phase_desc::eval_ops)
+  int compiled_order = 0;       // > 0: the phase's kernel is specialised for sections of exactly that many nodes
   // derived
   int n_z = 0, n_t = 0, n_fn = 0, n_v = 0, N = 0;
   std::vector<int32_t> sec_s;   // [K+1]

@@ -55,7 +55,8 @@ class _ProblemDesc(C.Structure):
                 ("n_pthess", C.c_int32), ("pthess_row", _i32p), ("pthess_col", _i32p),
                 ("n_orders", C.c_int32), ("orders", _i32p), ("quad_A", _f64p), ("quad_w", _f64p),
                 ("code_object", C.c_char_p), ("tail_kernel", C.c_char_p),
-                ("device", C.c_int32), ("threads_per_block", C.c_int32)]
+                ("device", C.c_int32), ("threads_per_block", C.c_int32), ("two_wave_occupancy", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class _Info(C.Structure):
@@ -111,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.pc_phase_tiles.argtypes = [vp, C.c_int, _i32p, _i32p, vp]
     lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
     lib.pc_synchronize.argtypes = [vp]
+    lib.pc_check.argtypes = [vp]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_interp_linear.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     lib.pc_copy_runs.argtypes = [vp, vp, vp, C.c_int64, vp]
@@ -244,6 +246,7 @@ class NlpEngine:
         desc.tail_kernel = b"pc_tail"
         desc.device = self.device
         desc.threads_per_block = int(tpb)
+        desc.two_wave_occupancy = codegen.two_wave_occupancy(m, code_object) if code_object else 0
         return desc
 
     def _check(self, ok):
@@ -272,6 +275,7 @@ class NlpEngine:
             raise ValueError(f"V_ocp / r_ocp must have {self.layout.num_ocp_x} entries")
         if self.W_ocp.shape != (self.layout.num_ocp_c,):
             raise ValueError(f"W_ocp must have {self.layout.num_ocp_c} entries")
+        self._cached_x = None
         self._check(self._lib.pc_set_scaling(self._h, self.V_ocp.ctypes.data, self.r_ocp.ctypes.data,
                                              self.W_ocp.ctypes.data, self.w_J))
 
@@ -305,32 +309,45 @@ class NlpEngine:
         return np.lexsort((r, c))
 
     # ---- evaluation (host pointers) ------------------------------------------------------------
-    def _x(self, x):
+    def _x(self, x, new_x=None):
+        """``new_x``: True / False for the IPOPT-protocol callbacks (the point the library's cache describes is
+        tracked in ``_cached_x``), None for every other entry point, after which no cached point is assumed."""
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
         if x.shape[0] != self.num_x:
             raise ValueError(f"x must have {self.num_x} entries")
+        if new_x is None:
+            self._cached_x = None
+        elif new_x:
+            self._cached_x = x.copy()
         return x
 
+    def cache_holds(self, x) -> bool:
+        """True when the library's J / grad J / c~ / G~ cache was filled at exactly ``x`` by the IPOPT-protocol
+        callbacks and nothing else has touched the handle since: the test a caller without IPOPT's ``new_x`` flag
+        (cyipopt) needs before it may pass ``new_x = 0``."""
+        c = getattr(self, "_cached_x", None)
+        return c is not None and np.array_equal(np.asarray(x, dtype=np.float64).reshape(-1), c)
+
     def evaluate_J(self, x, new_x=True):
-        x = self._x(x)
+        x = self._x(x, bool(new_x))
         out = C.c_double()
         self._check(self._lib.pc_eval_f(self._h, x.ctypes.data, int(new_x), C.addressof(out)))
         return out.value
 
     def evaluate_g(self, x, new_x=True):
-        x = self._x(x)
+        x = self._x(x, bool(new_x))
         g = np.empty(self.num_x)
         self._check(self._lib.pc_eval_grad_f(self._h, x.ctypes.data, int(new_x), g.ctypes.data))
         return g
 
     def evaluate_c(self, x, new_x=True):
-        x = self._x(x)
+        x = self._x(x, bool(new_x))
         c = np.empty(self.num_c)
         self._check(self._lib.pc_eval_g(self._h, x.ctypes.data, int(new_x), c.ctypes.data))
         return c
 
     def evaluate_G_nonzeros(self, x, new_x=True):
-        x = self._x(x)
+        x = self._x(x, bool(new_x))
         v = np.empty(self.nnz_jac)
         self._check(self._lib.pc_eval_jac_g(self._h, x.ctypes.data, int(new_x), v.ctypes.data))
         return v
@@ -340,7 +357,7 @@ class NlpEngine:
         return sparse.coo_matrix((self.evaluate_G_nonzeros(x), (r, c)), shape=(self.num_c, self.num_x))
 
     def evaluate_H_nonzeros(self, x, obj_factor, lagrange, new_x=True):
-        x = self._x(x)
+        x = self._x(x, bool(new_x))
         lam = np.ascontiguousarray(lagrange, dtype=np.float64).reshape(-1)
         if lam.shape[0] != self.num_c:
             raise ValueError(f"lagrange must have {self.num_c} entries")
@@ -380,6 +397,7 @@ class NlpEngine:
     def evaluate_all_inplace(self, obj_factor=1.0):
         """Fused c, G, H at the (x~, lambda) already written into :meth:`host_buffers`; results are read there."""
         x, lam, c, g, h = self.host_buffers()
+        self._cached_x = None
         self._check(self._lib.pc_eval_all(self._h, x.ctypes.data, float(obj_factor), lam.ctypes.data, c.ctypes.data,
                                           g.ctypes.data, h.ctypes.data))
         return c, g, h
@@ -387,6 +405,7 @@ class NlpEngine:
     def set_host_mode(self, mode: int):
         """0: one DMA copy up / down; 1: kernels read x~, lambda from pinned host memory; 2: kernels write c~, G~, H~
         to pinned host memory; 3: both (``pc_set_host_mode``)."""
+        self._cached_x = None
         self._check(self._lib.pc_set_host_mode(self._h, int(mode)))
 
     def evaluate_resident(self, x, obj_factor=1.0, lagrange=None, want_grad=True):
@@ -474,6 +493,11 @@ class NlpEngine:
     def synchronize(self):
         self._check(self._lib.pc_synchronize(self._h))
 
+    def check(self):
+        """After the caller synchronised its OWN stream (device API): raises if an evaluation's resident tail gave up
+        waiting for values of its launch (``pc_check``) -- e.g. two evaluations of this handle in flight at once."""
+        self._check(self._lib.pc_check(self._h))
+
     @property
     def stream(self):
         return self._lib.pc_stream(self._h)
@@ -489,17 +513,14 @@ class PycolloGpuProblem:
         self.engine = engine
         self.n, self.m = engine.num_x, engine.num_c
         self.obj_func_eval_counter = 0  # nlp.py:45
-        self._last_x = None
 
     def _new_x(self, x) -> bool:
-        """cyipopt does not forward IPOPT's ``new_x`` flag: it is recovered by comparing with the last point
-        (n doubles; far cheaper than an evaluation), so that objective / gradient / constraints / jacobian at one
-        point share one launch (``pc_eval_*`` with ``new_x = 0``)."""
-        x = np.asarray(x, dtype=np.float64).reshape(-1)
-        if self._last_x is not None and np.array_equal(x, self._last_x):
-            return False
-        self._last_x = x.copy()
-        return True
+        """cyipopt does not forward IPOPT's ``new_x`` flag: it is recovered by comparing with the point the ENGINE's
+        cache was filled at (n doubles; far cheaper than an evaluation), so that objective / gradient / constraints /
+        jacobian at one point share one launch (``pc_eval_*`` with ``new_x = 0``).  The engine owns that record
+        (``NlpEngine.cache_holds``): any other call on the same engine in between (evaluate_all, set_scaling, a
+        resident evaluation, a mesh-error pass) clears it, and the next callback re-evaluates."""
+        return not self.engine.cache_holds(x)
 
     def objective(self, x):
         self.obj_func_eval_counter += 1

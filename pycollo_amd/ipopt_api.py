@@ -106,7 +106,13 @@ class problem:                                   # (cyipopt's class name)
         if user:
             so, sx, sg = self.scaling
             inner = _UserScaled(self.problem_obj, so, sx, sg)
-            solver = InteriorPointSolver(inner, self.n, self.m, self.lb * sx, self.ub * sx, self.cl * sg, self.cu * sg, **kw)
+            # IPOPT tests "infinite" (|b| >= 1e19, nlp_lower/upper_bound_inf) on the UNSCALED bounds: a scale below
+            # 0.5 must not turn an absent bound into a finite one (-2e19 * 0.4 = -8e18 would get barrier terms)
+            def scaled(b, sc):
+                b = np.asarray(b, float)
+                return np.where(np.abs(b) >= 1e19, np.sign(b) * 2e19, b * sc)
+            solver = InteriorPointSolver(inner, self.n, self.m, scaled(self.lb, sx), scaled(self.ub, sx),
+                                         scaled(self.cl, sg), scaled(self.cu, sg), **kw)
             res = solver.solve(x0 * sx)
             xs = res.x / sx
             mult_g, zl_, zu_ = res.lam * sg / so, res.zl * sx / so, res.zu * sx / so

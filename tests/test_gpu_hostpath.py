@@ -109,3 +109,48 @@ def test_host_modes_and_inplace_views_write_the_same_bits(built, name, kw):
 def _indptr(eng):
     r, _ = eng.evaluate_G_structure()
     return np.concatenate([[0], np.cumsum(np.bincount(r, minlength=eng.num_c))])
+
+
+@pytest.mark.parametrize("then", ["hessian", "row_norms"])
+def test_prefetch_off_jacobian_after_other_calls(built, then):
+    """pc_set_prefetch_jac(0), kernels not writing host memory: G~ stays on the device until pc_eval_jac_g asks for
+    it.  A pc_eval_h (or a row-norm pass) in between drains the stream; the Jacobian requested afterwards at the same
+    point (new_x = 0) must still be fetched -- not the pinned block's previous contents."""
+    prob = problems.cart_pole(K=40, order=4)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    rng = np.random.default_rng(17)
+    x0, x1 = rng.uniform(-0.4, 0.4, eng.num_x), rng.uniform(-0.4, 0.4, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    eng.set_host_mode(0)
+    eng.set_prefetch_jac(True)
+    eng.evaluate_G_nonzeros(x0)            # the pinned block now holds G~(x0)
+    eng.set_prefetch_jac(False)
+    assert_matches_oracle(ora, x1, c=eng.evaluate_c(x1))          # new point: G~(x1) computed, left on the device
+    if then == "hessian":
+        assert_matches_oracle(ora, x1, H=eng.evaluate_H_nonzeros(x1, 0.9, lam, new_x=False), sigma=0.9, lam=lam)
+        assert_matches_oracle(ora, x1, G=eng.evaluate_G_nonzeros(x1, new_x=False))
+    else:
+        eng.G_row_norms(x1)
+        assert_matches_oracle(ora, x1, G=eng.evaluate_G_nonzeros(x1, new_x=False))
+        assert_matches_oracle(ora, x0, c=eng.evaluate_c(x0), G=eng.evaluate_G_nonzeros(x0, new_x=False))
+    eng.close()
+
+
+def test_cyipopt_object_survives_direct_engine_calls(built):
+    """PycolloGpuProblem recovers new_x from the ENGINE's record of its cached point: a direct engine call in between
+    (evaluate_all at another point) must not make the next callback return that other point's values."""
+    from pycollo_amd.engine import PycolloGpuProblem
+    prob = problems.cart_pole(K=30, order=4)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    p = PycolloGpuProblem(eng)
+    rng = np.random.default_rng(23)
+    x, x2 = rng.uniform(-0.4, 0.4, eng.num_x), rng.uniform(-0.4, 0.4, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    assert abs(p.objective(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+    eng.evaluate_all(x2, 1.0, lam)                        # the library's cache now describes x2
+    assert_matches_oracle(ora, x, c=p.constraints(x), G=p.jacobian(x), g=p.gradient(x))
+    eng.evaluate_c(x2)                                    # protocol callback at another point, by hand
+    assert_matches_oracle(ora, x, c=p.constraints(x), G=p.jacobian(x))
+    eng.close()

@@ -34,3 +34,5 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
 for k in sorted(acc):
     print(f"{k:28s} {acc[k][0] / acc[k][1]:16.1f}  (avg of {acc[k][1]} dispatches)")
 PY
+# the raw per-dispatch CSVs are tens of MB: gpurun_out/ only travels back below 64 MiB
+rm -rf $OUT/p[0-9] $OUT/p[0-9].log
