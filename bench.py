@@ -188,7 +188,8 @@ def main():
                     f"= {eng.layout.phases[0].N} collocation nodes{' per phase' if nph > 1 else ''}")
         extra = {"num_x": eng.num_x, "num_c": eng.num_c, "nnz_jac": eng.nnz_jac, "nnz_hess": eng.nnz_hess,
                  "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"], "waves_per_tile": info["waves_per_tile"],
-                 "launches_per_eval": info["n_launches"], "launch_thread_cpu": pinned_cpu}
+                 "launches_per_eval": info["n_launches"], "lds_bytes_per_workgroup": info["lds_bytes_max"],
+                 "launch_thread_cpu": pinned_cpu}
         if os.environ.get("PYCOLLO_AMD_BENCH_ADDR"):   # diagnostic: where the buffers landed
             extra["addr"] = {k: hex(t.data_ptr()) for k, t in (("x", x), ("lam", lam), ("c", c), ("G", G), ("H", H))}
     else:

@@ -274,6 +274,13 @@ void pc_kkt_destroy(pc_kkt* k);
 int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, int32_t* n_neg);
 int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x);                       /* host vectors [nu] */
 int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, double* y);   /* y = K x */
+/* x = K^-1 rhs with the current factors, iteratively refined ON THE DEVICE against the system with dvec_true on its
+ * diagonal (the factors may carry a slightly different diagonal): solve, residual, up to max_steps corrections, a
+ * correction kept only while it halves the residual 2-norm and stays finite.  One call per linear step of the
+ * interior-point method -- what IPOPT's linear-solver interface does inside IpPDFullSpaceSolver (the reference only
+ * names the solver, pycollo/backend.py:1703-1711).  n_solves (may be NULL): back-substitutions performed. */
+int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const double* rhs, int max_steps, double* x,
+                         int32_t* n_solves);
 /* Evaluate at (x, obj_factor, lambda) and leave g, jac_g and the Lagrangian Hessian in device memory; only J,
  * grad J (dense n, may be NULL) and g (may be NULL) come back.  lambda == NULL: g and jac_g only. */
 int pc_eval_resident(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* f, double* grad,
@@ -284,6 +291,9 @@ int pc_device_results(pc_handle* h, const double** d_g, const double** d_jac, co
 /* timing of the last n pc_eval_all_device launches is measured by the caller with HIP events on the
  * stream it passed; this returns the stream the handle owns (hipStream_t) */
 void* pc_stream(pc_handle* h);
+/* diagnostic: copy `bytes` of a __device__ variable of the problem's code object to the host (the clock stamps of a
+ * -DPC_STAMPS build, tools/stamps.py); synchronises the handle's stream first.  No reference counterpart. */
+int pc_read_symbol(pc_handle* h, const char* name, void* dst, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -269,10 +269,16 @@ def _point_struct(pt: PointModel) -> str:
     return "\n".join(lines)
 
 
-def generate_source(model: Model, orders=None) -> str:
+def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) -> str:
     orders = tuple(orders) if orders is not None else tuple(0 for _ in model.phases)
+    if heavy_cap is None:
+        heavy_cap = _heavy_cap_enabled()
+    heavy_any = any(is_heavy(pm) for pm in model.phases)
     parts = [f"// generated by pycollo_amd.codegen for model '{model.name}' digest {model.digest} -- do not edit",
              '#include "pc_kernels.hpp"',
+             "#ifdef PC_STAMPS   // diagnostic build (tools/stamps.py): per-wave clock stamps of the tile body",
+             'extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 10] = {};',
+             "#endif",
              "",
              "template <int N> __device__ __forceinline__ double pc_powi(double x) {",
              "  double r = 1.0;",
@@ -329,14 +335,16 @@ def generate_source(model: Model, orders=None) -> str:
                 'int tile_begin, int n_blocks, int wa, int wb')
     for pm in model.phases:
         # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}({lead_sig}, PcPhaseArgs a) {{')
+        hv = _heavy_attr(is_heavy(pm), heavy_cap)
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}({lead_sig}, PcPhaseArgs a) {{')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
         parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, false, 0, -1, &ld);')
         parts.append('}')
     if len(model.phases) == 1:
         pm = model.phases[0]
         parts.append("// resident-tail build: block 0 runs the tail beside the tiles, one launch per evaluation")
-        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
+        hv = _heavy_attr(is_heavy(pm), heavy_cap)
+        parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
         parts.append('  const int ntb = (wa >> 28) & 7;   // leading workgroups that run the tail')
         parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
         parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
@@ -349,7 +357,7 @@ def generate_source(model: Model, orders=None) -> str:
         # body takes long to compile once, and such models rarely share tiles.
         static_ws = _static_w_list(pm)
         for wn in static_ws:
-            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{_w2_attr(is_heavy(pm) and wn == 2)}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
+            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
             parts.append('  const int ntb = (wa >> 28) & 7;')
             parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
             parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
@@ -389,11 +397,12 @@ def generate_source(model: Model, orders=None) -> str:
         multi_sig = ("const double* x, const double* lam, double* c, double* G, double* H, const PcPhaseArgs* ph, int flags, "
                      "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tail_blocks")
         parts.append("static_assert(PC_MAX_PHASES + 1 == 9, \"pc_bulk_all spells PcMultiArgs::first_block out\");")
-        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all(' + multi_sig + ') {')
+        hva = _heavy_attr(heavy_any, heavy_cap)
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + hva + 'pc_bulk_all(' + multi_sig + ') {')
         parts += all_body(False)
         parts.append("}")
         parts.append("// the same with the resident tail as block 0")
-        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + 'pc_bulk_all_r(' + multi_sig + ', PcTailArgs t) {')
+        parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + hva + 'pc_bulk_all_r(' + multi_sig + ', PcTailArgs t) {')
         parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
         parts += all_body(True)
         parts.append("}")
@@ -401,8 +410,7 @@ def generate_source(model: Model, orders=None) -> str:
         # build --, W = 4 when every phase is light or medium
         multi_ws = sorted(set.intersection(*[set(_static_w_list(pm)) for pm in model.phases]))
         for wn in multi_ws:
-            heavy_any = any(is_heavy(pm) for pm in model.phases)
-            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{_w2_attr(heavy_any and wn == 2)}pc_bulk_all_r_w{wn}(' + multi_sig + ', PcTailArgs t) {')
+            parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hva}pc_bulk_all_r_w{wn}(' + multi_sig + ', PcTailArgs t) {')
             parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
             parts += all_body(True, wn)
             parts.append("}")
@@ -439,15 +447,20 @@ def _extra_defines() -> list[str]:
     return [d for d in os.environ.get("PYCOLLO_AMD_DEFINES", "").split() if d]
 
 
-def _two_wave_cap() -> bool:
-    """PYCOLLO_AMD_W2_CAP=1: the two-wave kernels of heavy models are compiled with ``amdgpu_waves_per_eu(2)`` -- the
-    register allocator must then fit 256 registers and spills what does not (A/B knob: a few spilled dwords against
-    one wave per SIMD)."""
-    return os.environ.get("PYCOLLO_AMD_W2_CAP", "0") == "1"
+HEAVY_SCRATCH_LIMIT = 128   # bytes per lane a capped heavy kernel may spill before the cap is given up
 
 
-def _w2_attr(heavy: bool) -> str:
-    return "__attribute__((amdgpu_waves_per_eu(2))) " if (heavy and _two_wave_cap() and _waves_per_eu() == 0) else ""
+def _heavy_cap_enabled() -> bool:
+    """PYCOLLO_AMD_HEAVY_CAP=0: never cap the registers of heavy models' kernels (A/B knob)."""
+    return os.environ.get("PYCOLLO_AMD_HEAVY_CAP", "1") != "0" and _waves_per_eu() == 0
+
+
+def _heavy_attr(heavy: bool, cap: bool) -> str:
+    """Heavy models' tile kernels are compiled for two waves per SIMD (``amdgpu_waves_per_eu(2)``: at most 256
+    registers; what does not fit is spilled -- Delta III, order 4: 266 -> 256 registers + 52 B of scratch per lane,
+    29.5 -> 25.9 us at 4 x 12.5 k nodes).  ``build_code_object`` drops the cap again when a kernel spills more than
+    HEAVY_SCRATCH_LIMIT bytes (space station: 472 registers uncapped)."""
+    return "__attribute__((amdgpu_waves_per_eu(2))) " if (heavy and cap) else ""
 
 
 def _occupancy_attr() -> str:
@@ -501,8 +514,8 @@ def code_object_path(model: Model, orders=None) -> str:
         occ += "_fc" + _fp_contract()
     if _preload_count() != 10:
         occ += f"_pl{_preload_count()}"
-    if _two_wave_cap():
-        occ += "_cap2"
+    if not _heavy_cap_enabled() and _waves_per_eu() == 0:
+        occ += "_nocap"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
@@ -528,23 +541,33 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
                            f"first in a plain process (python -c 'import __graft_entry__ as g; g.build()' or one "
                            f"unprofiled run of the same command)")
     src = out[:-6] + ".hip"
-    with open(src, "w") as f:
-        f.write(generate_source(model, orders))
-    # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
-    # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
-           "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
-           f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
-    if verbose:
-        print(res.stderr)
+    import json
+    # Heavy models: first with their tile kernels capped at two waves per SIMD (_heavy_attr); when a capped kernel
+    # spills more than HEAVY_SCRATCH_LIMIT bytes per lane the model does not fit (space station) and the object is
+    # built again without the cap.
+    attempts = [True, False] if (any(is_heavy(pm) for pm in model.phases) and _heavy_cap_enabled()) else [False]
+    for cap in attempts:
+        with open(src, "w") as f:
+            f.write(generate_source(model, orders, heavy_cap=cap))
+        # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
+        # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
+        cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
+               "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
+               f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
+        if verbose:
+            print(res.stderr)
+        resources = _parse_resources(res.stderr)
+        worst = max((k.get("scratch", 0) for name, k in resources.items() if name.startswith("pc_bulk")), default=0)
+        if not cap or worst <= HEAVY_SCRATCH_LIMIT:
+            break
     # what the compiler made of every kernel travels with the object: pc_create's launch shape depends on it (a
     # two-wave build that did not fit 256 registers must not be launched as one)
-    import json
+    resources["_build"] = {"heavy_cap": bool(cap)}
     with open(resources_path(out) + ".tmp", "w") as f:
-        json.dump(_parse_resources(res.stderr), f, indent=1, sort_keys=True)
+        json.dump(resources, f, indent=1, sort_keys=True)
     os.replace(resources_path(out) + ".tmp", resources_path(out))
     os.replace(out + ".tmp", out)
     return out
@@ -589,7 +612,7 @@ def two_wave_occupancy(model: Model, code_object: str) -> int:
     res = code_object_resources(code_object)
     name = "pc_bulk_all_r_w2" if len(model.phases) > 1 else f"pc_bulk_p{model.phases[0].index}_r_w2"
     k = res.get(name)
-    if not k or (k.get("scratch", 1) != 0 and not _two_wave_cap()):
+    if not k or k.get("scratch", HEAVY_SCRATCH_LIMIT + 1) > HEAVY_SCRATCH_LIMIT:
         return 0
     return int(k.get("occupancy", 0))
 

@@ -678,13 +678,29 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         tiles64 += (N + 62) / 63;
         h->two_wave = h->two_wave && P.n_y >= 2;
       }
-      h->two_wave = h->two_wave && tiles64 > 400;
+      // ... and with many more tiles than the chip holds at once the replicas' second evaluation of the node functions
+      // buys nothing: the (split, register-capped) one-wave-per-tile kernel already runs two waves per SIMD
+      int64_t max_tiles = 1 << 30;
+      if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_MAX_TILES")) max_tiles = std::atoll(env);
+      h->two_wave = h->two_wave && tiles64 > 400 && tiles64 <= max_tiles;
     }
     if (h->two_wave) {
-      constexpr int kQuarterCu = (160 * 1024) / 4 - 512;   // four workgroups per CU, one allocation granule to spare
+      // four workgroups per CU: a quarter of the 160 KiB less two allocation granules of 1280 B -- measured, Delta III
+      // 4 x 12.5 k nodes: 37 272 B per workgroup 23.2 us, 39 832 B (nominally still a quarter) 26.8 us
+      constexpr int kQuarterCu = 30 * 1280;
       int tc = 64;
       while (tc > std::max(max_nk, 32) && lds_need(64, tc, 2) > kQuarterCu) --tc;
-      if (lds_need(64, tc, 2) <= kQuarterCu) TC = tc;
+      // ... and every wave of the launch resident at once (2048 wave slots at two per SIMD): with smaller tiles than
+      // that allows, the one-wave-per-tile kernel -- itself two waves per SIMD -- is as fast or faster (Delta III order 6:
+      // 1160 tiles of 45 nodes x 2 waves 34.0 us, 872 tiles x 1 wave 32.2 us; 4 x 25 k nodes, order 5: 42.7 / 42.2 us)
+      int64_t tiles_tc = 0;
+      for (auto& P : Q.ph) {
+        int64_t N = 1, nmax = 2;
+        for (int k = 0; k < P.K; ++k) { N += P.n_k[k] - 1; nmax = std::max<int64_t>(nmax, P.n_k[k]); }
+        const int64_t per_tile = std::max<int64_t>(1, ((tc - 1) / (nmax - 1)) * (nmax - 1));
+        tiles_tc += (N - 1 + per_tile - 1) / per_tile;
+      }
+      if (lds_need(64, tc, 2) <= kQuarterCu && 2 * tiles_tc <= 2048) TC = tc;
       else h->two_wave = false;
     }
     if (const char* env = std::getenv("PYCOLLO_AMD_TILE_NODES")) {
@@ -1494,5 +1510,18 @@ int pc_synchronize(pc_handle* h) {
 }
 
 void* pc_stream(pc_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int pc_read_symbol(pc_handle* h, const char* name, void* dst, size_t bytes) {
+  return guarded([&] {
+    require_device(h);
+    if (!name || !dst) throw std::runtime_error("null symbol name or destination");
+    hipDeviceptr_t p = nullptr;
+    size_t sz = 0;
+    HIP_OK(hipModuleGetGlobal(&p, &sz, h->module, name));
+    if (bytes > sz) throw std::runtime_error("symbol is smaller than the requested read");
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
+  });
+}
 
 }  // extern "C"

@@ -468,6 +468,23 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 #endif
 }
 
+// Diagnostic build only (-DPC_STAMPS, tools/stamps.py): lane 0 of every wave writes the shader clock at a handful of
+// points of the tile body into a device array of the code object -- memory nothing else reads.  Never in a shipped
+// object: the stamps cost a scalar-memory round trip each.
+#ifdef PC_STAMPS
+#ifndef PC_STAMPS_WAVES
+#define PC_STAMPS_WAVES 16384
+#endif
+extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 10];
+#define PC_STAMP(i)                                                                                         \
+  do {                                                                                                      \
+    if ((threadIdx.x & 63) == 0 && pc_stamp_slot < PC_STAMPS_WAVES)                                         \
+      pc_stamps[(size_t)pc_stamp_slot * 10 + (i)] = (i) == 9 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PC_STAMP(i) do { } while (0)
+#endif
+
 // MULTI: one launch covers every phase (pc_bulk_all); KA then lives in device memory and the per-call pointers, the
 // flags and the granule tag arrive as plain values (mx .. mepoch: the members of PcMultiArgs the kernel needs --
 // handed over as a pointer to the struct, a large kernel keeps the whole struct in scratch memory), the workgroup's
@@ -500,6 +517,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // ---- this workgroup's tile and this lane's node, then the node loads, before anything else: with the lead
   //      scalars preloaded (pc_bulk_p<i>) their addresses need no scalar load, so the longest latency of the
   //      prologue starts at the wave's first instructions and everything below overlaps it
+#ifdef PC_STAMPS
+  const int pc_stamp_slot = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+#endif
+  PC_STAMP(0);
+  PC_STAMP(9);   // constant-rate clock at the start (the pair 0 / 9 of two waves gives the shader clock rate)
   const int N = A.N;
   // (a single-phase launch is swizzled here; pc_bulk_all swizzles before it picks the phase and passes `first_block`
   //  relative to the swizzled index, together with that index)
@@ -846,6 +868,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       constexpr int l = decltype(l_)::value;
       v[NZ + l] = sc[St::O_VS + l] * v[NZ + l] + sc[St::O_RS + l];
     });
+    PC_STAMP(1);   // node values have arrived
     if (uni) {
       const int g = node - kp * (un - 1);           // node index relative to the first staged section
       ls_r = (node == 0) ? -1 : (g - 1) / (un - 1);
@@ -986,11 +1009,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // the one-pass kernel spills (space station, 96 partials: 512 VGPRs + 584 B scratch -> 472, no scratch, 58.6 ->
   // 49.2 us at 60k nodes); where it merely lowers the register count the recomputed subexpressions cost more
   // than the occupancy returns (shuttle 194 -> 171 VGPRs: 6 % slower; Delta III 302 -> 218: 3 % slower).
-  // A heavy model whose tiles are shared by two waves with the replica index compiled in (WN = 2, codegen's two-wave
-  // build) is split as well: there the point is not the spill but the register count itself -- at <= 256 VGPRs a SIMD
-  // holds two such waves, each with half a tile's outputs, and one wave issues while the other waits (Delta III:
-  // 308 -> 256 VGPRs, one -> two waves per SIMD, 30.6 -> 23.2 us at 4 x 12.5 k nodes).
-  constexpr bool SPLIT = ((NJ + NH >= PC_SPLIT_MIN) || (WN >= 2 && M::HEAVY)) && St::NWT == 0;   // (time parameters: the t strips need both passes' values)
+  // A heavy model (M::HEAVY, codegen) is split as well, in every build of its tile body: there the point is not the
+  // spill but the register count itself -- at <= 256 VGPRs a SIMD holds two of its waves and one issues while the other
+  // waits (Delta III: 308 -> 256 VGPRs; 4 x 12.5 k nodes, two waves per tile: 30.6 -> 23.2 us; 4 x 50 k: 108 -> 82 us).
+  // Every build, not only the two-wave one: the two passes round differently from the fused evaluation in the last
+  // bits, and the sharded evaluation (two-launch kernels) must return the bits of the unsharded one.
+  constexpr bool SPLIT = ((NJ + NH >= PC_SPLIT_MIN) || M::HEAVY) && St::NWT == 0;   // (time parameters: the t strips need both passes' values)
   constexpr bool RED_EARLY = RES && NS == 0 && NRED > 0;
   double mult[NFN > 0 ? NFN : 1];
   if (active) {
@@ -1024,6 +1048,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // without static parameters every partial sum is an integrand sum and complete here: the resident-tail build
   // publishes them now, a kernel's length ahead of the tail's need for them
   if constexpr (RED_EARLY) deposit_partials();
+  PC_STAMP(2);   // node functions (first pass) evaluated
   node_sync();
 
   // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
@@ -1045,6 +1070,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TN + sk] - v[a]) + stretch * accf[a]);
     });
   }
+  PC_STAMP(3);   // defect values formed, c~ stores issued
   block_sync();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
 
   // number of nodes this tile owns, and the first one (for the staged per-node runs)
@@ -1201,6 +1227,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   }
 
   if constexpr (!SPLIT && !RED_EARLY) deposit_partials();
+  PC_STAMP(4);   // path / integral rows (and, fused build, the Hessian) done
   // ---- Jacobian of the defect rows (compiled.py:305-334), one state at a time:
   //      entries are produced column-wise / row-wise into the staging buffer, then the tile's
   //      contiguous CSR run of that state is written to HBM fully coalesced
@@ -1290,9 +1317,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     });
   }
 
+  PC_STAMP(5);   // Jacobian of the defect rows staged and stored
   if constexpr (SPLIT) {         // second pass: second partials, the Hessian runs built from them, then the sums
     if (wantH && hess_replica) {
       if (active) M::eval_h(v, mult, Hv);
+      PC_STAMP(6);   // second partials evaluated
       hess_second();
     }
     if constexpr (!RED_EARLY) deposit_partials();
@@ -1307,6 +1336,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       A.partials[(int64_t)tile * NRED + tid] = sr;
     }
   }
+  PC_STAMP(7);   // instruction stream done, stores in flight
+#ifdef PC_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  PC_STAMP(8);   // this wave's stores have left
 }
 #undef PC_ITEM
 

@@ -94,22 +94,92 @@ __global__ void kkt_diag(double* __restrict__ vals, const int64_t* __restrict__ 
   *p = fixed[u] ? 1.0 : *p + dvec[u];
 }
 
-// y = K x over natural unknowns, one wave per row of the recipe
-__global__ void kkt_matvec(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const int32_t* __restrict__ kind,
-                           const int32_t* __restrict__ idx, const double* __restrict__ coef, const double* __restrict__ G,
+// y = K x over natural unknowns (rows of the symmetric recipe).  A KKT row of a collocation NLP has 7-14 entries (a
+// node variable: its Hessian band + the defect rows of its section; a multiplier: its Jacobian row), so a wave per row
+// (round 2: 178 us at 30 k rows, < 20 % of the lanes active, four dependent loads per entry in a lane of its own)
+// wastes the machine.  Here 8 lanes share a row: consecutive lanes read consecutive table entries (rows are stored
+// back to back, so a wave's 8 rows are one contiguous stretch of the tables), kind and index travel in ONE word
+// (kind << 30 | index), and the 8 partial sums meet through DPP row shifts.  Rows longer than MV_LONG entries -- the
+// integral / parameter rows with one entry per node -- would serialise 8 lanes over thousands of entries: the host
+// lists them, they are skipped here and done by one workgroup each (kkt_matvec_long).
+constexpr int MV_LANES = 8, MV_LONG = 256;
+__device__ __forceinline__ double mv_entry(unsigned src, double coef, const double* __restrict__ G, const double* __restrict__ H, int use_H) {
+  const unsigned k = src >> 30, idx = src & 0x3fffffffu;
+  const double v = k == SRC_G ? G[idx] : (k == SRC_H ? (use_H ? H[idx] : 0.0) : 1.0);
+  return v * coef;
+}
+// MODE 0: y = K x; MODE 1: y = b - K x (the residual of the iterative refinement)
+template <int MODE>
+__global__ void __launch_bounds__(256) kkt_matvec(const int64_t* __restrict__ ptr, const int32_t* __restrict__ col, const uint32_t* __restrict__ src,
+                           const double* __restrict__ coef, const double* __restrict__ G,
                            const double* __restrict__ H, int use_H, const uint8_t* __restrict__ fixed,
-                           const double* __restrict__ dvec, const double* __restrict__ x, double* __restrict__ y, int64_t nu) {
-  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (row >= nu) return;
+                           const double* __restrict__ dvec, const double* __restrict__ x, const double* __restrict__ b,
+                           double* __restrict__ y, int64_t nu) {
+  const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / MV_LANES;
+  const int lane = threadIdx.x & (MV_LANES - 1);
+  const bool live = row < nu;
+  const int64_t e0 = live ? ptr[row] : 0, e1 = live ? ptr[row + 1] : 0;
+  const bool is_long = e1 - e0 > MV_LONG;
   double acc = 0.0;
-  for (int64_t e = ptr[row] + lane; e < ptr[row + 1]; e += 64) {
-    const int k = kind[e];
-    const double v = k == SRC_G ? G[idx[e]] : (k == SRC_H ? (use_H ? H[idx[e]] : 0.0) : 1.0);
-    acc += v * coef[e] * x[col[e]];
+  if (!is_long)
+    for (int64_t e = e0 + lane; e < e1; e += MV_LANES) acc += mv_entry(src[e], coef[e], G, H, use_H) * x[col[e]];
+  // fixed order: lane i += lane i+1, i+2, i+4 inside its group of 8 (all 64 lanes take part: no divergence here)
+  acc += __shfl_down(acc, 1, MV_LANES);
+  acc += __shfl_down(acc, 2, MV_LANES);
+  acc += __shfl_down(acc, 4, MV_LANES);
+  if (live && lane == 0 && !is_long) {
+    const double v = fixed[row] ? x[row] : acc + dvec[row] * x[row];
+    y[row] = MODE == 0 ? v : b[row] - v;
   }
+}
+template <int MODE>
+__global__ void __launch_bounds__(256) kkt_matvec_long(const int64_t* __restrict__ rows, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
+                                const uint32_t* __restrict__ src, const double* __restrict__ coef,
+                                const double* __restrict__ G, const double* __restrict__ H, int use_H,
+                                const uint8_t* __restrict__ fixed, const double* __restrict__ dvec,
+                                const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
+  __shared__ double part[4];
+  const int64_t row = rows[blockIdx.x];
+  double acc = 0.0;
+  for (int64_t e = ptr[row] + threadIdx.x; e < ptr[row + 1]; e += 256) acc += mv_entry(src[e], coef[e], G, H, use_H) * x[col[e]];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) y[row] = fixed[row] ? x[row] : acc + dvec[row] * x[row];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s = ((part[0] + part[1]) + part[2]) + part[3];
+    const double v = fixed[row] ? x[row] : s + dvec[row] * x[row];
+    y[row] = MODE == 0 ? v : b[row] - v;
+  }
+}
+
+// small vector kernels of the on-device iterative refinement (pc_kkt_solve_refined)
+__global__ void kkt_add(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+// out[0] = sum r^2, out[1] = number of non-finite entries of t: per-block partial sums, then one block in block order
+__global__ void __launch_bounds__(256) kkt_norm_partial(const double* __restrict__ r, const double* __restrict__ t, double* __restrict__ part, int64_t n) {
+  __shared__ double s0[4], s1[4];
+  double a = 0.0, bad = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    a += r[i] * r[i];
+    bad += isfinite(t[i]) ? 0.0 : 1.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); bad += __shfl_down(bad, off, 64); }
+  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = a; s1[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = ((s0[0] + s0[1]) + s0[2]) + s0[3];
+    part[2 * blockIdx.x + 1] = ((s1[0] + s1[1]) + s1[2]) + s1[3];
+  }
+}
+__global__ void kkt_norm_final(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0, bad = 0.0;
+    for (int i = 0; i < nblocks; ++i) { a += part[2 * i]; bad += part[2 * i + 1]; }
+    out[0] = a;
+    out[1] = bad;
+  }
 }
 
 // ---- dense block elimination ------------------------------------------------------------------------------------
@@ -143,14 +213,16 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
     }
     for (int c = tid; c < w; c += nt) rowC[c] = M[(size_t)j * ld + m + c];
     blk_sync<WAVE>();
-    const int rows = m - j - 1, width = rows + w;
-    for (int e = tid; e < rows * width; e += nt) {
-      const int i = j + 1 + e / width, k = e % width;
-      if (k < rows) {
-        const int kk = j + 1 + k;
-        if (kk <= i) M[(size_t)i * ld + kk] -= lcol[i] * colL[kk];
-      } else {
-        M[(size_t)i * ld + m + (k - rows)] -= lcol[i] * rowC[k - rows];
+    // trailing update, two-dimensional: 16 lanes walk a row (its lower-triangle part, then its C part), nt / 16 rows at
+    // a time -- no division per element (the flat e / width, e % width form of round 2 spent most of a leaf's 296 us in
+    // integer division) and neighbouring lanes touch neighbouring LDS words
+    {
+      const int ti = tid >> 4, tk = tid & 15, nrow = nt >> 4;
+      for (int i = j + 1 + ti; i < m; i += nrow) {
+        const double li = lcol[i];
+        double* Mi = M + (size_t)i * ld;
+        for (int kk = j + 1 + tk; kk <= i; kk += 16) Mi[kk] -= li * colL[kk];
+        for (int c = tk; c < w; c += 16) Mi[m + c] -= li * rowC[c];
       }
     }
     for (int i = j + 1 + tid; i < m; i += nt) M[(size_t)i * ld + j] = lcol[i];
@@ -171,15 +243,30 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
       S[e] = -acc;
     }
   blk_sync<WAVE>();
-  for (int e = tid; e < m * w; e += nt) {
-    const int j = e / w, c = e - j * w;
-    M[(size_t)j * ld + m + c] *= dinv[j];
-  }
-  for (int j = m - 1; j > 0; --j) {
-    blk_sync<WAVE>();
-    for (int e = tid; e < j * w; e += nt) {
-      const int i = e / w, c = e - i * w;
-      M[(size_t)i * ld + m + c] -= M[(size_t)j * ld + i] * M[(size_t)j * ld + m + c];
+  // (rows x columns of the C part, two-dimensional again: wc = the power of two that holds w columns)
+  const int wsh = w <= 4 ? 2 : (w <= 8 ? 3 : (w <= 16 ? 4 : (w <= 32 ? 5 : 6)));
+  const int wc = 1 << wsh, ri = tid >> wsh, ci = tid & (wc - 1), rstep = nt >> wsh > 0 ? nt >> wsh : 1;
+  if (w <= 64) {
+    if (ci < w && ri < rstep)
+      for (int j = ri; j < m; j += rstep) M[(size_t)j * ld + m + ci] *= dinv[j];
+    for (int j = m - 1; j > 0; --j) {
+      blk_sync<WAVE>();
+      if (ci < w && ri < rstep) {
+        const double xj = M[(size_t)j * ld + m + ci];
+        for (int i = ri; i < j; i += rstep) M[(size_t)i * ld + m + ci] -= M[(size_t)j * ld + i] * xj;
+      }
+    }
+  } else {   // (wider than a wave: the flat form)
+    for (int e = tid; e < m * w; e += nt) {
+      const int j = e / w, c = e - j * w;
+      M[(size_t)j * ld + m + c] *= dinv[j];
+    }
+    for (int j = m - 1; j > 0; --j) {
+      blk_sync<WAVE>();
+      for (int e = tid; e < j * w; e += nt) {
+        const int i = e / w, c = e - i * w;
+        M[(size_t)i * ld + m + c] -= M[(size_t)j * ld + i] * M[(size_t)j * ld + m + c];
+      }
     }
   }
   blk_sync<WAVE>();
@@ -718,7 +805,12 @@ struct pc_kkt {
   Dev<double> vals, r, leafG, chainG, dvec, vin, vout, src_coef, mv_coef;
   Dev<int64_t> perm, leaf_ptr, chain_ptr, chain_phase_ptr, leaf_left, leafA_off, leafS_off, chainD_off, chainS_off,
       leaf_of_left, leafG_off, chainG_off, dst, run_ptr, diag_pos, mv_ptr;
-  Dev<int32_t> src_kind, src_idx, mv_col, mv_kind, mv_idx;
+  Dev<int32_t> src_kind, src_idx, mv_col;
+  Dev<uint32_t> mv_src;            // kind << 30 | index of every matvec entry
+  Dev<int64_t> mv_long;            // rows with more than MV_LONG entries (one workgroup each)
+  int64_t n_mv_long = 0;
+  Dev<double> w_rhs, w_sol, w_res, w_trial, w_dx, w_dvec, w_part, w_norm;   // on-device iterative refinement
+  Pin<double> h_norm;
   Dev<uint8_t> fixed, chain_last;
   Dev<int> counts;
   Pin<int> h_counts;
@@ -726,6 +818,43 @@ struct pc_kkt {
   KArgs args{};
   bool factored = false;
 };
+
+// the solve chain on the handle's stream, device vectors in natural order (d_rhs is not modified; d_x may alias it)
+static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
+  hipStream_t st = k->stream;
+  const unsigned nbk = (unsigned)((k->nu + 255) / 256);
+  hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, d_rhs, k->perm.p, k->fixed.p, k->r.p, k->nu);
+  if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
+  if (k->chain_cr) {
+    for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
+      const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
+    }
+  } else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+  hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(256), k->lds_border, st, k->args);
+  if (k->chain_cr) {
+    for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
+      const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
+    }
+  } else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+  if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
+  hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, d_x, k->nu);
+  KHIP(hipGetLastError());
+}
+
+// y = K x (MODE 0) or y = b - K x (MODE 1) on the handle's stream, device vectors
+template <int MODE>
+static void matvec_device(pc_kkt* k, int use_hess, const double* d_dvec, const double* d_x, const double* d_b, double* d_y) {
+  hipStream_t st = k->stream;
+  const int64_t threads = k->nu * MV_LANES;
+  hipLaunchKernelGGL(kkt_matvec<MODE>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k->mv_ptr.p, k->mv_col.p,
+                     k->mv_src.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, d_dvec, d_x, d_b, d_y, k->nu);
+  if (k->n_mv_long)
+    hipLaunchKernelGGL(kkt_matvec_long<MODE>, dim3((unsigned)k->n_mv_long), dim3(256), 0, st, k->mv_long.p, k->mv_ptr.p,
+                       k->mv_col.p, k->mv_src.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, d_dvec, d_x, d_b, d_y);
+  KHIP(hipGetLastError());
+}
 
 extern "C" {
 
@@ -767,9 +896,25 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     k->fixed.upload(d->fixed, d->nu);
     k->mv_ptr.upload(d->mv_ptr, d->nu + 1);
     k->mv_col.upload(d->mv_col, d->n_mv);
-    k->mv_kind.upload(d->mv_kind, d->n_mv);
-    k->mv_idx.upload(d->mv_idx, d->n_mv);
+    {
+      std::vector<uint32_t> srcw((size_t)d->n_mv);
+      for (int64_t e = 0; e < d->n_mv; ++e) {
+        if (d->mv_idx[e] < 0 || d->mv_idx[e] >= (1 << 30) || d->mv_kind[e] < 0 || d->mv_kind[e] > 2)
+          throw std::runtime_error("matvec table entry out of range");
+        srcw[e] = ((uint32_t)d->mv_kind[e] << 30) | (uint32_t)d->mv_idx[e];
+      }
+      k->mv_src.upload(srcw.data(), srcw.size());
+      std::vector<int64_t> longs;
+      for (int64_t r = 0; r < d->nu; ++r)
+        if (d->mv_ptr[r + 1] - d->mv_ptr[r] > MV_LONG) longs.push_back(r);
+      k->n_mv_long = (int64_t)longs.size();
+      k->mv_long.upload(longs.data(), longs.size());
+    }
     k->mv_coef.upload(d->mv_coef, d->n_mv);
+    for (auto* w : {&k->w_rhs, &k->w_sol, &k->w_res, &k->w_trial, &k->w_dx, &k->w_dvec}) w->alloc((size_t)d->nu);
+    k->w_part.alloc(2 * 256);
+    k->w_norm.alloc(2);
+    k->h_norm.alloc(2);
     // derived tables
     std::vector<uint8_t> last(d->n_chain, 0);
     for (int64_t p = 0; p < d->n_phase; ++p) last[d->chain_phase_ptr[p + 1] - 1] = 1;
@@ -962,27 +1107,9 @@ int pc_kkt_solve(pc_kkt* k, const double* rhs, double* x) {
     if (!k->factored) throw std::runtime_error("pc_kkt_solve before pc_kkt_factor");
     KHIP(hipSetDevice(k->device));
     hipStream_t st = k->stream;
-    const unsigned nbk = (unsigned)((k->nu + 255) / 256);
     std::memcpy(k->h_a.p, rhs, k->nu * sizeof(double));
     KHIP(hipMemcpyAsync(k->vin.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, k->vin.p, k->perm.p, k->fixed.p, k->r.p, k->nu);
-    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
-    if (k->chain_cr) {
-      for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
-        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
-      }
-    } else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
-    hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(256), k->lds_border, st, k->args);
-    if (k->chain_cr) {
-      for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
-        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
-      }
-    } else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
-    if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
-    hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, k->vout.p, k->nu);
-    KHIP(hipGetLastError());
+    solve_device(k, k->vin.p, k->vout.p);
     KHIP(hipMemcpyAsync(k->h_b.p, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
     KHIP(hipStreamSynchronize(st));
     std::memcpy(x, k->h_b.p, k->nu * sizeof(double));
@@ -996,15 +1123,69 @@ int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, 
     hipStream_t st = k->stream;
     std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
     std::memcpy(k->h_b.p, x, k->nu * sizeof(double));
-    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(k->w_dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     KHIP(hipMemcpyAsync(k->vin.p, k->h_b.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
-    const int64_t threads = k->nu * 64;
-    hipLaunchKernelGGL(kkt_matvec, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k->mv_ptr.p, k->mv_col.p, k->mv_kind.p,
-                       k->mv_idx.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, k->dvec.p, k->vin.p, k->vout.p, k->nu);
-    KHIP(hipGetLastError());
+    matvec_device<0>(k, use_hess, k->w_dvec.p, k->vin.p, nullptr, k->vout.p);
     KHIP(hipMemcpyAsync(k->h_a.p, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));   // (queued behind the kernel that read dvec)
     KHIP(hipStreamSynchronize(st));
     std::memcpy(y, k->h_a.p, k->nu * sizeof(double));
+  });
+}
+
+// Solve K x = rhs with the current factors, refined against the system that has `dvec_true` on its diagonal -- the
+// whole loop of the interior-point method's linear step (solve, residual, up to `max_steps` corrections, each kept
+// only while it at least halves the residual's 2-norm and stays finite) in ONE call: rhs and dvec_true go up once, x
+// comes down once, and per correction only two doubles (the residual norm and a non-finite count) cross the bus.
+// Round 2 made eight host calls of this (k.solve / k.matvec), each with its own vector copies and stream wait.
+int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const double* rhs, int max_steps, double* x,
+                         int32_t* n_solves) {
+  return guarded([&] {
+    if (!k || !dvec_true || !rhs || !x) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_solve_refined before pc_kkt_factor");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    const int64_t nu = k->nu;
+    const unsigned nbk = (unsigned)((nu + 255) / 256);
+    const int nred = (int)std::min<int64_t>(256, (nu + 255) / 256);
+    std::memcpy(k->h_a.p, rhs, nu * sizeof(double));
+    std::memcpy(k->h_b.p, dvec_true, nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->w_rhs.p, k->h_a.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(k->w_dvec.p, k->h_b.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    auto norms = [&](const double* d_r, const double* d_t, double& sumsq, double& bad) {
+      hipLaunchKernelGGL(kkt_norm_partial, dim3(nred), dim3(256), 0, st, d_r, d_t, k->w_part.p, nu);
+      hipLaunchKernelGGL(kkt_norm_final, dim3(1), dim3(64), 0, st, k->w_part.p, nred, k->w_norm.p);
+      KHIP(hipMemcpyAsync(k->h_norm.p, k->w_norm.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      KHIP(hipStreamSynchronize(st));
+      sumsq = k->h_norm.p[0];
+      bad = k->h_norm.p[1];
+    };
+    double* sol = k->w_sol.p;
+    double* res = k->w_res.p;
+    double* trial = k->w_trial.p;
+    double* res_t = k->w_dx.p;      // (the correction is formed in vout, the trial's residual lands here)
+    solve_device(k, k->w_rhs.p, sol);
+    matvec_device<1>(k, use_hess, k->w_dvec.p, sol, k->w_rhs.p, res);
+    int solves = 1;
+    double nres = 0.0, bad = 0.0;
+    if (max_steps > 0) norms(res, sol, nres, bad);
+    for (int it = 0; it < max_steps; ++it) {
+      solve_device(k, res, k->vout.p);
+      hipLaunchKernelGGL(kkt_add, dim3(nbk), dim3(256), 0, st, sol, k->vout.p, trial, nu);
+      matvec_device<1>(k, use_hess, k->w_dvec.p, trial, k->w_rhs.p, res_t);
+      ++solves;
+      double nt = 0.0, bad_t = 0.0;
+      norms(res_t, trial, nt, bad_t);
+      // numpy semantics of the loop this replaces: a NaN norm compares false, i.e. the trial is kept unless it is
+      // non-finite itself or fails to halve the residual
+      if (bad_t > 0.0 || std::sqrt(nt) >= 0.5 * std::sqrt(nres)) break;
+      std::swap(sol, trial);
+      std::swap(res, res_t);
+      nres = nt;
+    }
+    KHIP(hipMemcpyAsync(k->h_b.p, sol, nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    std::memcpy(x, k->h_b.p, nu * sizeof(double));
+    if (n_solves) *n_solves = solves;
   });
 }
 

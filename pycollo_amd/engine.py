@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_check.argtypes = [vp]
+    lib.pc_read_symbol.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.pc_row_norms_jac.argtypes = [vp, vp, vp]
     lib.pc_interp_linear.argtypes = [C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]
     lib.pc_copy_runs.argtypes = [vp, vp, vp, C.c_int64, vp]
@@ -492,6 +493,12 @@ class NlpEngine:
 
     def synchronize(self):
         self._check(self._lib.pc_synchronize(self._h))
+
+    def read_symbol(self, name: str, dtype, count: int):
+        """Diagnostic: ``count`` items of a ``__device__`` array of the code object (``pc_read_symbol``)."""
+        out = np.empty(count, dtype=dtype)
+        self._check(self._lib.pc_read_symbol(self._h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
 
     def check(self):
         """After the caller synchronised its OWN stream (device API): raises if an evaluation's resident tail gave up

@@ -494,16 +494,9 @@ class GpuInteriorPointSolver(InteriorPointSolver):
         """Solve with the current factors, refined against the system with ``dvec_true`` on the diagonal."""
         k = self.kkt
         t0 = time.perf_counter()
-        sol = k.solve(rhs)
-        res = rhs - k.matvec(dvec_true, sol, use_hess)
-        n_solves = 1
-        for _ in range(3):
-            trial = sol + k.solve(res)
-            res_t = rhs - k.matvec(dvec_true, trial, use_hess)
-            n_solves += 1
-            if not np.all(np.isfinite(trial)) or np.linalg.norm(res_t) >= 0.5 * np.linalg.norm(res):
-                break
-            sol, res = trial, res_t
+        # solve, residual and up to three corrections (each kept only while it halves the residual and stays finite) in
+        # one device-side call: the vectors cross the bus once (pc_kkt_solve_refined)
+        sol, n_solves = k.solve_refined(rhs, dvec_true, use_hess, max_steps=3)
         self.times["solve"] += time.perf_counter() - t0
         self.counts["kkt_solves"] = self.counts.get("kkt_solves", 0) + n_solves
         self.counts["refined_solves"] = self.counts.get("refined_solves", 0) + 1

@@ -329,6 +329,7 @@ class GpuKkt:
         lib.pc_kkt_factor.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.pc_kkt_solve.argtypes = [vp, vp, vp]
         lib.pc_kkt_matvec.argtypes = [vp, C.c_int, vp, vp, vp]
+        lib.pc_kkt_solve_refined.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.POINTER(C.c_int32)]
         lib.pc_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         d = _Desc()
         self._keep = []
@@ -378,6 +379,17 @@ class GpuKkt:
         y = np.empty(self.nu)
         self._check(self._lib.pc_kkt_matvec(self._h, int(bool(use_hess)), dvec.ctypes.data, x.ctypes.data, y.ctypes.data))
         return y
+
+    def solve_refined(self, rhs, dvec_true, use_hess=True, max_steps=3):
+        """``K^-1 rhs`` with the current factors, iteratively refined on the device against the system with
+        ``dvec_true`` on its diagonal (``pc_kkt_solve_refined``); returns (x, back-substitutions performed)."""
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        dvec_true = np.ascontiguousarray(dvec_true, dtype=np.float64)
+        x = np.empty(self.nu)
+        n = C.c_int32()
+        self._check(self._lib.pc_kkt_solve_refined(self._h, int(bool(use_hess)), dvec_true.ctypes.data, rhs.ctypes.data,
+                                                   int(max_steps), x.ctypes.data, C.byref(n)))
+        return x, n.value
 
     def close(self):
         if getattr(self, "_h", None):

@@ -88,12 +88,22 @@ def test_generated_source_is_straight_line_fp64():
                                             ("delta_iii", dict(K=10, order=5), (5, 5, 5, 5))])
 def test_kernels_use_no_scratch_memory(name, kw, orders):
     """A run-time subscript into a register array sends the array -- and with it the dispatch -- to scratch memory
-    (it cost the resident-tail kernel 2.5 us of a 4.6 us evaluation before it was found): every bulk / tail kernel of
-    the headline models must compile to zero scratch bytes."""
+    (it cost the resident-tail kernel 2.5 us of a 4.6 us evaluation before it was found; hundreds of bytes per lane):
+    every bulk / tail kernel of the headline models must compile to zero scratch bytes.  One deliberate exception: a
+    HEAVY model's tile kernels are compiled for two waves per SIMD (codegen._heavy_attr) and may spill the few
+    registers past 256 -- at most codegen.HEAVY_SCRATCH_LIMIT bytes, recorded in the object's resource sidecar."""
     from pycollo_amd import codegen, problems
     from pycollo_amd.model import compile_model
-    res = codegen.kernel_resources(compile_model(problems.REGISTRY[name](**kw)), orders)
+    model = compile_model(problems.REGISTRY[name](**kw))
+    res = codegen.code_object_resources(codegen.build_code_object(model, orders))   # what the compiler reported at build time
     assert any(k.endswith("_r") for k in res), sorted(res)
+    heavy = any(codegen.is_heavy(pm) for pm in model.phases)
+    capped = res.get("_build", {}).get("heavy_cap", False)
+    assert capped == (heavy and codegen._heavy_cap_enabled()) or not heavy
     for kern, r in res.items():
-        if kern.startswith(("pc_bulk", "pc_tail")):
+        if kern.startswith("pc_tail") or (kern.startswith("pc_bulk") and not (heavy and capped)):
             assert r["scratch"] == 0, (kern, r)
+        elif kern.startswith("pc_bulk"):
+            assert r["scratch"] <= codegen.HEAVY_SCRATCH_LIMIT and r["occupancy"] >= 2, (kern, r)
+    if name == "delta_iii":   # the two-wave launch kernel of config 5's uniform mesh fits without spilling at all
+        assert res["pc_bulk_all_r_w2"]["scratch"] == 0 and res["pc_bulk_all_r_w2"]["vgprs"] <= 256
