@@ -749,6 +749,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, phase_max_tile_rows(P), std::min(TC, phase_max_tile_rows(P) + 1));   // the largest tile's runs
+      if (const char* env = std::getenv("PYCOLLO_AMD_LDS_ROWS_EXTRA"))   // experiments: staging sized for that many more rows
+        D.lds_out = phase_lds_out(P, phase_max_tile_rows(P) + std::atoi(env), std::min(TC, phase_max_tile_rows(P) + 1));
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
       // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle

@@ -326,15 +326,26 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Cooperative, fully coalesced copy of a staged CSR run from LDS to HBM: 16 B per lane and instruction (1 KiB per
-// wave instruction).  A run starts wherever the CSR layout puts it (8-byte granularity), so lane 0 peels one
-// element when that makes the destination 16-byte aligned; the LDS side is then read as two 8-byte halves.
-#ifdef PC_NT_STORES   // experiment: streaming (non-temporal) stores for the CSR runs
-#define PC_RUN_STORE(p, v) __builtin_nontemporal_store((pc_d2_a16)(v), (p))
+// wave instruction), counted from the run's FIRST element.  A run starts wherever the CSR layout puts it (8-byte
+// granularity): the 16-byte stores are simply issued at that address -- global memory takes them unaligned, a wave's
+// 64 stores still cover one contiguous KiB -- and the LDS side is read as two 8-byte halves.  Every batch of
+// PC_FLUSH_DEPTH wave-instructions issues ALL its LDS reads (lanes past the end masked) before the first store, and the
+// odd last element rides with the first batch: a run costs one LDS round trip per batch and nothing else.  (Round 2
+// peeled an element for alignment, ran the remainder one pair at a time and peeled the tail: up to six exposed LDS
+// round trips per run, ~10 runs per wave -- a third of a tile wave's life at two waves per SIMD.)
+#if defined(PC_EXP_NOSTORE)   // timing experiment: the staged runs are read back from LDS but never stored (results are wrong)
+#define PC_RUN_STORE(p, v) asm volatile("" ::"v"(v), "v"(p))
+#elif defined(PC_NT_STORES)   // experiment: streaming (non-temporal) stores for the CSR runs
+#define PC_RUN_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define PC_RUN_STORE(p, v) (*(p) = (v))
 #endif
 typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+#ifndef PC_FLUSH_DEPTH
+#define PC_FLUSH_DEPTH 4
+#endif
 typedef double pc_d2_a16 __attribute__((ext_vector_type(2), aligned(16)));
+#ifdef PC_FLUSH_PEEL   // A/B: round 2's form -- one element peeled for 16-byte alignment, remainder pair by pair, tail peeled
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
                                           int TB) {
   if (len <= 0) return;
@@ -345,22 +356,49 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
   len -= head;
   const int pairs = len >> 1;
   int e = tid;
-#ifndef PC_FLUSH_DEPTH
-#define PC_FLUSH_DEPTH 4
-#endif
   for (; e + (PC_FLUSH_DEPTH - 1) * TB < pairs; e += PC_FLUSH_DEPTH * TB) {   // LDS reads in flight before the first store issues
     pc_d2_a8 a[PC_FLUSH_DEPTH];
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + q * TB));
 #pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)), a[q]);
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)) = a[q];
   }
   for (; e < pairs; e += TB) {
     const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
-    PC_RUN_STORE(reinterpret_cast<pc_d2_a16*>(dst + 2 * e), a0);
+    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
   }
   if ((len & 1) && tid == TB - 1) dst[len - 1] = src[len - 1];
 }
+#else
+__device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
+                                          int TB) {
+  if (len <= 0) return;
+#ifdef PC_FLUSH_ALIGN   // A/B: peel one element so that the 16-byte stores are 16-byte aligned (read with the first batch too)
+  const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
+  double first = 0.0;
+  if (head && tid == 1) first = src[0];
+  if (head && tid == 1) dst[0] = first;
+  dst += head;
+  src += head;
+  len -= head;
+#endif
+  const int pairs = len >> 1;
+  const bool odd = (len & 1) && tid == 0;
+  double last = 0.0;
+  if (odd) last = src[len - 1];
+  for (int e0 = tid; e0 - tid < pairs; e0 += PC_FLUSH_DEPTH * TB) {   // (uniform trip count: e0 - tid is the batch's first pair)
+    pc_d2_a8 a[PC_FLUSH_DEPTH];
+    // (unconditional reads at clamped indices: a read under `if` makes its register a conditional definition, and the
+    //  compiler then waits for LDS before every single read)
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * min(e0 + q * TB, pairs - 1));
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q)
+      if (e0 + q * TB < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (e0 + q * TB)), a[q]);
+  }
+  if (odd) dst[len - 1] = last;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // bulk kernel
@@ -519,6 +557,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   //      prologue starts at the wave's first instructions and everything below overlaps it
 #ifdef PC_STAMPS
   const int pc_stamp_slot = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+#endif
+#ifdef PC_STAGGER   // experiment: the wave in the odd hardware slot of its SIMD starts PC_STAGGER x 64 clocks late
+  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) {   // HW_REG_HW_ID, WAVE_ID[3:0]
+#pragma unroll 1
+    for (int i_ = 0; i_ < PC_STAGGER; i_ += 16) __builtin_amdgcn_s_sleep(16);   // 16 x 64 clocks a turn
+  }
 #endif
   PC_STAMP(0);
   PC_STAMP(9);   // constant-rate clock at the start (the pair 0 / 9 of two waves gives the shader clock rate)

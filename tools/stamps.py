@@ -54,28 +54,28 @@ def main():
         eng.evaluate_all_device(x, 1.0, lam, c, G, H)
         eng.synchronize()
         st = eng.read_symbol("pc_stamps", np.uint64, n_waves * 10).reshape(n_waves, 10).astype(np.int64)
-        st = st[st[:, 0] > 0]
-        live = st[st[:, 7] > 0]
-        if rep < 2 or len(live) == 0:
+        live = st[(st[:, 0] > 0) & (st[:, 7] > 0)]
+        if rep >= 2 and len(live):
+            rows.append(live)
+    live = np.concatenate(rows, axis=0)
+    # s_memtime counts per XCD (the counters of different XCDs are not aligned): durations are taken per wave; the wave
+    # starts are placed with the constant 100 MHz counter (stamp 9, 10 ns a tick), which is global
+    rel = live[:, :9] - live[:, :1]
+    start_us = (live[:, 9] - live[:, 9].min()) * 0.01
+    life = rel[:, 8]
+    print(f"{len(live)} tile waves stamped over {len(rows)} launches; wave starts spread over {np.percentile(start_us % 1e6, 99):.2f} us "
+          f"(launch-relative, p99); wave life: median {np.median(life):.0f} ticks, p10 {np.percentile(life, 10):.0f}, p90 {np.percentile(life, 90):.0f}")
+    print(f"{'phase (between stamps)':58s} {'median':>8s} {'p10':>8s} {'p90':>8s} {'share':>6s}")
+    names = ["0-1 wave start -> node values arrived", "1-2 node functions, first pass", "2-3 defect values, c~ stores",
+             "3-4 path / integral rows (+ Hessian, fused build)", "4-5 Jacobian of the defect rows: staged + stored",
+             "5-6 second partials (split build)", "6-7 Hessian runs from them, sums", "7-8 own stores drained"]
+    prev = 0
+    for i in range(1, 9):
+        if np.all(rel[:, i] <= 0):      # a stamp this build does not have
             continue
-        t0 = live[:, 0].min()
-        # shader clock rate from the constant 100 MHz counter (stamp 9) between the first and the last wave start
-        i0, i1 = np.argmin(live[:, 0]), np.argmax(live[:, 0])
-        dreal = live[i1, 9] - live[i0, 9]
-        ghz = (live[i1, 0] - live[i0, 0]) / max(dreal, 1) * 0.1 if dreal > 0 else 2.1
-        rows.append(((live[:, :9] - t0) / (ghz * 1e3), ghz, len(live)))
-    ghz = np.median([r[1] for r in rows])
-    print(f"shader clock {ghz:.2f} GHz, {rows[0][2]} tile waves stamped, {len(rows)} launches; offsets from the first wave start, us")
-    print(f"{'stamp':46s} {'p10':>7s} {'median':>7s} {'p90':>7s} {'max':>7s}")
-    allv = np.concatenate([r[0] for r in rows], axis=0)
-    for i, nm in enumerate(NAMES):
-        col = allv[:, i]
-        col = col[col > -1e6]
-        if np.all(allv[:, i] <= 0) and i not in (0,):
-            continue
-        print(f"{nm:46s} {np.percentile(col, 10):7.2f} {np.median(col):7.2f} {np.percentile(col, 90):7.2f} {col.max():7.2f}")
-    d = np.diff(allv[:, :9], axis=1)
-    print("durations between consecutive stamps, median us:", " ".join(f"{np.median(d[:, i]):.2f}" for i in range(8)))
+        d = rel[:, i] - rel[:, prev]
+        print(f"{names[i - 1]:58s} {np.median(d):8.0f} {np.percentile(d, 10):8.0f} {np.percentile(d, 90):8.0f} {np.median(d) / np.median(life):6.1%}")
+        prev = i
     eng.close()
 
 
