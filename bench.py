@@ -85,6 +85,69 @@ def host_leg(eng, x_np, lam_np, n_calls: int):
             "by_mode": by_mode}
 
 
+def sharded_config_lines(world, rank, local_rank, dev, tstream, args):
+    """BASELINE.json configs[3] and configs[4] -- the configurations the north_star shards -- on the same N ranks, beside
+    the headline line: whole-NLP evaluations per second (strong scaling: the mesh is fixed), the time of the exchange
+    alone, the time of this launch's tile kernels on the slowest rank and their HBM fraction.  Every rank runs this (it
+    contains collectives); rank 0 reports.  Serial and overlapped exchange, padded all-gather and all-gatherv."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pycollo_amd import problems
+    from pycollo_amd.sharding import ShardedNlp
+    lines = []
+    for label, name, kw in (("config 4: shuttle, 20000 sections x 4 nodes", "shuttle", dict(K=20000, order=4)),
+                            ("config 5: Delta III, 4 phases x 3125 sections x 5 nodes", "delta_iii", dict(K=3125, order=5))):
+        sh = ShardedNlp(problems.REGISTRY[name](**kw), device=local_rank)
+        lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+        x = torch.from_numpy(np.random.default_rng(1234).uniform(lo, hi, sh.num_x)).to(dev)
+        lam = torch.from_numpy(np.random.default_rng(1235).normal(size=sh.num_c)).to(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def timed(fn, n):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            with torch.cuda.stream(tstream):
+                e0.record(tstream)
+                for _ in range(n):
+                    fn()
+                e1.record(tstream)
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / n], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item()) * 1e3   # us, slowest rank
+
+        def run(**kk):
+            with torch.cuda.stream(tstream):
+                sh.evaluate_all_device(x, 1.0, lam, tstream.cuda_stream, **kk)
+
+        def bulk():
+            sh.engine.launch_bulk_only(x, lam, sh.c, sh.G, sh.H, tstream.cuda_stream)
+
+        def exch():
+            with torch.cuda.stream(tstream):
+                sh.exchange.run(sh.buf)
+
+        n = 30
+        t_serial = timed(lambda: run(), n)
+        t_overlap = timed(lambda: run(overlap=True), n)
+        t_unpadded = timed(lambda: run(unpadded=True), n)
+        t_root = timed(lambda: run(root=0), n)
+        t_bulk = timed(bulk, n)
+        t_exch = timed(exch, n)
+        lines.append({"workload": label, "nodes": int(sum(pl.N for pl in sh.engine.layout.phases)), "n_gpus": world,
+                      "evals_per_s": round(1e6 / min(t_serial, t_overlap), 1),
+                      "us_per_eval": {"serial_exchange": round(t_serial, 1), "exchange_overlapping_hessian_tiles": round(t_overlap, 1),
+                                      "all_gatherv_unpadded": round(t_unpadded, 1), "gather_to_rank0": round(t_root, 1)},
+                      "exchange_us": round(t_exch, 1), "exchange_bytes_per_rank": int(8 * sh.plan.maxlen * world),
+                      "rank_tile_kernels_us": round(t_bulk, 2),
+                      "rank_hbm_fraction": round(sh.local_algorithmic_bytes / (t_bulk * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                      "rank_algorithmic_bytes": int(sh.local_algorithmic_bytes)})
+        sh.engine.close()
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +170,9 @@ def main():
     ap.add_argument("--generic", action="store_true", help="use the any-mesh kernels (no order specialisation)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N > 1 on one GPU")
     ap.add_argument("--check", action="store_true", help="N > 1: compare the sharded result with an unsharded one")
+    ap.add_argument("--overlap", action="store_true", help="N > 1: exchange the c / G runs while the H tiles still run (two tile launches)")
+    ap.add_argument("--unpadded", action="store_true", help="N > 1: all-gatherv (one broadcast per rank at its exact length) instead of the padded all-gather")
+    ap.add_argument("--no-sharded-configs", action="store_true", help="N > 1: skip the config-4 / config-5 lines (BASELINE.json configs[3], configs[4])")
     args = ap.parse_args()
 
     import numpy as np
@@ -202,7 +268,7 @@ def main():
         root = 0 if args.gather_root else None
 
         def step():
-            sh.evaluate_all_device(x, 1.0, lam, stream, root)
+            sh.evaluate_all_device(x, 1.0, lam, stream, root, overlap=args.overlap, unpadded=args.unpadded)
 
         def bulk_only():   # this rank's tiles only
             sh.engine.launch_bulk_only(x, lam, sh.c, sh.G, sh.H, stream)
@@ -213,7 +279,7 @@ def main():
             rG = torch.empty(ref.nnz_jac, dtype=torch.float64, device=dev)
             rH = torch.empty(ref.nnz_hess, dtype=torch.float64, device=dev)
             ref.evaluate_all_device(x, 1.0, lam, rc, rG, rH, stream)
-            c_, G_, H_ = sh.evaluate_all_device(x, 1.0, lam, stream)
+            c_, G_, H_ = sh.evaluate_all_device(x, 1.0, lam, stream, overlap=args.overlap, unpadded=args.unpadded)
             torch.cuda.synchronize()
             def same(a, b):   # bit for bit, NaN == NaN (a random point may leave a model's domain)
                 return bool(torch.equal(torch.nan_to_num(a, nan=1.25e300), torch.nan_to_num(b, nan=1.25e300)))
@@ -236,6 +302,7 @@ def main():
                  "exchange": ("one gather to rank 0 per evaluation" if args.gather_root else "one all_gather_into_tensor per evaluation")
                              + " (CSR runs of c, G, H + per-tile partial sums)",
                  "exchange_padding_fraction": round(sh.plan.padding_fraction, 4),
+                 "exchange_overlapped_with_hessian_tiles": bool(args.overlap), "exchange_unpadded": bool(args.unpadded),
                  "backend": dist.get_backend(), "world_size": dist.get_world_size()}
         assert dist.get_world_size() == world == args.gpus
 
@@ -356,6 +423,9 @@ def main():
         calls = int(max(20, min(args.host_calls, 4e9 / per_call)))
         host = host_leg(eng, x.cpu().numpy(), lam.cpu().numpy(), calls)
 
+    sharded_configs = None
+    if world > 1 and not args.no_sharded_configs:
+        sharded_configs = sharded_config_lines(world, rank, local_rank, dev, tstream, args)
     if rank == 0:
         out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6),
@@ -365,6 +435,8 @@ def main():
                "config": {"workload": workload, **extra}}
         if world > 1 and args.scaling == "weak":
             out["shard_evals_per_s"] = round(evals_per_s * world, 2)
+        if sharded_configs is not None:
+            out["sharded_configs"] = sharded_configs
         if roofline is not None:
             out["roofline"] = roofline
         if host is not None:

@@ -213,6 +213,11 @@ int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nre
 /* redirect the per-tile partial sums of one phase, double [n_tiles][nred], into caller-owned device
  * memory so that they can travel in the same all-gather as the output segments (NULL = internal) */
 int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials);
+/* the tile kernels for a subset of the outputs (flags: 1 = g rows, 2 = jac_g, 4 = hess; the tiles' partial sums are
+ * produced by whichever launch computes their source: integrand sums with g, parameter sums with hess).  Lets a
+ * sharded evaluation start the exchange of g / jac_g while the tiles of hess still run (pycollo_amd/sharding.py). */
+int pc_launch_bulk_flags_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,
+                                double* d_hess, int flags, void* stream);
 int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
                           double* d_jac, double* d_hess, void* stream);
 int pc_synchronize(pc_handle* h);

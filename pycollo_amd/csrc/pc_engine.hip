@@ -1070,6 +1070,16 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
   });
 }
 
+int pc_launch_bulk_flags_device(pc_handle* h, const double* d_x, const double* d_lambda, double* d_g, double* d_jac,
+                                double* d_hess, int flags, void* stream) {
+  return guarded([&] {
+    require_device(h);
+    if (flags & ~(PC_FLAG_C | PC_FLAG_G | PC_FLAG_H)) throw std::runtime_error("flags must be a combination of 1 (g), 2 (jac_g), 4 (hess)");
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, flags, st, 1.0, true, false);
+  });
+}
+
 int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
                           double* d_jac, double* d_hess, void* stream) {
   return guarded([&] {

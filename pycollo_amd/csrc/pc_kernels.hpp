@@ -376,8 +376,8 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #ifdef PC_FLUSH_ALIGN   // A/B: peel one element so that the 16-byte stores are 16-byte aligned (read with the first batch too)
   const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
   double first = 0.0;
+  double* const dst0 = dst;
   if (head && tid == 1) first = src[0];
-  if (head && tid == 1) dst[0] = first;
   dst += head;
   src += head;
   len -= head;
@@ -397,6 +397,9 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
       if (e0 + q * TB < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (e0 + q * TB)), a[q]);
   }
   if (odd) dst[len - 1] = last;
+#ifdef PC_FLUSH_ALIGN
+  if (head && tid == 1) dst0[0] = first;
+#endif
 }
 #endif
 

@@ -108,6 +108,7 @@ def load_library() -> C.CDLL:
     lib.pc_eval_all_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
     lib.pc_launch_bulk_device.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     lib.pc_launch_tail_device.argtypes = [vp, vp, C.c_double, vp, vp, vp, vp, vp]
+    lib.pc_launch_bulk_flags_device.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.pc_set_tile_range.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.pc_phase_tiles.argtypes = [vp, C.c_int, _i32p, _i32p, vp]
     lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
@@ -458,6 +459,13 @@ class NlpEngine:
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
         self._check(self._lib.pc_launch_bulk_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
                                                     stream))
+
+    def launch_bulk_flags(self, d_x, d_lam, d_c, d_G, d_H, flags: int, stream=None):
+        """The tile kernels for a subset of the outputs: ``flags`` = 1 (c~) | 2 (G~) | 4 (H~)."""
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._check(self._lib.pc_launch_bulk_flags_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
+                                                          int(flags), stream))
 
     def launch_tail_only(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None):
         def addr(t):

@@ -127,6 +127,25 @@ class ShardPlan:
         # share of the gathered buffer that is padding (all_gather_into_tensor moves equal-sized pieces)
         self.padding_fraction = 1.0 - sum(self.lengths) / max(1, world * self.maxlen)
 
+    def split(self):
+        """The plan as two exchanges: (c~ and G~ runs) and (H~ runs + per-tile partial sums).  The first can travel
+        while the tiles of H~ are still being computed (``ShardedNlp.evaluate_all_device(overlap=True)``)."""
+        cut = self.num_c + self.nnz_G
+        return (_SubPlan(self.world, [[(a, b) for a, b in seg if a < cut] for seg in self.segments]),
+                _SubPlan(self.world, [[(a, b) for a, b in seg if a >= cut] for seg in self.segments]))
+
+
+class _SubPlan:
+    """A subset of a plan's segments with the attributes SegmentExchange reads."""
+
+    def __init__(self, world, segments):
+        self.world, self.segments = world, segments
+        self.index = [np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in s]) if s else np.zeros(0, np.int64)
+                      for s in segments]
+        self.lengths = [len(i) for i in self.index]
+        self.maxlen = max(self.lengths) if self.lengths else 0
+        self.padding_fraction = 1.0 - sum(self.lengths) / max(1, world * self.maxlen)
+
 
 def _chunk_table(runs, chunk: int) -> np.ndarray:
     """[(src offset, dst offset, length)] of contiguous runs, cut into pieces of at most ``chunk`` elements."""
@@ -188,20 +207,31 @@ class SegmentExchange:
         if not self.lib.pc_copy_runs(src.data_ptr(), dst.data_ptr(), tab.data_ptr(), tab.shape[0], stream):
             raise RuntimeError("pc_copy_runs failed: " + self.lib.pc_last_error().decode())
 
-    def run(self, buf, root=None):
+    def run(self, buf, root=None, unpadded=False):
         """Exchange in place.  ``root=None``: all-gather, every rank ends with the complete buffer.  ``root=r``: gather
-        to rank r only (the rank an NLP solver lives on): the other ranks send their share and keep their own."""
+        to rank r only (the rank an NLP solver lives on): the other ranks send their share and keep their own.
+        ``unpadded``: the all-gather in its list form, every rank's piece at its exact length (an all-gatherv: no padding
+        to the longest share; RCCL runs it as a group of broadcasts -- an A/B switch, the padded single-buffer form is
+        the default)."""
         import torch.distributed as dist
         torch = self.torch
         n = self.idx_me.numel()
+        if self.world > 1 and max(self.plan.lengths) == 0:
+            return buf
         if root is not None:
             if buf.is_cuda:
                 self._copy_runs(buf, self.send, self.pack_tab)
             elif n:
                 torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
             ml = self.maxlen
-            pieces = [self.recv[q * ml:(q + 1) * ml] for q in range(self.world)] if self.rank == root else None
-            dist.gather(self.send, pieces, dst=root, group=self.group)
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal (ranks sharing one GPU): through the host
+                pieces = [torch.empty(ml, dtype=self.recv.dtype) for _ in range(self.world)] if self.rank == root else None
+                dist.gather(self.send.cpu(), pieces, dst=root, group=self.group)
+                if self.rank == root:
+                    self.recv.copy_(torch.cat(pieces))
+            else:
+                pieces = [self.recv[q * ml:(q + 1) * ml] for q in range(self.world)] if self.rank == root else None
+                dist.gather(self.send, pieces, dst=root, group=self.group)
             if self.rank == root:
                 if buf.is_cuda:
                     self._copy_runs(self.recv, buf, self.unpack_tab)
@@ -218,6 +248,17 @@ class SegmentExchange:
             recv = torch.empty(self.recv.shape, dtype=self.recv.dtype)
             dist.all_gather_into_tensor(recv, self.send.cpu(), group=self.group)
             self.recv.copy_(recv)
+        elif unpadded:
+            ml = self.maxlen
+            # all-gatherv as one broadcast per rank at its exact length (what the list form of all_gather is on RCCL;
+            # gloo's insists on equal sizes)
+            for q in range(self.world):
+                nq = self.plan.lengths[q]
+                if nq:
+                    piece = self.recv[q * ml:q * ml + nq]
+                    if q == self.rank:
+                        piece.copy_(self.send[:nq])
+                    dist.broadcast(piece, src=dist.get_global_rank(self.group, q) if self.group is not None else q, group=self.group)
         else:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         if buf.is_cuda:
@@ -250,6 +291,11 @@ class ShardedNlp:
             tb, te = plan.tile_ranges[self.rank][ip]
             eng.set_tile_range(ip, tb, te)
         self.exchange = SegmentExchange(plan, self.rank, dev, group)
+        cg, hp = plan.split()
+        self.exchange_cg = SegmentExchange(cg, self.rank, dev, group)
+        self.exchange_h = SegmentExchange(hp, self.rank, dev, group)
+        self.cstream = torch.cuda.Stream(device=dev)       # the exchange's own stream when it overlaps the H~ tiles
+        self._ev = [torch.cuda.Event() for _ in range(3)]
         # kernels, torch pack/unpack ops and the collective must share ONE non-default stream (the C ABI maps a
         # NULL stream to the handle's private stream)
         self.tstream = torch.cuda.Stream(device=dev)
@@ -257,18 +303,41 @@ class ShardedNlp:
         # algorithmic bytes this rank's kernels move per evaluation: its share of the outputs + the inputs it reads
         self.local_algorithmic_bytes = 8 * (plan.lengths[self.rank] + (eng.num_x + eng.num_c) // self.world)
 
-    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None, root=None):
+    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None, root=None, overlap=False, unpadded=False):
         """Asynchronous on the torch stream that is current when called (must not be the default stream);
         falls back to this object's own stream.  ``root``: gather to that rank only (it alone finishes the evaluation
-        and holds the complete c~, G~, H~); default: every rank does."""
+        and holds the complete c~, G~, H~); default: every rank does.
+
+        ``overlap``: the tiles are launched twice -- c~ / G~ first, H~ second -- and the exchange of the c~ / G~ runs
+        (four fifths of the bytes) travels on a second stream while the H~ tiles run; the H~ runs and the partial sums
+        follow, then the tail.  Same bits as the serial form (the tile kernels compute an output the same way whatever
+        else the launch computes); the price is a second evaluation of the node functions."""
         import torch
         cur = torch.cuda.current_stream()
         ts = cur if cur.cuda_stream != 0 else self.tstream
         eng = self.engine
+        if overlap and self.world > 1:
+            e1, e2, e3 = self._ev
+            with torch.cuda.stream(ts):
+                eng.launch_bulk_flags(d_x, d_lam, self.c, self.G, self.H, 1 | 2, ts.cuda_stream)
+                e1.record(ts)
+                eng.launch_bulk_flags(d_x, d_lam, self.c, self.G, self.H, 4, ts.cuda_stream)
+                e2.record(ts)
+            with torch.cuda.stream(self.cstream):
+                self.cstream.wait_event(e1)
+                self.exchange_cg.run(self.buf, root, unpadded)
+                self.cstream.wait_event(e2)
+                self.exchange_h.run(self.buf, root, unpadded)
+                e3.record(self.cstream)
+            with torch.cuda.stream(ts):
+                ts.wait_event(e3)
+                if root is None or self.rank == root:
+                    eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+            return self.c, self.G, self.H
         with torch.cuda.stream(ts):
             eng.launch_bulk_only(d_x, d_lam, self.c, self.G, self.H, ts.cuda_stream)
             if self.world > 1:
-                self.exchange.run(self.buf, root)
+                self.exchange.run(self.buf, root, unpadded)
             if root is None or self.rank == root:
                 eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
         return self.c, self.G, self.H

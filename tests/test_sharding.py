@@ -52,19 +52,18 @@ def test_plan_partitions_bulk_outputs(built, name, kw, world):
     assert {i for i in got if eng.num_c <= i < eng.num_c + eng.nnz_jac} == set(g_pos.tolist())
     # H: whole-row runs may carry endpoint extras of the edge rows (the tail rewrites those), never fewer
     h_got = {i for i in got if eng.num_c + eng.nnz_jac <= i < oP}
-    assert set(h_pos.tolist()) - h_got <= _tail_rewritten(eng)
+    assert set(h_pos.tolist()) <= h_got
+    # the split plan (c~ / G~ runs | H~ runs + partial sums) is the same partition in two parts
+    cg, hp = plan.split()
+    for r in range(world):
+        np.testing.assert_array_equal(np.sort(np.concatenate([cg.index[r], hp.index[r]])), np.sort(plan.index[r]))
+        assert np.all(cg.index[r] < eng.num_c + eng.nnz_jac) and np.all(hp.index[r] >= eng.num_c + eng.nnz_jac)
     # all partial sums travel
     assert {i for i in got if i >= oP} == set(range(oP, plan.total))
     # tile ranges tile every phase exactly
     for ip, (k0, _) in enumerate(plan.tiles):
         rs = [plan.tile_ranges[r][ip] for r in range(world)]
         assert rs[0][0] == 0 and rs[-1][1] == len(k0) - 1 and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
-
-
-def _tail_rewritten(eng):
-    """Strip positions that coincide with endpoint-Hessian entries of non-owned kind cannot exist; the only
-    H positions the plan may legitimately omit are none -- return the empty set (kept for clarity)."""
-    return set()
 
 
 def _free_port():
@@ -82,7 +81,7 @@ def _ragged(prob, K, seed=7):
     return prob
 
 
-def _worker(rank, world, port, name, kw, q, root=None):
+def _worker(rank, world, port, name, kw, q, root=None, mode="single"):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -101,7 +100,11 @@ def _worker(rank, world, port, name, kw, q, root=None):
         buf = torch.full((plan.total,), float("nan"), dtype=torch.float64)
         mine = torch.from_numpy(plan.index[rank])
         buf[mine] = torch.from_numpy(ref)[mine]                      # what this rank's bulk kernels produce
-        SegmentExchange(plan, rank, torch.device("cpu")).run(buf, root)
+        if mode == "split":      # the overlapped form's two exchanges: c~ / G~ runs, then H~ runs + partial sums
+            for sub in plan.split():
+                SegmentExchange(sub, rank, torch.device("cpu")).run(buf, root)
+        else:
+            SegmentExchange(plan, rank, torch.device("cpu")).run(buf, root, unpadded=(mode == "unpadded"))
         allidx = np.concatenate(plan.index)
         if root is None or rank == root:
             ok = bool(np.array_equal(buf.numpy()[allidx], ref[allidx]))
@@ -116,16 +119,19 @@ def _worker(rank, world, port, name, kw, q, root=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,kw,root", [("two_phase_transfer", dict(K=40, order=4), None),
-                                          ("hypersensitive", dict(K=300, order=6), None),
-                                          ("delta_iii", dict(K=37, order=4, ragged=True), None),      # ph-refined style mesh
-                                          ("shuttle", dict(K=90, order=4, ragged=True), 0)])          # gather to rank 0
-def test_exchange_world2_gloo(built, name, kw, root):
+@pytest.mark.parametrize("name,kw,root,mode", [("two_phase_transfer", dict(K=40, order=4), None, "single"),
+                                               ("hypersensitive", dict(K=300, order=6), None, "single"),
+                                               ("delta_iii", dict(K=37, order=4, ragged=True), None, "single"),      # ph-refined style mesh
+                                               ("shuttle", dict(K=90, order=4, ragged=True), 0, "single"),           # gather to rank 0
+                                               ("delta_iii", dict(K=37, order=4, ragged=True), None, "split"),       # overlapped form
+                                               ("two_phase_transfer", dict(K=40, order=4), 1, "split"),
+                                               ("shuttle", dict(K=90, order=4, ragged=True), None, "unpadded")])     # all-gatherv
+def test_exchange_world2_gloo(built, name, kw, root, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, kw, q, root)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, kw, q, root, mode)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
