@@ -276,9 +276,6 @@ def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) ->
     heavy_any = any(is_heavy(pm) for pm in model.phases)
     parts = [f"// generated by pycollo_amd.codegen for model '{model.name}' digest {model.digest} -- do not edit",
              '#include "pc_kernels.hpp"',
-             "#ifdef PC_STAMPS   // diagnostic build (tools/stamps.py): per-wave clock stamps of the tile body",
-             'extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 10] = {};',
-             "#endif",
              "",
              "template <int N> __device__ __forceinline__ double pc_powi(double x) {",
              "  double r = 1.0;",

@@ -516,11 +516,11 @@ __device__ __forceinline__ int xcd_major(int b, int nb) {
 #ifndef PC_STAMPS_WAVES
 #define PC_STAMPS_WAVES 16384
 #endif
-extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 10];
+extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 24];
 #define PC_STAMP(i)                                                                                         \
   do {                                                                                                      \
     if ((threadIdx.x & 63) == 0 && pc_stamp_slot < PC_STAMPS_WAVES)                                         \
-      pc_stamps[(size_t)pc_stamp_slot * 10 + (i)] = (i) == 9 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+      pc_stamps[(size_t)pc_stamp_slot * 24 + (i)] = (i) == 9 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define PC_STAMP(i) do { } while (0)
@@ -1357,10 +1357,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         }
       }
       stage_sync();
+      if constexpr (a < 7) PC_STAMP(10 + 2 * a);   // state a's block produced into the staging buffer
       const int len = (int)((long long)Da * (E1 - E0)) + Ca * T;
       const int64_t g0 = goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
       flush_run(A.G + g0, s_out, len, t, TN);
       stage_sync();
+      if constexpr (a < 7) PC_STAMP(11 + 2 * a);   // ... read back and its stores issued
     });
   }
 

@@ -172,11 +172,16 @@ class MeshIteration:
             # can send the filter line search into its restoration phase on one path and not on the other.  A failed
             # GPU-factorised solve is repeated once with the host factorisation before the mesh iteration is given up;
             # the result says so.
-            first = res.status
+            import warnings
+            first, first_seconds, first_iterations = res.status, res.seconds, res.iterations
+            warnings.warn(f"the GPU-factorised interior-point solve ended with '{first}' after {first_iterations} iterations; "
+                          f"repeating this NLP with the host factorisation", RuntimeWarning, stacklevel=2)
             solver = InteriorPointSolver(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
                                          tol=tol, max_iter=max_iter, verbose=verbose, warm_start=warm_start)
             res = solver.solve(self.guess_x_tilde)
-            res.evaluations["gpu_linear_solver_gave_up"] = first
+            res.evaluations["gpu_linear_solver_gave_up"] = first     # never silent: a warning, this flag, OcpResult's list
+            res.seconds += first_seconds                              # both attempts are this mesh iteration's time
+            res.evaluations["gpu_first_attempt_iterations"] = first_iterations
         self.result = res
         self.x_tilde = res.x
         self.objective = res.objective / self.w                                 # scaling.py:186-189

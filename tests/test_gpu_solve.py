@@ -17,6 +17,7 @@ def test_brachistochrone_solution(built):
     res = solve_ocp(problems.brachistochrone())
     GPOPS_II_SOLUTION = 0.82434
     assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-4, atol=0.0)
+    assert res.gpu_linear_solver_gave_up == []
     assert res.mesh_tolerance_met is True
     np.testing.assert_allclose(res.objective, 0.8243386694458454, rtol=1e-9)     # tests/unit/test_iteration.py:305-318
 
@@ -26,6 +27,7 @@ def test_hypersensitive_solution(built):
     res = solve_ocp(problems.hypersensitive())
     GPOPS_II_SOLUTION = 3.36206
     assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-5, atol=0.0)
+    assert res.gpu_linear_solver_gave_up == []
     assert res.mesh_tolerance_met is True
     assert res.mesh_iterations <= 10                                             # settings.max_mesh_iterations default
 
@@ -37,18 +39,28 @@ def test_space_shuttle_solution(built):
     GPOPS_II_SOLUTION, SOS_SOLUTION = -0.59628, -0.59588
     assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-3, atol=0.0)
     assert np.isclose(res.objective, SOS_SOLUTION, rtol=1e-3, atol=0.0)
+    assert res.gpu_linear_solver_gave_up == []
     assert res.mesh_tolerance_met is True
 
 
 def test_free_flying_robot_solution(built):
-    """tests/integration/test_free_flying_robot.py:186-204 (mesh tolerance 1e-5, at most 15 mesh iterations).  The
-    reference asserts rtol = 1e-4 against 7.9101902 / 7.910154646; the stand-in solver stops on a bang-bang solution
-    1.5e-4 above them (7.91138), so the tolerance here is 5e-4 -- a statement about the stand-in, not the callbacks."""
+    """tests/integration/test_free_flying_robot.py:186-204.  At the reference's settings (mesh tolerance 1e-5, at most 15
+    mesh iterations) the refinement stops on a ~100-node mesh whose NLP optimum is 7.9113: a bang-bang solution's
+    objective moves by +-7e-4 from one such mesh to the next (7.9109 .. 7.9122 over the last six meshes), so which side
+    of the reference's rtol = 1e-4 the run ends on is decided by the mesh sequence, i.e. by the NLP solver's iterates
+    (IPOPT there, the stand-in here) -- 5e-4 is asserted at those settings.  That the path converges to the published
+    value is asserted where it can be: with the mesh tolerance one decade tighter the run ends at 7.91027, inside the
+    reference's own rtol = 1e-4 of both published values."""
     from pycollo_amd.solve import solve_ocp
     res = solve_ocp(problems.free_flying_robot(), mesh_tolerance=1e-5, max_mesh_iterations=15)
     assert np.isclose(res.objective, 7.9101902, rtol=5e-4, atol=0.0)
     assert np.isclose(res.objective, 7.910154646, rtol=5e-4, atol=0.0)
     assert res.mesh_tolerance_met is True
+    assert res.gpu_linear_solver_gave_up == []          # every NLP was solved with the GPU factorisation
+    fine = solve_ocp(problems.free_flying_robot(), mesh_tolerance=1e-6, max_mesh_iterations=20)
+    assert np.isclose(fine.objective, 7.9101902, rtol=1e-4, atol=0.0)      # the reference's assertion, verbatim
+    assert np.isclose(fine.objective, 7.910154646, rtol=1e-4, atol=0.0)
+    assert fine.mesh_tolerance_met is True and fine.gpu_linear_solver_gave_up == []
 
 
 def test_space_station_solution(built):
@@ -58,18 +70,20 @@ def test_space_station_solution(built):
     GPOPS_II_SOLUTION, SOS_SOLUTION = 3.58675, 3.58688
     assert np.isclose(res.objective, GPOPS_II_SOLUTION, rtol=1e-4, atol=0.0)
     assert np.isclose(res.objective, SOS_SOLUTION, rtol=1e-4, atol=0.0)
+    assert res.gpu_linear_solver_gave_up == []
     assert res.mesh_tolerance_met is True
 
 
 def test_tumour_anti_angiogenesis_solution(built):
-    """tests/integration/test_tumour_anti_angiogenesis.py:119-137: objective within rtol 1e-5 of both published values.
-    (The mesh tolerance is approached -- 1.2e-7 after 12 mesh iterations -- but not asserted: the stand-in solver's
-    iterates differ from IPOPT's and the last refinement steps add one node at a time.)"""
+    """tests/integration/test_tumour_anti_angiogenesis.py:119-137, every assertion: objective within rtol 1e-5 of both
+    published values and the mesh tolerance met within the default ten mesh iterations (with the reference's NLP
+    tolerance, 1e-10: solve_ocp's default)."""
     from pycollo_amd.solve import solve_ocp
-    res = solve_ocp(problems.tumour_anti_angiogenesis(), max_mesh_iterations=8)
+    res = solve_ocp(problems.tumour_anti_angiogenesis())
     assert np.isclose(res.objective, 7.57166986e+03, rtol=1e-5, atol=0.0)
     assert np.isclose(res.objective, 7.5716831e+03, rtol=1e-5, atol=0.0)
-    assert res.iterations[-1]["max_rel_err"] < 1e-6
+    assert res.mesh_tolerance_met is True
+    assert res.gpu_linear_solver_gave_up == []
 
 
 @pytest.mark.parametrize("num_phases", [1, 2, 3, 4])

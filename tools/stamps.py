@@ -53,7 +53,7 @@ def main():
         eng.synchronize()
         eng.evaluate_all_device(x, 1.0, lam, c, G, H)
         eng.synchronize()
-        st = eng.read_symbol("pc_stamps", np.uint64, n_waves * 10).reshape(n_waves, 10).astype(np.int64)
+        st = eng.read_symbol("pc_stamps", np.uint64, n_waves * 24).reshape(n_waves, 24).astype(np.int64)
         live = st[(st[:, 0] > 0) & (st[:, 7] > 0)]
         if rep >= 2 and len(live):
             rows.append(live)
@@ -76,6 +76,17 @@ def main():
         d = rel[:, i] - rel[:, prev]
         print(f"{names[i - 1]:58s} {np.median(d):8.0f} {np.percentile(d, 10):8.0f} {np.percentile(d, 90):8.0f} {np.median(d) / np.median(life):6.1%}")
         prev = i
+    # per defect state (stamps 10 + 2a: block produced into LDS, 11 + 2a: read back and stores issued), over the waves
+    # that own the state
+    prevcol = 4
+    print("Jacobian of the defect rows, state by state (waves that own the state):")
+    for a in range(7):
+        pa, fa = live[:, 10 + 2 * a] - live[:, 0], live[:, 11 + 2 * a] - live[:, 0]
+        own = (live[:, 10 + 2 * a] > 0) & (live[:, 11 + 2 * a] > 0)
+        if not own.any():
+            continue
+        print(f"  state {a}: {own.sum():6d} waves | produced at {np.median(pa[own]):8.0f} | produce->flushed {np.median((fa - pa)[own]):7.0f} ticks "
+              f"(p10 {np.percentile((fa - pa)[own], 10):.0f}, p90 {np.percentile((fa - pa)[own], 90):.0f})")
     eng.close()
 
 
