@@ -294,6 +294,7 @@ class InteriorPointSolver:
         status, hist = "max_iter", []
         k_eps, k_mu, th_mu, s_max, g_th, g_phi, eta = 10.0, 0.2, 1.5, 100.0, 1e-5, 1e-8, 1e-4
         accept_count = 0
+        restarts = 0
         it = 0
         last_alpha = last_amax = 0.0
         last_tag = ""
@@ -377,6 +378,12 @@ class InteriorPointSolver:
                         if accepted:
                             break
                 alpha *= 0.5
+            if not accepted and e0 <= self.acceptable_tol:
+                # IPOPT's rule for a line search that fails at a point already inside the acceptable tolerances
+                # (BacktrackingLineSearch -> STOP_AT_ACCEPTABLE_POINT): no restoration from a converged point whose
+                # remaining error is the linear solver's floor
+                status = "acceptable"
+                break
             if not accepted:
                 # feasibility restoration, reduced to its core: Gauss-Newton steps on ||c||_1 (minimum-norm
                 # solution of the linearised constraints, fraction-to-the-boundary, backtracking) until the
@@ -413,8 +420,31 @@ class InteriorPointSolver:
                             ok_r = True
                             break
                 if not ok_r:
-                    status = "restoration_failed"
-                    break
+                    # The Gauss-Newton restoration could not find a point the filter accepts.  Before giving the NLP up:
+                    # a barrier restart from the best restoration point -- mu back up (two decades, at most mu_init), the
+                    # filter emptied, multipliers re-estimated and the bound multipliers put back on the central path
+                    # -- at most three times per solve.  (IPOPT recovers from the same situation inside its restoration
+                    # NLP; the degenerate cases here are bang-bang solutions on coarse meshes, where the two
+                    # factorisations' rounding decides which side of the filter a trial point falls on.)
+                    restarts += 1
+                    if restarts > 3:
+                        status = "restoration_failed"
+                        break
+                    if float(np.sum(np.abs(cr_))) < theta:      # keep whatever feasibility the restoration did gain
+                        v = vr
+                    mu = min(self.mu_init, max(100.0 * mu, 1e-6))
+                    filt = []
+                    # the fraction-to-the-boundary steps can have left components ON a bound in floating point: back
+                    # inside by the distance the new central path keeps from it, then everything at that point anew
+                    v = self._push_interior(v, min(1e-2, mu), min(1e-2, mu))
+                    c, J, f = self._c(v), self._J(v[:n]), self._f(v[:n])
+                    g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+                    dlv, duv = np.where(self.hasl, v - self.vl, 1.0), np.where(self.hasu, self.vu - v, 1.0)
+                    zl = np.where(self.hasl, mu / dlv, 0.0)
+                    zu = np.where(self.hasu, mu / duv, 0.0)
+                    lam = self._ls_multipliers(J, g - zl + zu)
+                    last_alpha, last_amax, last_tag = 0.0, a_max, " r"
+                    continue
                 v, c, J, f = vr, cr_, Jr, ft
                 last_alpha, last_amax, last_tag = 0.0, a_max, " R"
                 g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
@@ -435,6 +465,7 @@ class InteriorPointSolver:
             g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
             J = self._J(v[:n])
         ev = dict(self.counts)
+        ev["barrier_restarts"] = restarts
         ev["kkt_seconds"] = self.kkt_seconds
         return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
                          inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist,
