@@ -307,24 +307,14 @@ def host_cpu_facts() -> dict:
     return facts
 
 
-def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
-    """Time cp_eval_all (direct CSR writes, preallocated workspace, one OpenMP region per evaluation with static
-    section ranges) on the bench workload over a thread sweep 1, 2, 4, ... up to the host's CPUs (SURVEY 8d timing
-    protocol, items 1-2).  ``value`` is the single-thread figure (``cores`` = 1); ``best_value`` / ``best_threads`` the
-    best of the sweep; the host facts (CPU model, cgroup quota) say what the sweep could use."""
+def _sweep(K: int, order: int, budget_s: float, counts: list) -> dict:
+    """Times cp_eval_all at each thread count of ``counts`` in THIS process (libgomp reads OMP_* once, at start-up)."""
     from pycollo_amd import problems
     from pycollo_amd.quadrature import QuadratureTables
-    facts = host_cpu_facts()
-    ncpu = facts["affinity_cpus"]
-    os.environ["OMP_NUM_THREADS"] = str(ncpu)    # read when libgomp starts: the ceiling for cp_set_threads
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    # passive waiting: inside a CPU-quota cgroup, threads spinning at the barriers burn the quota the working threads need
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive" if facts["quota_cpus"] and facts["quota_cpus"] < ncpu else "active")
     cp = CPort(problems.hypersensitive(K=K, order=order), QuadratureTables("lobatto"))
     x = np.random.default_rng(1234).uniform(-0.45, 0.45, cp.num_x)
     lam = np.random.default_rng(1235).normal(size=cp.num_c)
     out = {}
-    counts = sorted({t for t in (1, 2, 4, 8, 16, 32, 64) if t <= ncpu})
     for thr in counts:
         cp.set_threads(thr)
         for _ in range(20):
@@ -337,7 +327,48 @@ def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
             dt = time.perf_counter() - t0
             if dt > budget_s / len(counts) or n >= 50000:
                 break
-        out[thr] = (n / dt, n, dt)
+        out[int(thr)] = (n / dt, n, dt)
+    return out
+
+
+def _sweep_child(K, order, budget_s, counts, policy, ceiling):
+    """One sweep in a child process with its own OpenMP environment; returns {threads: (rate, n, seconds)}."""
+    import json
+    import sys
+    env = dict(os.environ, OMP_NUM_THREADS=str(ceiling), OMP_PROC_BIND="close", OMP_WAIT_POLICY=policy)
+    root = os.path.dirname(os.path.dirname(HERE))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    code = ("import json, sys; from oracle import cport; "
+            f"print('SWEEP' + json.dumps(cport._sweep({K}, {order}, {budget_s!r}, {list(counts)!r})))")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root)
+    for line in res.stdout.splitlines():
+        if line.startswith("SWEEP"):
+            return {int(k): tuple(v) for k, v in json.loads(line[5:]).items()}
+    raise RuntimeError("thread sweep failed: " + res.stderr[-1500:])
+
+
+def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
+    """Time cp_eval_all (direct CSR writes, preallocated workspace, one OpenMP region per evaluation with static
+    section ranges) on the bench workload over a thread sweep 1, 2, 4, ... 64 (SURVEY 8d timing protocol, items 1-2).
+    libgomp reads its environment once per process, so the sweep runs in child processes: thread counts the
+    container's CPU quota can run at once wait ACTIVELY at the region's barriers (an evaluation of 10 k nodes is a few
+    hundred microseconds: sleeping threads are woken too late to help), counts above the quota wait passively (spinning
+    threads would burn the quota the working threads need).  ``value`` is the single-thread figure (``cores`` = 1);
+    ``best_value`` / ``best_threads`` the best of the sweep; the host facts (CPU model, cgroup quota) say what the sweep
+    could use."""
+    facts = host_cpu_facts()
+    ncpu = facts["affinity_cpus"]
+    can_spin = int(facts["quota_cpus"]) if facts["quota_cpus"] else ncpu
+    counts = sorted({t for t in (1, 2, 4, 8, 16, 32, 64) if t <= ncpu})
+    spin = [t for t in counts if t <= can_spin]
+    sleep = [t for t in counts if t > can_spin]
+    out, policy = {}, {}
+    if spin:
+        out.update(_sweep_child(K, order, budget_s * len(spin) / len(counts), spin, "active", max(spin)))
+        policy.update({t: "active" for t in spin})
+    if sleep:
+        out.update(_sweep_child(K, order, budget_s * len(sleep) / len(counts), sleep, "passive", max(sleep)))
+        policy.update({t: "passive" for t in sleep})
     best_thr = max(out, key=lambda t: out[t][0])
     one = out[1]
     return {"value": round(one[0], 2), "unit": "evals/s", "cores": 1, "kind": "port",
@@ -345,7 +376,8 @@ def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
                       f"port (gcc -O3 -march=native -fopenmp), values written straight into the CSR arrays, no "
                       f"allocation per call, one parallel region per evaluation (static section ranges)",
             "by_threads": {str(t): {"value": round(v[0], 2), "evals": v[1], "seconds": round(v[2], 2),
-                                    "speedup_over_1": round(v[0] / one[0], 2)} for t, v in out.items()},
+                                    "speedup_over_1": round(v[0] / one[0], 2), "omp_wait_policy": policy[t]}
+                           for t, v in sorted(out.items())},
             "host_cpus": ncpu, "cpu_model": facts["model"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
-            "quota_cpus": facts["quota_cpus"], "omp_wait_policy": os.environ.get("OMP_WAIT_POLICY"),
+            "quota_cpus": facts["quota_cpus"],
             "best_value": round(out[best_thr][0], 2), "best_threads": best_thr}
