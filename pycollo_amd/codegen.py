@@ -113,14 +113,23 @@ def is_heavy(pm: PhaseModel) -> bool:
     return pm.eval_ops > STATIC_W_MAX_OPS
 
 
-def _static_w_list(pm: PhaseModel) -> list[int]:
+def _static_w_list(pm: PhaseModel, single_phase: bool = False) -> list[int]:
     """Waves-per-tile counts that get a kernel with the replica index compiled in.  Light and medium models: 2 and 4
-    (6-8 % over the run-time replica index).  Heavy models: 2 only -- the *two-wave build*: each replica's copy holds
+    (6-8 % over the run-time replica index).  Heavy models: 2 -- the *two-wave build*: each replica's copy holds
     its own items only and evaluates the node functions in two passes (M::HEAVY), which is what brings a Delta III
-    tile body from 308 to <= 256 registers, i.e. two resident waves per SIMD instead of one."""
+    tile body from 308 to <= 256 registers, i.e. two resident waves per SIMD instead of one -- and, for a single-phase
+    model, 4 as well: on a small mesh (space station, 96 tiles) a replica's copy of the node functions keeps only what
+    its own items need, 23.8 -> 17.9 us (a multi-phase kernel would carry phases x 4 heavy bodies: not built)."""
     if os.environ.get("PYCOLLO_AMD_STATIC_W", "1") == "0":
         return []
-    return [2] if is_heavy(pm) else [2, 4]
+    if is_heavy(pm):
+        return [2, 4] if single_phase and _heavy_w4_enabled() else [2]
+    return [2, 4]
+
+
+def _heavy_w4_enabled() -> bool:
+    """PYCOLLO_AMD_HEAVY_W4=0 leaves the four-wave per-replica kernel of heavy single-phase models out (compile time)."""
+    return os.environ.get("PYCOLLO_AMD_HEAVY_W4", "1") != "0"
 
 
 def _constexpr_table(name: str, values: list[int]) -> str:
@@ -350,9 +359,8 @@ def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) ->
         # The same launch with the replica index as a template argument, one kernel per waves-per-tile count: a
         # replica's copy of the tile body then holds only the items dealt to it (everything else is dead code in that
         # copy) -- 6-8 % on every workload that shares tiles (config 2, W = 4: 4.45-4.7 -> 4.14-4.32 us).  pc_create
-        # picks pc_bulk_p0_r_w<W> when the code object has it.  Light and medium models only: a heavy model's tile
-        # body takes long to compile once, and such models rarely share tiles.
-        static_ws = _static_w_list(pm)
+        # picks pc_bulk_p0_r_w<W> when the code object has it (which W exist: _static_w_list).
+        static_ws = _static_w_list(pm, single_phase=True)
         for wn in static_ws:
             parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
             parts.append('  const int ntb = (wa >> 28) & 7;')
@@ -513,6 +521,8 @@ def code_object_path(model: Model, orders=None) -> str:
         occ += f"_pl{_preload_count()}"
     if not _heavy_cap_enabled() and _waves_per_eu() == 0:
         occ += "_nocap"
+    if not _heavy_w4_enabled():
+        occ += "_nohw4"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
     return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
