@@ -314,9 +314,12 @@ class InteriorPointSolver:
             e_pr = float(np.max(np.abs(c))) if m else 0.0
             return max(e_du / sd, e_pr, comp / scz), e_pr, e_du
 
+        phase = {"setup": time.perf_counter() - t_start, "errors": 0.0, "line_search": 0.0}
         for it in range(self.max_iter + 1):
             JTlam = self._JT(J, lam)
+            t_ph = time.perf_counter()
             e0, inf_pr, inf_du = errors(0.0)
+            phase["errors"] += time.perf_counter() - t_ph
             hist.append((it, f, inf_pr, inf_du, mu))
             if self.verbose:
                 print(f"{it:4d}  f {f: .8e}  inf_pr {inf_pr:.2e}  inf_du {inf_du:.2e}  lg(mu) {np.log10(mu):5.1f}  dw {dw_last:.1e}"
@@ -353,6 +356,7 @@ class InteriorPointSolver:
             a_z = min(self._alpha_dual(zl[self.hasl], dzl[self.hasl], tau) if self.hasl.any() else 1.0,
                       self._alpha_dual(zu[self.hasu], dzu[self.hasu], tau) if self.hasu.any() else 1.0)
             # filter line search
+            t_ph = time.perf_counter()
             theta = float(np.sum(np.abs(c)))
             phi = self._barrier(v, f, mu)
             dphi = float(grad_phi @ dv)
@@ -378,6 +382,7 @@ class InteriorPointSolver:
                         if accepted:
                             break
                 alpha *= 0.5
+            phase["line_search"] += time.perf_counter() - t_ph
             if not accepted and e0 <= self.acceptable_tol:
                 # IPOPT's rule for a line search that fails at a point already inside the acceptable tolerances
                 # (BacktrackingLineSearch -> STOP_AT_ACCEPTABLE_POINT): no restoration from a converged point whose
@@ -467,6 +472,7 @@ class InteriorPointSolver:
         ev = dict(self.counts)
         ev["barrier_restarts"] = restarts
         ev["kkt_seconds"] = self.kkt_seconds
+        ev["phase_seconds"] = {k: round(v, 6) for k, v in phase.items()}   # wall time by part of the loop (with kkt_seconds)
         return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it, inf_pr=inf_pr,
                          inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist,
                          zl=(zl[:n] / self.sf).copy(), zu=(zu[:n] / self.sf).copy())

@@ -33,6 +33,12 @@ for ls in ("gpu", "host"):
     for key in ("kkt_solves", "refined_solves", "jacobian", "hessian", "constraints"):
         if key in ev:
             row["n_" + key] = ev[key]
+    if "phase_seconds" in ev:
+        # the part before the first iteration (starting point, scaling, least-squares multipliers and, on the GPU path,
+        # the one-off build of the KKT tables for this mesh) apart from the iterations themselves
+        setup = ev["phase_seconds"]["setup"]
+        row["setup_s"] = round(setup, 4)
+        row["loop_ms_per_iteration"] = round(1e3 * (res.seconds - setup) / max(1, res.iterations), 2)
     if "gpu_seconds" in ev:
         row["gpu_seconds"] = {k: round(v, 4) for k, v in ev["gpu_seconds"].items()}
         row["ms_per_factorisation"] = round(1e3 * ev["gpu_seconds"]["factor"] / max(1, ev["factorisations"]), 3)
