@@ -271,6 +271,18 @@ typedef struct {
   const int32_t *mv_col, *mv_kind, *mv_idx;
   const double* mv_coef;
 } pc_kkt_desc;
+/* Host-only helper of the table build (no device): value-buffer position of K[u[e], v[e]] for n pairs of natural
+ * unknowns under the elimination plan (class 0 leaf / 1 chain / 2 border, block and local index per unknown; block
+ * geometry per leaf and per chain node); -1 for a pair the plan keeps apart.  pycollo_amd/kkt.py::build_tables. */
+typedef struct {
+  int64_t nu, nb, border_off;
+  const int8_t* cls;
+  const int64_t *blk, *local;
+  const int64_t *leafA_off, *m_l, *w_l, *leaf_left;        /* per leaf */
+  const int64_t *chainD_off, *nzb, *nzb_next, *wc;          /* per chain node */
+  const uint8_t* last_of_phase;
+} pc_kkt_plan;
+int pc_kkt_plan_positions(const pc_kkt_plan* plan, int64_t n, const int64_t* u, const int64_t* v, int64_t* out);
 const char* pc_kkt_last_error(void);
 int pc_kkt_create(const pc_kkt_desc* desc, const double* d_jac, const double* d_hess, int device, pc_kkt** out);
 void pc_kkt_destroy(pc_kkt* k);

@@ -132,24 +132,34 @@ __global__ void __launch_bounds__(256) kkt_matvec(const int64_t* __restrict__ pt
     y[row] = MODE == 0 ? v : b[row] - v;
   }
 }
-template <int MODE>
-__global__ void __launch_bounds__(256) kkt_matvec_long(const int64_t* __restrict__ rows, const int64_t* __restrict__ ptr, const int32_t* __restrict__ col,
-                                const uint32_t* __restrict__ src, const double* __restrict__ coef,
+// A long row is cut into chunks of MV_CHUNK entries, one workgroup per chunk (a single workgroup per row walked
+// 10 k entries in 40 dependent rounds of four loads each: 55 us); the chunks' sums are added in chunk order by
+// kkt_matvec_long_finish, so the result does not depend on the launch geometry.
+constexpr int MV_CHUNK = 1024;
+__global__ void __launch_bounds__(256) kkt_matvec_long(const int64_t* __restrict__ chunk_e0, const int64_t* __restrict__ chunk_e1,
+                                const int32_t* __restrict__ col, const uint32_t* __restrict__ src, const double* __restrict__ coef,
                                 const double* __restrict__ G, const double* __restrict__ H, int use_H,
-                                const uint8_t* __restrict__ fixed, const double* __restrict__ dvec,
-                                const double* __restrict__ x, const double* __restrict__ b, double* __restrict__ y) {
+                                const double* __restrict__ x, double* __restrict__ part_out) {
   __shared__ double part[4];
-  const int64_t row = rows[blockIdx.x];
   double acc = 0.0;
-  for (int64_t e = ptr[row] + threadIdx.x; e < ptr[row + 1]; e += 256) acc += mv_entry(src[e], coef[e], G, H, use_H) * x[col[e]];
+  for (int64_t e = chunk_e0[blockIdx.x] + threadIdx.x; e < chunk_e1[blockIdx.x]; e += 256) acc += mv_entry(src[e], coef[e], G, H, use_H) * x[col[e]];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double s = ((part[0] + part[1]) + part[2]) + part[3];
-    const double v = fixed[row] ? x[row] : s + dvec[row] * x[row];
-    y[row] = MODE == 0 ? v : b[row] - v;
-  }
+  if (threadIdx.x == 0) part_out[blockIdx.x] = ((part[0] + part[1]) + part[2]) + part[3];
+}
+template <int MODE>
+__global__ void kkt_matvec_long_finish(const int64_t* __restrict__ rows, const int64_t* __restrict__ row_chunk0, int64_t n_rows,
+                                       const double* __restrict__ part, const uint8_t* __restrict__ fixed,
+                                       const double* __restrict__ dvec, const double* __restrict__ x,
+                                       const double* __restrict__ b, double* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int64_t row = rows[i];
+  double s = 0.0;
+  for (int64_t c = row_chunk0[i]; c < row_chunk0[i + 1]; ++c) s += part[c];
+  const double v = fixed[row] ? x[row] : s + dvec[row] * x[row];
+  y[row] = MODE == 0 ? v : b[row] - v;
 }
 
 // small vector kernels of the on-device iterative refinement (pc_kkt_solve_refined)
@@ -173,10 +183,13 @@ __global__ void __launch_bounds__(256) kkt_norm_partial(const double* __restrict
     part[2 * blockIdx.x + 1] = ((s1[0] + s1[1]) + s1[2]) + s1[3];
   }
 }
+// (one wave: lane l adds the partial sums l, l + 64, ... in turn, then the lanes meet in a fixed order)
 __global__ void kkt_norm_final(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double a = 0.0, bad = 0.0;
-    for (int i = 0; i < nblocks; ++i) { a += part[2 * i]; bad += part[2 * i + 1]; }
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  double a = 0.0, bad = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a += part[2 * i]; bad += part[2 * i + 1]; }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); bad += __shfl_down(bad, off, 64); }
+  if (threadIdx.x == 0) {
     out[0] = a;
     out[1] = bad;
   }
@@ -807,8 +820,9 @@ struct pc_kkt {
       leaf_of_left, leafG_off, chainG_off, dst, run_ptr, diag_pos, mv_ptr;
   Dev<int32_t> src_kind, src_idx, mv_col;
   Dev<uint32_t> mv_src;            // kind << 30 | index of every matvec entry
-  Dev<int64_t> mv_long;            // rows with more than MV_LONG entries (one workgroup each)
-  int64_t n_mv_long = 0;
+  Dev<int64_t> mv_long, mv_long_c0, mv_chunk_e0, mv_chunk_e1;   // rows with more than MV_LONG entries, cut into chunks
+  Dev<double> mv_long_part;                                     // one partial sum per chunk
+  int64_t n_mv_long = 0, n_mv_chunks = 0;
   Dev<double> w_rhs, w_sol, w_res, w_trial, w_dx, w_dvec, w_part, w_norm;   // on-device iterative refinement
   Pin<double> h_norm;
   Dev<uint8_t> fixed, chain_last;
@@ -850,9 +864,12 @@ static void matvec_device(pc_kkt* k, int use_hess, const double* d_dvec, const d
   const int64_t threads = k->nu * MV_LANES;
   hipLaunchKernelGGL(kkt_matvec<MODE>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, k->mv_ptr.p, k->mv_col.p,
                      k->mv_src.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, d_dvec, d_x, d_b, d_y, k->nu);
-  if (k->n_mv_long)
-    hipLaunchKernelGGL(kkt_matvec_long<MODE>, dim3((unsigned)k->n_mv_long), dim3(256), 0, st, k->mv_long.p, k->mv_ptr.p,
-                       k->mv_col.p, k->mv_src.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, k->fixed.p, d_dvec, d_x, d_b, d_y);
+  if (k->n_mv_long) {
+    hipLaunchKernelGGL(kkt_matvec_long, dim3((unsigned)k->n_mv_chunks), dim3(256), 0, st, k->mv_chunk_e0.p, k->mv_chunk_e1.p,
+                       k->mv_col.p, k->mv_src.p, k->mv_coef.p, k->d_G, k->d_H, use_hess, d_x, k->mv_long_part.p);
+    hipLaunchKernelGGL(kkt_matvec_long_finish<MODE>, dim3((unsigned)((k->n_mv_long + 63) / 64)), dim3(64), 0, st, k->mv_long.p,
+                       k->mv_long_c0.p, k->n_mv_long, k->mv_long_part.p, k->fixed.p, d_dvec, d_x, d_b, d_y);
+  }
   KHIP(hipGetLastError());
 }
 
@@ -904,11 +921,23 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
         srcw[e] = ((uint32_t)d->mv_kind[e] << 30) | (uint32_t)d->mv_idx[e];
       }
       k->mv_src.upload(srcw.data(), srcw.size());
-      std::vector<int64_t> longs;
+      std::vector<int64_t> longs, c0{0}, ce0, ce1;
       for (int64_t r = 0; r < d->nu; ++r)
-        if (d->mv_ptr[r + 1] - d->mv_ptr[r] > MV_LONG) longs.push_back(r);
+        if (d->mv_ptr[r + 1] - d->mv_ptr[r] > MV_LONG) {
+          longs.push_back(r);
+          for (int64_t e = d->mv_ptr[r]; e < d->mv_ptr[r + 1]; e += MV_CHUNK) {
+            ce0.push_back(e);
+            ce1.push_back(std::min<int64_t>(e + MV_CHUNK, d->mv_ptr[r + 1]));
+          }
+          c0.push_back((int64_t)ce0.size());
+        }
       k->n_mv_long = (int64_t)longs.size();
+      k->n_mv_chunks = (int64_t)ce0.size();
       k->mv_long.upload(longs.data(), longs.size());
+      k->mv_long_c0.upload(c0.data(), c0.size());
+      k->mv_chunk_e0.upload(ce0.data(), ce0.size());
+      k->mv_chunk_e1.upload(ce1.data(), ce1.size());
+      k->mv_long_part.alloc((size_t)std::max<int64_t>(1, k->n_mv_chunks));
     }
     k->mv_coef.upload(d->mv_coef, d->n_mv);
     for (auto* w : {&k->w_rhs, &k->w_sol, &k->w_res, &k->w_trial, &k->w_dx, &k->w_dvec}) w->alloc((size_t)d->nu);
@@ -1050,6 +1079,48 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
   }
   *out = k;
   return 1;
+}
+
+// Host integer work (no device): where in the value buffer the entry K[u, v] of the blocked matrix lives, for n pairs
+// of natural unknowns -- the rule pycollo_amd/kkt.py documents (leaf < chain < border; inside a class the lower block
+// first; inside a block the larger local index is the row).  -1 where the elimination order keeps the pair apart.
+int pc_kkt_plan_positions(const pc_kkt_plan* P, int64_t n, const int64_t* u, const int64_t* v, int64_t* out) {
+  return guarded([&] {
+    if (!P || !u || !v || !out || n < 0) throw std::runtime_error("null argument");
+    constexpr int LEAF = 0, CHAIN = 1, BORDER = 2;
+    for (int64_t e = 0; e < n; ++e) {
+      int64_t a = u[e], b = v[e];
+      if (a < 0 || a >= P->nu || b < 0 || b >= P->nu) throw std::runtime_error("unknown index out of range");
+      const int cu = P->cls[a], cv = P->cls[b];
+      const bool swap = cu > cv || (cu == cv && (P->blk[a] > P->blk[b] || (P->blk[a] == P->blk[b] && P->local[a] < P->local[b])));
+      if (swap) std::swap(a, b);
+      const int ca = P->cls[a], cb = P->cls[b];
+      const int64_t ba = P->blk[a], bb = P->blk[b], la = P->local[a], lb = P->local[b];
+      int64_t pos = -1;
+      if (ca == LEAF) {
+        const int64_t row = P->leafA_off[ba] + la * (P->m_l[ba] + P->w_l[ba]), left = P->leaf_left[ba];
+        if (cb == LEAF) {
+          if (ba == bb) pos = row + lb;
+        } else if (cb == CHAIN) {
+          if (bb == left) pos = row + P->m_l[ba] + lb;
+          else if (bb == left + 1) pos = row + P->m_l[ba] + P->nzb[left] + lb;
+        } else {
+          pos = row + P->m_l[ba] + P->nzb[left] + P->nzb[left + 1] + lb;
+        }
+      } else if (ca == CHAIN) {
+        const int64_t row = P->chainD_off[ba] + la * (P->nzb[ba] + P->wc[ba]);
+        if (cb == CHAIN) {
+          if (ba == bb) pos = row + lb;
+          else if (bb == ba + 1 && !P->last_of_phase[ba]) pos = row + P->nzb[ba] + lb;
+        } else if (cb == BORDER) {
+          pos = row + P->nzb[ba] + P->nzb_next[ba] + lb;
+        }
+      } else if (cb == BORDER) {
+        pos = P->border_off + la * P->nb + lb;
+      }
+      out[e] = pos;
+    }
+  });
 }
 
 void pc_kkt_destroy(pc_kkt* k) {

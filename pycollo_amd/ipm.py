@@ -495,7 +495,10 @@ class GpuInteriorPointSolver(InteriorPointSolver):
     def _ensure_kkt(self):
         if self.kkt is None:
             from .kkt import GpuKkt
+            t0 = time.perf_counter()
             self.kkt = GpuKkt(self.engine, self.ineq, self.fixed, self.sc)
+            self.times["tables"] = self.times.get("tables", 0.0) + time.perf_counter() - t0   # once per solve
+            self.times["tables_host"] = self.kkt.seconds_tables
         return self.kkt
 
     # G~ (and H~) live on the device; the "matrix" handed around is a token saying at which point they were evaluated
@@ -522,8 +525,9 @@ class GpuInteriorPointSolver(InteriorPointSolver):
 
     def _factor(self, dvec, use_hess):
         self.counts["factorisations"] += 1
+        k = self._ensure_kkt()
         t0 = time.perf_counter()
-        out = self._ensure_kkt().factor(dvec, use_hess)
+        out = k.factor(dvec, use_hess)
         self.times["factor"] += time.perf_counter() - t0
         return out
 

@@ -112,7 +112,16 @@ def default_group(engine, ineq_rows) -> list[int]:
     return out
 
 
-def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None) -> KktTables:
+class _Plan(C.Structure):
+    _fields_ = [("nu", C.c_int64), ("nb", C.c_int64), ("border_off", C.c_int64), ("cls", C.POINTER(C.c_int8)),
+                ("blk", C.POINTER(C.c_int64)), ("local", C.POINTER(C.c_int64)),
+                ("leafA_off", C.POINTER(C.c_int64)), ("m_l", C.POINTER(C.c_int64)), ("w_l", C.POINTER(C.c_int64)),
+                ("leaf_left", C.POINTER(C.c_int64)),
+                ("chainD_off", C.POINTER(C.c_int64)), ("nzb", C.POINTER(C.c_int64)), ("nzb_next", C.POINTER(C.c_int64)),
+                ("wc", C.POINTER(C.c_int64)), ("last_of_phase", C.POINTER(C.c_uint8))]
+
+
+def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: str = "library") -> KktTables:
     """``ineq_rows``: constraint rows with a slack (in order); ``fixed_v`` [n + ns]: primal unknowns held fixed;
     ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise); ``group``: mesh sections per leaf
     (int or one per phase; default ``default_group``)."""
@@ -230,8 +239,35 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None) -> KktTables
     keep = ~(fixed[eu] | fixed[ev])
     eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
 
-    def dest(u, v):
-        """Position in the value buffer of K[u, v] (u, v natural), vectorised; -1 where the pair has no place."""
+    def dest_library(u, v):
+        """The same rule as ``dest_numpy`` below in one pass of host C++ (``pc_kkt_plan_positions``): the vectorised form
+        allocates ~100 temporaries of the entry count each, and their first-touch page faults were most of a table
+        build inside a solve (95 of 110 ms at config 2)."""
+        from .engine import load_library
+        lib = load_library()
+        lib.pc_kkt_plan_positions.argtypes = [C.POINTER(_Plan), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pc_kkt_last_error.restype = C.c_char_p
+        keep = [np.ascontiguousarray(a, dtype=t) for a, t in (
+            (cls, np.int8), (blk, np.int64), (local, np.int64), (leafA_off, np.int64), (m_l, np.int64), (w_l, np.int64),
+            (leaf_left, np.int64), (chainD_off, np.int64), (nzb, np.int64), (nzb_next, np.int64), (wc, np.int64),
+            (last_of_phase, np.uint8))]
+        keep = [a if a.size else np.zeros(1, a.dtype) for a in keep]
+        P = _Plan()
+        P.nu, P.nb, P.border_off = int(nu), int(nb), int(border_off)
+        for name, a in zip(("cls", "blk", "local", "leafA_off", "m_l", "w_l", "leaf_left", "chainD_off", "nzb", "nzb_next",
+                            "wc", "last_of_phase"), keep):
+            ctype = {np.dtype(np.int8): C.c_int8, np.dtype(np.int64): C.c_int64, np.dtype(np.uint8): C.c_uint8}[a.dtype]
+            setattr(P, name, a.ctypes.data_as(C.POINTER(ctype)))
+        u = np.ascontiguousarray(u, dtype=np.int64)
+        v = np.ascontiguousarray(v, dtype=np.int64)
+        out = np.empty(len(u), np.int64)
+        if not lib.pc_kkt_plan_positions(C.byref(P), len(u), u.ctypes.data, v.ctypes.data, out.ctypes.data):
+            raise RuntimeError(lib.pc_kkt_last_error().decode())
+        return out
+
+    def dest_numpy(u, v):
+        """Position in the value buffer of K[u, v] (u, v natural), vectorised; -1 where the pair has no place.  (The
+        statement of the rule; ``positions="numpy"`` selects it, the CPU tests hold the library against it.)"""
         cu, cv = cls[u], cls[v]
         # order the pair so that `a` is the one eliminated first: leaf < chain < border; inside a class lower block first
         swap = (cu > cv) | ((cu == cv) & (blk[u] > blk[v])) | ((cu == cv) & (blk[u] == blk[v]) & (local[u] < local[v]))
@@ -266,6 +302,7 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None) -> KktTables
         out[k] = border_off + la[k] * nb + lb[k]
         return out
 
+    dest = {"library": dest_library, "numpy": dest_numpy}[positions]
     d = dest(eu, ev)
     if np.any(d < 0):
         bad = np.nonzero(d < 0)[0][0]
@@ -319,7 +356,10 @@ class GpuKkt:
         if engine.device < 0:
             raise RuntimeError("the KKT solver needs a GPU engine; pycollo_amd has no CPU fallback")
         self.engine = engine
+        import time
+        t0 = time.perf_counter()
         self.tables = T = build_tables(engine, ineq_rows, fixed_v, row_scale, group)
+        self.seconds_tables = time.perf_counter() - t0          # host: the elimination plan as index tables
         self._lib = lib = load_library()
         vp = C.c_void_p
         lib.pc_kkt_last_error.restype = C.c_char_p
@@ -355,6 +395,7 @@ class GpuKkt:
         if not lib.pc_kkt_create(C.byref(d), dj, dh, int(engine.device), C.byref(self._h)):
             raise RuntimeError("pc_kkt_create failed: " + lib.pc_kkt_last_error().decode())
         self.nu = T.nu
+        self.seconds_create = time.perf_counter() - t0 - self.seconds_tables   # descriptor + device allocation / upload
 
     def _check(self, ok):
         if not ok:

@@ -84,3 +84,16 @@ def test_block_elimination_matches_a_general_sparse_solve(built, name, kw, group
     assert np.max(np.abs(xs - xr)) <= 1e-9 * np.max(np.abs(xr))
     np.testing.assert_allclose(R.matvec(G, H, dvec, xs), rhs, atol=1e-7 * np.max(np.abs(rhs)))
     eng.close()
+
+
+@pytest.mark.parametrize("name,kw", CASES[:9])
+def test_plan_positions_in_the_library_follow_the_stated_rule(built, name, kw):
+    """``pc_kkt_plan_positions`` (host C++, what ``build_tables`` uses) against the vectorised statement of the same
+    rule kept beside it in ``kkt.py``: every table identical, for two leaf sizes."""
+    import dataclasses
+    eng, _, _, _, ineq, fixed, sc, _ = kkt_case(name, kw)
+    for group in (1, None):
+        A = kkt.build_tables(eng, ineq, fixed, sc, group)
+        B = kkt.build_tables(eng, ineq, fixed, sc, group, positions="numpy")
+        for f in dataclasses.fields(A):
+            assert np.array_equal(getattr(A, f.name), getattr(B, f.name)), f.name

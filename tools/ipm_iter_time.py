@@ -54,4 +54,5 @@ for k, (s, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     tot += s
 print(f"  {'(solver loop itself)':18s} {(wall - tot) * 1e3:8.2f} ms")
 print("  counters:", {k: v for k, v in res.evaluations.items() if not isinstance(v, dict)})
+print("  gpu_seconds:", res.evaluations.get("gpu_seconds"))
 print("  loop phases:", res.evaluations.get("phase_seconds"), "solve() total", round(res.seconds, 4))

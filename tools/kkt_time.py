@@ -22,3 +22,9 @@ for g in groups:
         print(name, kw, "group",g,"leaves",k.tables.n_leaf,nm,"median ms",round(1e3*float(np.median(ts)),3),"min",round(1e3*min(ts),3), flush=True)
     print("   create s",round(t1-t0,3), "refined back-substitutions", k.solve_refined(rhs, dvec)[1])
     k.close()
+    # the same tables a second time in the process: host table build against the device-side create
+    from pycollo_amd import kkt as _kkt
+    t0=time.perf_counter(); _kkt.build_tables(eng, ineq, fixed, sc, g); t1=time.perf_counter()
+    k2 = GpuKkt(eng, ineq, fixed, sc, group=g); t2=time.perf_counter()
+    print("   second create: build_tables ms", round(1e3*(t1-t0),1), "| GpuKkt (tables + pc_kkt_create) ms", round(1e3*(t2-t1),1), flush=True)
+    k2.close()
