@@ -31,5 +31,8 @@ run delta_iii12k_n4 --problem delta_iii --sections 4167 --order 4 --steps 100 --
 run delta_iii50k --problem delta_iii --sections 12500 --order 5 --steps 50 --warmup 10 &&
 run delta_iii_ragged50k --problem delta_iii --sections 2500 --ragged --steps 50 --warmup 10 ;
 fi
+if [ "$PART" = 3 ]; then
+run space_station6k --problem space_station --sections 2000 --order 4 --steps 300 --warmup 30 ;
+fi
 # the raw traces are tens of MB per workload: condense on the box, ship only the summaries (copy them to profiles/)
 cd $R && PROFILES_DST=$R/gpurun_out/profiles_out_$PART python3 tools/summarise_profiles.py $TAG > /dev/null && rm -rf $OUT && ls $R/gpurun_out/profiles_out_$PART
