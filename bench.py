@@ -390,7 +390,7 @@ def main():
         if one_launch:   # the per-replica variant pc_create picks when tiles are shared (two-wave build of heavy models)
             from pycollo_amd import codegen as _cg
             wpt = int(extra.get("waves_per_tile", 1))
-            if wpt > 1 and all(wpt in _cg._static_w_list(pm) for pm in eng.model.phases):
+            if wpt > 1 and all(wpt in _cg._static_w_list(pm, single_phase=len(eng.model.phases) == 1) for pm in eng.model.phases):
                 kname += f"_w{wpt}"
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
         # this process); only quoted when the workload is the one those passes profiled

@@ -386,7 +386,22 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
   const bool odd = (len & 1) && tid == 0;
   double last = 0.0;
   if (odd) last = src[len - 1];
-  for (int e0 = tid; e0 - tid < pairs; e0 += PC_FLUSH_DEPTH * TB) {   // (uniform trip count: e0 - tid is the batch's first pair)
+  int b0 = 0;   // first pair of the batch: wave-uniform, so the loop and the choice below are scalar branches
+#ifndef PC_FLUSH_PRED_ALL
+  // full batches: every lane reads and stores, nothing is predicated (a predicated store is a compare, an exec-mask
+  // save / restore and a branch around one instruction: two thirds of the flush's instructions when every store had one)
+  for (; b0 + PC_FLUSH_DEPTH * TB <= pairs; b0 += PC_FLUSH_DEPTH * TB) {
+    const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
+    pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
+    pc_d2_a8 a[PC_FLUSH_DEPTH];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[q * TB];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(dp + q * TB, a[q]);
+  }
+#endif
+  for (; b0 < pairs; b0 += PC_FLUSH_DEPTH * TB) {   // the last, partial batch (one pass unless PC_FLUSH_PRED_ALL)
+    const int e0 = b0 + tid;
     pc_d2_a8 a[PC_FLUSH_DEPTH];
     // (unconditional reads at clamped indices: a read under `if` makes its register a conditional definition, and the
     //  compiler then waits for LDS before every single read)
@@ -1319,15 +1334,37 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
                 s_out[rs + before * n + extra + pos] = val;
               }
             });
-            if constexpr (PC_CE(St::own_sparse(a))) {
-              const int o = rs + PC_CE(St::ndep_before(a, a)) * n;
-              if (pos == 0) s_out[o] = WV;
-              if (pos == j) s_out[o + 1] = -WV;
-            }
           }
         };
         if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r, cr);
         if (has_start) write_cols(ls_s, 0, n_s, cs);
+#ifdef PC_OWN_SPARSE_BY_COLUMN   // A/B: the earlier form, the two D entries written by the lanes that own their columns
+        if constexpr (PC_CE(St::own_sparse(a))) {
+          auto d_cols = [&](int ls, int pos, int n_in) {
+            const int n = UN > 0 ? UN : n_in;
+#pragma unroll
+            for (int j = 1; j < n; ++j) {
+              const int o = row_off(ls, j, n) + PC_CE(St::ndep_before(a, a)) * n;
+              if (pos == 0) s_out[o] = WV;
+              if (pos == j) s_out[o + 1] = -WV;
+            }
+          };
+          if (ls_r >= lsA) d_cols(ls_r, pos_r, n_r);
+          if (has_start) d_cols(ls_s, 0, n_s);
+        }
+#else
+        // a state whose own derivative does not depend on it has just the two D entries in its own columns (section
+        // start: +W V, node j: -W V): both written by the lane that owns the ROW -- one predicated block per state
+        // instead of two predicated stores per row and column pass
+        if constexpr (PC_CE(St::own_sparse(a))) {
+          if (t >= 1) {
+            const int n = UN > 0 ? UN : n_r;
+            const int o = row_off(ls_r, pos_r, n) + PC_CE(St::ndep_before(a, a)) * n;
+            s_out[o] = WV;
+            s_out[o + 1] = -WV;
+          }
+        }
+#endif
         if constexpr (NT + PC_CE(St::nxdep(a)) > 0) {
           if (rowthr) {   // q, t and s columns of this lane's own row
             const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
