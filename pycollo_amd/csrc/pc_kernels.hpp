@@ -407,9 +407,23 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
     //  compiler then waits for LDS before every single read)
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * min(e0 + q * TB, pairs - 1));
+#ifdef PC_FLUSH_PRED_ALL
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q)
       if (e0 + q * TB < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (e0 + q * TB)), a[q]);
+#else
+    // chunk q of the batch is full, partial or empty -- a wave-uniform fact (scalar compares and branches); only the
+    // one partial chunk stores under a lane predicate
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) {
+      const int c0 = b0 + q * TB;
+      if (c0 + TB <= pairs) {
+        PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)), a[q]);
+      } else if (c0 < pairs) {
+        if (c0 + tid < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)), a[q]);
+      }
+    }
+#endif
   }
   if (odd) dst[len - 1] = last;
 #ifdef PC_FLUSH_ALIGN
@@ -673,11 +687,17 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     }
     lam_cnt = n1 - lam0;
     if (wantH) {
-      static_for<0, NY>([&](auto a_) {
+      // one predicated block per chunk for all states (a select per load is an exec-mask save / restore and a branch
+      // around each one: 2 NY of them here and again at the LDS stores below)
+      static_for<0, 2 * NY>([&](auto i_) { r_lam[decltype(i_)::value] = 0.0; });
+      const double* src0 = A.lamd + lam0;
+      if (tid < lam_cnt) static_for<0, NY>([&](auto a_) {
         constexpr int a = decltype(a_)::value;
-        const double* src = A.lamd + (int64_t)a * (N - 1) + lam0;
-        r_lam[2 * a] = tid < lam_cnt ? src[tid] : 0.0;
-        r_lam[2 * a + 1] = tid + TB < lam_cnt ? src[tid + TB] : 0.0;
+        r_lam[2 * a] = src0[(int64_t)a * (N - 1) + tid];
+      });
+      if (tid + TB < lam_cnt) static_for<0, NY>([&](auto a_) {
+        constexpr int a = decltype(a_)::value;
+        r_lam[2 * a + 1] = src0[(int64_t)a * (N - 1) + tid + TB];
       });
     }
     if constexpr (UN > 0) {
@@ -872,10 +892,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   }
   for (int i = tid + TB; i < nsec; i += TB) s_h[i] = A.sec_h[kp + i];
   if (wantH) {
-    static_for<0, NY>([&](auto a_) {
+    if (tid < lam_cnt) static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
-      if (tid < lam_cnt) s_lam[a * (TN + PC_MAX_ORDER) + tid] = r_lam[2 * a];
-      if (tid + TB < lam_cnt) s_lam[a * (TN + PC_MAX_ORDER) + tid + TB] = r_lam[2 * a + 1];
+      s_lam[a * (TN + PC_MAX_ORDER) + tid] = r_lam[2 * a];
+    });
+    if (tid + TB < lam_cnt) static_for<0, NY>([&](auto a_) {
+      constexpr int a = decltype(a_)::value;
+      s_lam[a * (TN + PC_MAX_ORDER) + tid + TB] = r_lam[2 * a + 1];
     });
   }
   if (!uni) {
