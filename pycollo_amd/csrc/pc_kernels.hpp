@@ -390,6 +390,32 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #ifndef PC_FLUSH_PRED_ALL
   // full batches: every lane reads and stores, nothing is predicated (a predicated store is a compare, an exec-mask
   // save / restore and a branch around one instruction: two thirds of the flush's instructions when every store had one)
+#ifdef PC_FLUSH_PIPELINED   // A/B: the next batch's LDS reads are issued before this batch's stores
+  if (b0 + PC_FLUSH_DEPTH * TB <= pairs) {
+    pc_d2_a8 a[PC_FLUSH_DEPTH], nx[PC_FLUSH_DEPTH];
+    {
+      const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
+#pragma unroll
+      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[q * TB];
+    }
+    for (;;) {
+      const int b1 = b0 + PC_FLUSH_DEPTH * TB;
+      const bool more = b1 + PC_FLUSH_DEPTH * TB <= pairs;
+      if (more) {
+        const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b1 + tid);
+#pragma unroll
+        for (int q = 0; q < PC_FLUSH_DEPTH; ++q) nx[q] = sp[q * TB];
+      }
+      pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
+#pragma unroll
+      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(dp + q * TB, a[q]);
+      b0 = b1;
+      if (!more) break;
+#pragma unroll
+      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = nx[q];
+    }
+  }
+#else
   for (; b0 + PC_FLUSH_DEPTH * TB <= pairs; b0 += PC_FLUSH_DEPTH * TB) {
     const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
     pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
@@ -399,6 +425,7 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(dp + q * TB, a[q]);
   }
+#endif
 #endif
   for (; b0 < pairs; b0 += PC_FLUSH_DEPTH * TB) {   // the last, partial batch (one pass unless PC_FLUSH_PRED_ALL)
     const int e0 = b0 + tid;
