@@ -1166,6 +1166,57 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   // ---- defect rows: value (row-wise; backend.py:1601-1603) ---------------------------------------
   double accf[NY > 0 ? NY : 1];
   const bool rowthr = active && t >= 1;
+#ifdef PC_MFMA_DEFECT
+  // Optional build (-DPC_MFMA_DEFECT, off in the product; SURVEY row X1, backend.py:1601-1603): the contraction with the
+  // integration matrix, sum_i A[j][i] f_a(z_i), on the matrix cores -- v_mfma_f64_16x16x4_f64, sixteen consecutive
+  // defect rows of the tile (columns of the result) against up to sixteen states (its rows), four nodes per step:
+  //   lane l, step s:  A-operand = f_(l & 15)(node kb + 4 s + (l >> 4))          [state x node]
+  //                    B-operand = A[j(q) - 1][that node - section start of row q], q = l & 15, 0 outside the section
+  //   result:          lane l, register i holds state (l >> 4) + 4 i of row q = l & 15
+  // (cdna_hip_programming.md, "f64 MFMA does NOT use these maps").  The row's lane then collects its NY sums with one
+  // cross-lane read per state.  Uniform-order tiles of 64 nodes only; anything else takes the vector form below.
+  // Not equal to it in the last bits (fused accumulation, zero terms of neighbouring sections -- a NaN in one section's
+  // f reaches the rows of the sections sharing its group of 16), which is why it is an A/B build and not the default.
+  constexpr bool MFMA_DEF = UN > 0 && NY > 0 && NY <= 16;
+  double accm[NY > 0 ? NY : 1];
+  bool mfma_done = false;
+  if constexpr (MFMA_DEF) {
+    if (TN == 64 && (wantC || wantG)) {   // wave-uniform
+      typedef double pc_d4 __attribute__((ext_vector_type(4)));
+      constexpr int n = UN > 0 ? UN : 2;
+      constexpr int KS = (16 + 2 * (n - 1) + 1 + 3) / 4;    // node span of 16 consecutive rows, in steps of four
+      const int lane = t & 63, q = lane & 15, hq = lane >> 4;
+      const double* Atab = s_qa + QAO(n);
+      static_for<0, NY>([&](auto a_) { accm[decltype(a_)::value] = 0.0; });
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (16 * g >= T) break;                            // (T is wave-uniform)
+        const int rr = 16 * g + q;                          // this lane's column of the result: tile row rr
+        const int sec = rr / (n - 1), jm1 = rr - sec * (n - 1), sk = sec * (n - 1);
+        const int kb = ((16 * g) / (n - 1)) * (n - 1);     // first node any row of the group touches
+        pc_d4 acc4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) {
+          const int kk = kb + 4 * s4 + hq;                  // node (tile-local) of this lane's k
+          const int i = kk - sk;
+          const bool in = rr < T && i >= 0 && i < n;
+          const double coef = Atab[in ? jm1 * n + i : 0];
+          const double fval = s_f[min(q, NY - 1) * TN + min(kk, T)];
+          acc4 = __builtin_amdgcn_mfma_f64_16x16x4f64(q < NY ? fval : 0.0, in ? coef : 0.0, acc4, 0, 0, 0);
+        }
+        // row 16 g + q' lives in lanes q', 16 + q', 32 + q', 48 + q': state a in lane 16 (a & 3) + q', register a >> 2
+        const int mine_q = (t - 1) & 15;
+        const bool here = rowthr && ((t - 1) >> 4) == g;
+        static_for<0, NY>([&](auto a_) {
+          constexpr int a = decltype(a_)::value;
+          const double got = __shfl(acc4[a >> 2], 16 * (a & 3) + mine_q, 64);
+          if (here) accm[a] = got;
+        });
+      }
+      mfma_done = true;
+    }
+  }
+#endif
   if (rowthr && (wantC || wantG)) {
     const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
     const double h = S_h(ls_r);
@@ -1175,8 +1226,15 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       accf[a] = 0.0;
       if (!mine(PC_ITEM(St::IT_D + a))) return;
       double acc = 0.0;
+#ifdef PC_MFMA_DEFECT
+      if (mfma_done) {
+        acc = accm[a];
+      } else
+#endif
+      {
 #pragma unroll
-      for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TN + sk + i];
+        for (int i = 0; i < n; ++i) acc += Arow[i] * s_f[a * TN + sk + i];
+      }
       accf[a] = h * acc;
       if (wantC)
         A.c[A.c_off + (int64_t)a * (N - 1) + node - 1] = sc[St::O_WD + a] * ((s_yu[a * TN + sk] - v[a]) + stretch * accf[a]);

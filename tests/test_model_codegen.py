@@ -107,3 +107,29 @@ def test_kernels_use_no_scratch_memory(name, kw, orders):
             assert r["scratch"] <= codegen.HEAVY_SCRATCH_LIMIT and r["occupancy"] >= 2, (kern, r)
     if name == "delta_iii":   # the two-wave launch kernel of config 5's uniform mesh fits without spilling at all
         assert res["pc_bulk_all_r_w2"]["scratch"] == 0 and res["pc_bulk_all_r_w2"]["vgprs"] <= 256
+
+
+def test_mfma_build_of_the_defect_contraction_uses_the_matrix_cores(monkeypatch, tmp_path):
+    """-DPC_MFMA_DEFECT: the code object then carries v_mfma_f64_16x16x4_f64 in its tile kernels and no
+    scratch; the default build carries no matrix instruction at all (DESIGN.md section 8 says why it is not the default)."""
+    import os
+    import subprocess
+    from pycollo_amd import codegen, problems
+    from pycollo_amd.model import compile_model
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("llvm-objdump not found")
+    model = compile_model(problems.hypersensitive(K=10, order=6))
+
+    def mfma_count(path):
+        co = str(tmp_path / (os.path.basename(path) + ".co"))
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        f"--input={path}", f"--output={co}"], check=True, capture_output=True)
+        text = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True).stdout
+        return text.count("v_mfma_f64_16x16x4")
+    assert mfma_count(codegen.build_code_object(model, (6,))) == 0
+    monkeypatch.setenv("PYCOLLO_AMD_DEFINES", "PC_MFMA_DEFECT")
+    flagged = codegen.build_code_object(model, (6,))
+    assert mfma_count(flagged) > 0
+    res = codegen.code_object_resources(flagged)
+    assert all(r["scratch"] == 0 for k, r in res.items() if k.startswith("pc_bulk")), res
