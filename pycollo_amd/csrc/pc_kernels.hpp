@@ -372,6 +372,9 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #else
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
                                           int TB) {
+  // The length is the same in every lane, but on a mesh of mixed orders it is computed from LDS tables, i.e. in a vector
+  // register: the compiler then treats the batch loop and the chunk tests below as divergent (exec-mask loops).
+  len = __builtin_amdgcn_readfirstlane(len);
   if (len <= 0) return;
 #ifdef PC_FLUSH_ALIGN   // A/B: peel one element so that the 16-byte stores are 16-byte aligned (read with the first batch too)
   const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
@@ -1403,7 +1406,14 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   //      contiguous CSR run of that state is written to HBM fully coalesced
   if (wantG) {
     const int lsA = has_prev ? 1 : 0;                       // first section of the tile (local index)
-    const long long E0 = S_E(lsA), E1 = S_E(nsec);
+    // (wave-uniform values read from an LDS table on a mixed-order mesh: as scalars, so that the run's start address,
+    //  its length and the row offsets below are scalar arithmetic)
+    auto uniform64 = [](long long v) -> long long {
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+      const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+      return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    const long long E0 = uni ? S_E(lsA) : uniform64(S_E(lsA)), E1 = uni ? S_E(nsec) : uniform64(S_E(nsec));
     static_for<0, NY>([&](auto a_) {
       constexpr int a = decltype(a_)::value;
       if (!mine(PC_ITEM(St::IT_D + a))) return;
@@ -1428,10 +1438,17 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
           const int n = UN > 0 ? UN : n_in;
           const double h = HOIST ? 0.0 : S_h(ls);
           const double* At = s_qa + (HOIST ? 0 : QAO(n));
+          // (first row's offset once: inside the loop the section tables would be re-read from LDS for every row --
+          //  the stores to the staging buffer may alias them as far as the compiler knows)
+          const int rs1 = row_off(ls, 1, n), rstride = Da * n + Ca;
 #pragma unroll
           for (int j = 1; j < n; ++j) {
             const double coef = HOIST ? cc[j - 1] : h * At[(j - 1) * n + pos];
+#ifdef PC_ROWOFF_IN_LOOP   // A/B: the earlier form
             const int rs = row_off(ls, j, n);
+#else
+            const int rs = rs1 + (j - 1) * rstride;
+#endif
             static_for<0, NZ>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
               if constexpr (PC_CE(St::dep(a, b))) {
