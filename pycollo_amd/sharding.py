@@ -290,6 +290,9 @@ class ShardedNlp:
                 eng.set_partials_buffer(ip, self.buf[off:off + (len(k0) - 1) * nred])
             tb, te = plan.tile_ranges[self.rank][ip]
             eng.set_tile_range(ip, tb, te)
+        # (a group of one rank has nothing to exchange; ``always_exchange`` sends its outputs through the collectives
+        #  all the same -- how the RCCL path is rehearsed on a one-GPU box, tests/test_gpu_sharded_process.py)
+        self.always_exchange = False
         self.exchange = SegmentExchange(plan, self.rank, dev, group)
         cg, hp = plan.split()
         self.exchange_cg = SegmentExchange(cg, self.rank, dev, group)
@@ -316,7 +319,8 @@ class ShardedNlp:
         cur = torch.cuda.current_stream()
         ts = cur if cur.cuda_stream != 0 else self.tstream
         eng = self.engine
-        if overlap and self.world > 1:
+        exchanging = self.world > 1 or self.always_exchange
+        if overlap and exchanging:
             e1, e2, e3 = self._ev
             with torch.cuda.stream(ts):
                 eng.launch_bulk_flags(d_x, d_lam, self.c, self.G, self.H, 1 | 2, ts.cuda_stream)
@@ -336,7 +340,7 @@ class ShardedNlp:
             return self.c, self.G, self.H
         with torch.cuda.stream(ts):
             eng.launch_bulk_only(d_x, d_lam, self.c, self.G, self.H, ts.cuda_stream)
-            if self.world > 1:
+            if exchanging:
                 self.exchange.run(self.buf, root, unpadded)
             if root is None or self.rank == root:
                 eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
