@@ -138,14 +138,14 @@ class CPort:
         os.makedirs(BUILD, exist_ok=True)
         so = os.path.join(BUILD, f"cport_{digest}.so")
         if not os.path.exists(so):
-            cfile = so[:-3] + ".c"
+            cfile = so[:-3] + f".{os.getpid()}.c"   # (per process: parallel test workers generate side by side)
             with open(cfile, "w") as f:
                 f.write(text)
-            cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", f"-I{HERE}", "-o", so + ".tmp", cfile, "-lm"]
+            cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", f"-I{HERE}", "-o", so + f".tmp{os.getpid()}", cfile, "-lm"]
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError("gcc failed:\n" + res.stderr[-3000:])
-            os.replace(so + ".tmp", so)
+            os.replace(so + f".tmp{os.getpid()}", so)
         self.lib = lib = C.CDLL(so)
         if threads is not None:
             os.environ["OMP_NUM_THREADS"] = str(threads)

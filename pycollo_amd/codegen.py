@@ -549,18 +549,21 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
                            f"unprofiled run of the same command)")
     src = out[:-6] + ".hip"
     import json
+    tmp_tag = f".tmp{os.getpid()}"          # (per process: two processes may build the same object side by side)
+    tmp_out = out + tmp_tag
     # Heavy models: first with their tile kernels capped at two waves per SIMD (_heavy_attr); when a capped kernel
     # spills more than HEAVY_SCRATCH_LIMIT bytes per lane the model does not fit (space station) and the object is
     # built again without the cap.
     attempts = [True, False] if (any(is_heavy(pm) for pm in model.phases) and _heavy_cap_enabled()) else [False]
     for cap in attempts:
-        with open(src, "w") as f:
+        with open(src + tmp_tag, "w") as f:
             f.write(generate_source(model, orders, heavy_cap=cap))
+        os.replace(src + tmp_tag, src)           # (whole file or none: another process may be compiling the same source)
         # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
         # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
         cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
                "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
-               f"-I{CSRC}", "-o", out + ".tmp", src] + [f"-D{d}" for d in _extra_defines()]
+               f"-I{CSRC}", "-o", tmp_out, src] + [f"-D{d}" for d in _extra_defines()]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
@@ -573,10 +576,10 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     # what the compiler made of every kernel travels with the object: pc_create's launch shape depends on it (a
     # two-wave build that did not fit 256 registers must not be launched as one)
     resources["_build"] = {"heavy_cap": bool(cap)}
-    with open(resources_path(out) + ".tmp", "w") as f:
+    with open(resources_path(out) + tmp_tag, "w") as f:
         json.dump(resources, f, indent=1, sort_keys=True)
-    os.replace(resources_path(out) + ".tmp", resources_path(out))
-    os.replace(out + ".tmp", out)
+    os.replace(resources_path(out) + tmp_tag, resources_path(out))
+    os.replace(tmp_out, out)
     return out
 
 

@@ -24,7 +24,9 @@ def harness(built):
     so = os.path.join(BUILD, "ipopt_protocol.so")
     src = os.path.join(ROOT, "tests", "c", "ipopt_protocol.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-fPIC", "-shared", "-o", so, src], check=True)
+        tmp = so + f".tmp{os.getpid()}"
+        subprocess.run(["gcc", "-O1", "-Wall", "-Werror", "-fPIC", "-shared", "-o", tmp, src], check=True)
+        os.replace(tmp, so)
     lib = C.CDLL(so)
     vp, ci = C.c_void_p, C.c_int
     lib.drive_structure.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]

@@ -27,10 +27,10 @@ def harness():
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         os.makedirs(os.path.dirname(EXE), exist_ok=True)
         cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-               "-fno-omit-frame-pointer", "-o", EXE + ".tmp", SRC]
+               "-fno-omit-frame-pointer", "-o", EXE + f".tmp{os.getpid()}", SRC]   # (per process: pytest-xdist workers build side by side)
         res = subprocess.run(cmd, capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[-3000:]
-        os.replace(EXE + ".tmp", EXE)
+        os.replace(EXE + f".tmp{os.getpid()}", EXE)
     return EXE
 
 
