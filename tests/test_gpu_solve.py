@@ -138,3 +138,30 @@ def test_reference_ipopt_hookup_lines_against_the_adapter(built):
     np.testing.assert_allclose(info["obj_val"] / it.w, 0.8243386694458454, rtol=1e-8)
     assert len(info["mult_g"]) == nlp_problem.m and len(info["mult_x_L"]) == nlp_problem.n
     it.engine.close()
+
+
+@pytest.mark.parametrize("name", ["shuttle", "hypersensitive", "tumour_anti_angiogenesis"])
+def test_parity_on_the_mesh_the_refinement_loop_ends_on(built, name):
+    """The callbacks on a mesh the build's OWN ph refinement produced (pycollo/mesh_refinement.py:250-392 restated in
+    pycollo_amd/refinement.py): after solve_ocp has met the mesh tolerance, the final mesh -- sections of different
+    widths and orders, so the any-order kernels -- is handed to the oracle as it stands, and c~, G~, H~ are compared
+    entry by entry at the converged point (where every defect is a cancelling sum) and at a random one."""
+    from conftest import assert_matches_oracle, golden_tables
+    from oracle.ref_numpy import OracleNlp
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.REGISTRY[name]())
+    assert res.mesh_tolerance_met is True and res.mesh_iterations >= 2
+    it = res.final
+    eng = it.engine
+    orders = {int(n) for m in it.meshes for n in np.unique(m.n)}
+    widths = np.concatenate([np.asarray(m.sizes, float) for m in it.meshes])
+    assert len(orders) > 1 or np.ptp(widths) > 1e-6 * np.max(widths), "the refinement left a uniform mesh"
+    ora = OracleNlp(it.problem, golden_tables(it.model.quadrature_method), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=eng.w_J)
+    rng = np.random.default_rng(3)
+    for x in (np.asarray(it.x_tilde, float), np.asarray(it.x_tilde, float) + 0.01 * rng.normal(size=eng.num_x)):
+        lam = rng.normal(size=eng.num_c)
+        c, G, H = eng.evaluate_all(x, 0.8, lam)
+        assert_matches_oracle(ora, x, c=c, G=G, H=H, sigma=0.8, lam=lam)
+    for got, ref in ((eng.evaluate_G_structure(), ora.G_structure()), (eng.evaluate_H_structure(), ora.H_structure())):
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
