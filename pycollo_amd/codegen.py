@@ -452,7 +452,7 @@ def _extra_defines() -> list[str]:
     return [d for d in os.environ.get("PYCOLLO_AMD_DEFINES", "").split() if d]
 
 
-HEAVY_SCRATCH_LIMIT = 128   # bytes per lane a capped heavy kernel may spill before the cap is given up
+HEAVY_SCRATCH_LIMIT = int(os.environ.get("PYCOLLO_AMD_HEAVY_SCRATCH_LIMIT", "128"))   # bytes per lane a capped heavy kernel may spill (env: experiments)
 
 
 def _heavy_cap_enabled() -> bool:

@@ -1137,6 +1137,106 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       constexpr int r = decltype(r_)::value;
       mult[r] = (r >= NY && r < NY + NP) ? mu[r] : stretch * mu[r];
     });
+  }
+  // number of nodes this tile owns, and the first one (for the staged per-node runs)
+  const int n_own = T + (last_tile ? 1 : 0);
+  // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
+  const bool edge0 = (node == 0), edgeN = (node == N - 1);
+  // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot: in the
+  // resident-tail build such an entry goes to the tail workgroup as a record (the tail adds the term and stores it).
+  // Which sites those are is a property of the model (M::efl, compile time); the record of a flagged site is
+  // erec0 + its rank among the flagged sites (node 0's first).  A model without such terms pays nothing.
+  constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
+  auto edge_store = [&](auto site_, double* dstp, double val) {
+    constexpr int site = decltype(site_)::value;
+    constexpr bool f0 = M::efl(site) != 0, fN = M::efl(NEDGE + site) != 0;
+    if constexpr (RES && (f0 || fN)) {
+      constexpr int r0 = PC_CE(St::erank(site)), rN = PC_CE(St::erank(NEDGE + site));
+      if (edge0 ? f0 : fN) {
+        publish_granules(A.erec + 2 * (int64_t)(A.erec0 + (edge0 ? r0 : rN)), A.epoch, val);
+        return;
+      }
+    }
+    *dstp = val;
+  };
+  auto hess_second = [&]() {     // everything built from the second partials
+    // bands: one variable block row at a time; rows with several entries go through the staging buffer
+    static_for<0, NZ>([&](auto rv_) {
+      constexpr int rv = decltype(rv_)::value;
+      constexpr int MB = PC_CE(St::hrow_count(rv));
+      if constexpr (MB > 0) if (mine(PC_ITEM(St::IT_HB + rv))) {
+        double vals[MB];
+        static_for<0, NH>([&](auto e_) {
+          constexpr int e = decltype(e_)::value;
+          if constexpr (M::hr(e) == rv)
+            vals[PC_CE(St::hpos(e))] = sc[St::O_VZ + rv] * sc[St::O_VZ + M::hc(e)] * Hv[e];
+        });
+        if (owns && (edge0 || edgeN)) {   // edge rows may interleave endpoint entries: explicit slots
+          static_for<0, NH>([&](auto e_) {
+            constexpr int e = decltype(e_)::value;
+            if constexpr (M::hr(e) == rv)
+              edge_store(ic<St::hzz_index(e)>{}, A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))],
+                         vals[PC_CE(St::hpos(e))]);
+          });
+        }
+        if constexpr (MB == 1) {
+          if (owns && !edge0 && !edgeN) A.H[hoff[St::HO_Z + rv] + (int64_t)node] = vals[0];
+        } else {
+          if (owns) static_for<0, MB>([&](auto q_) { s_out[t * MB + decltype(q_)::value] = vals[decltype(q_)::value]; });
+          stage_sync();
+          // interior nodes of the tile: [lo, hi)
+          const int lo = (n0 == 0) ? 1 : 0, hi = (last_tile ? n_own - 1 : n_own);
+          if (hi > lo)
+            flush_run(A.H + hoff[St::HO_Z + rv] + (int64_t)(n0 + lo) * MB, s_out + lo * MB, (hi - lo) * MB, t, TN);
+          stage_sync();
+        }
+      }
+    });
+    if (owns) {
+      static_for<0, NH>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        constexpr int rv = M::hr(e), cv = M::hc(e);
+        if constexpr (rv >= NZ && cv < NZ && St::is_t(rv >= NZ ? rv - NZ : 0)) {
+          // a time parameter's strip is the t strip (hess_tstrips adds this entry to the stretch term)
+        } else if constexpr (rv >= NZ && cv < NZ) {
+          if (mine(PC_ITEM(St::IT_HS + cv))) {
+            double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
+            const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
+            if (edge0 || edgeN) edge_store(ic<St::NHZZ + 2 * NZ + (rv - NZ) * NZ + cv>{}, dstp, val); else *dstp = val;
+          }
+        } else if constexpr (rv >= NZ) {
+          constexpr int l = rv - NZ, l2 = cv - NZ;
+          red[PC_CE(St::rss(l, l2))] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
+        }
+      });
+    }
+  };
+  // The second pass of a split build: second partials, then the Hessian runs built from them.
+  auto second_pass = [&]() {
+    if (wantH && hess_replica) {
+      if (active) M::eval_h(v, mult, Hv);
+      PC_STAMP(6);   // second partials evaluated
+      hess_second();
+    }
+  };
+  // Every wave of a launch walks the same phases at the same time, so the run stores arrive in bursts (all defect-
+  // Jacobian runs within a third of the launch) that the memory system cannot absorb while it idles during the
+  // evaluation phases.  With PC_SWAP_PASSES every other tile does its second pass FIRST: half the tiles store Hessian
+  // runs while the other half evaluate first partials, and so on.  Same results bit for bit (the passes share nothing
+  // but their inputs); the two barriers keep the staging buffer of one replica off the tables another still reads.
+#ifdef PC_SWAP_PASSES
+  const bool swap_passes = SPLIT && (tile & 1) != 0 && wantG && wantH;
+#else
+  constexpr bool swap_passes = false;
+#endif
+  if constexpr (SPLIT) {
+    if (swap_passes) {   // (a second call site of the pass: the default build has one)
+      block_sync();
+      second_pass();
+      block_sync();
+    }
+  }
+  if (active) {
     if constexpr (SPLIT) M::eval_fj(v, F, Jv);
     else M::eval(v, mult, F, Jv, Hv);
     if (owns) {   // this node's terms of the integral rows' sums (backend.py:1645-1647)
@@ -1246,9 +1346,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   PC_STAMP(3);   // defect values formed, c~ stores issued
   block_sync();   // every replica is done with f / y / lambda: the staging buffer may overwrite them
 
-  // number of nodes this tile owns, and the first one (for the staged per-node runs)
-  const int n_own = T + (last_tile ? 1 : 0);
-
   // ---- path rows (backend.py:1612-1614, compiled.py:336-355) ------------------------------------
   static_for<0, NP>([&](auto m_) {
     constexpr int m = decltype(m_)::value;
@@ -1290,77 +1387,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     });
   }
 
-  // ---- Hessian (compiled.py:484-500): flag 1 bands, flag 2 strips, flag 3 sums -------------------
-  const bool edge0 = (node == 0), edgeN = (node == N - 1);
-  // A Hessian entry of an edge node (0 or N-1) is stored -- unless an endpoint term lands on the same slot: in the
-  // resident-tail build such an entry goes to the tail workgroup as a record (the tail adds the term and stores it).
-  // Which sites those are is a property of the model (M::efl, compile time); the record of a flagged site is
-  // erec0 + its rank among the flagged sites (node 0's first).  A model without such terms pays nothing.
-  constexpr int NEDGE = St::NHZZ + 2 * NZ + NS * NZ;
-  auto edge_store = [&](auto site_, double* dstp, double val) {
-    constexpr int site = decltype(site_)::value;
-    constexpr bool f0 = M::efl(site) != 0, fN = M::efl(NEDGE + site) != 0;
-    if constexpr (RES && (f0 || fN)) {
-      constexpr int r0 = PC_CE(St::erank(site)), rN = PC_CE(St::erank(NEDGE + site));
-      if (edge0 ? f0 : fN) {
-        publish_granules(A.erec + 2 * (int64_t)(A.erec0 + (edge0 ? r0 : rN)), A.epoch, val);
-        return;
-      }
-    }
-    *dstp = val;
-  };
-  auto hess_second = [&]() {     // everything built from the second partials
-    // bands: one variable block row at a time; rows with several entries go through the staging buffer
-    static_for<0, NZ>([&](auto rv_) {
-      constexpr int rv = decltype(rv_)::value;
-      constexpr int MB = PC_CE(St::hrow_count(rv));
-      if constexpr (MB > 0) if (mine(PC_ITEM(St::IT_HB + rv))) {
-        double vals[MB];
-        static_for<0, NH>([&](auto e_) {
-          constexpr int e = decltype(e_)::value;
-          if constexpr (M::hr(e) == rv)
-            vals[PC_CE(St::hpos(e))] = sc[St::O_VZ + rv] * sc[St::O_VZ + M::hc(e)] * Hv[e];
-        });
-        if (owns && (edge0 || edgeN)) {   // edge rows may interleave endpoint entries: explicit slots
-          static_for<0, NH>([&](auto e_) {
-            constexpr int e = decltype(e_)::value;
-            if constexpr (M::hr(e) == rv)
-              edge_store(ic<St::hzz_index(e)>{}, A.H + (edge0 ? A.hslot0 : A.hslotN)[PC_CE(St::hzz_index(e))],
-                         vals[PC_CE(St::hpos(e))]);
-          });
-        }
-        if constexpr (MB == 1) {
-          if (owns && !edge0 && !edgeN) A.H[hoff[St::HO_Z + rv] + (int64_t)node] = vals[0];
-        } else {
-          if (owns) static_for<0, MB>([&](auto q_) { s_out[t * MB + decltype(q_)::value] = vals[decltype(q_)::value]; });
-          stage_sync();
-          // interior nodes of the tile: [lo, hi)
-          const int lo = (n0 == 0) ? 1 : 0, hi = (last_tile ? n_own - 1 : n_own);
-          if (hi > lo)
-            flush_run(A.H + hoff[St::HO_Z + rv] + (int64_t)(n0 + lo) * MB, s_out + lo * MB, (hi - lo) * MB, t, TN);
-          stage_sync();
-        }
-      }
-    });
-    if (owns) {
-      static_for<0, NH>([&](auto e_) {
-        constexpr int e = decltype(e_)::value;
-        constexpr int rv = M::hr(e), cv = M::hc(e);
-        if constexpr (rv >= NZ && cv < NZ && St::is_t(rv >= NZ ? rv - NZ : 0)) {
-          // a time parameter's strip is the t strip (hess_tstrips adds this entry to the stretch term)
-        } else if constexpr (rv >= NZ && cv < NZ) {
-          if (mine(PC_ITEM(St::IT_HS + cv))) {
-            double* dstp = A.H + hoff[St::HO_S + (rv - NZ) * NZ + cv] + node;
-            const double val = sc[St::O_VS + rv - NZ] * sc[St::O_VZ + cv] * Hv[e];
-            if (edge0 || edgeN) edge_store(ic<St::NHZZ + 2 * NZ + (rv - NZ) * NZ + cv>{}, dstp, val); else *dstp = val;
-          }
-        } else if constexpr (rv >= NZ) {
-          constexpr int l = rv - NZ, l2 = cv - NZ;
-          red[PC_CE(St::rss(l, l2))] = sc[St::O_VS + l] * sc[St::O_VS + l2] * Hv[e];
-        }
-      });
-    }
-  };
+  // ---- Hessian (compiled.py:484-500): the pieces built from the second partials are defined ahead of the first pass
+  //      (edge_store, hess_second); here the t strips, built from the adjoint weights and the first partials
   auto hess_tstrips = [&]() {    // built from the adjoint weights and the first partials
     if (owns) {
       // time coupling through stretch: d/dt~_j of stretch * (mu . dF/dv), f and g rows only
@@ -1530,11 +1558,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
 
   PC_STAMP(5);   // Jacobian of the defect rows staged and stored
   if constexpr (SPLIT) {         // second pass: second partials, the Hessian runs built from them, then the sums
-    if (wantH && hess_replica) {
-      if (active) M::eval_h(v, mult, Hv);
-      PC_STAMP(6);   // second partials evaluated
-      hess_second();
-    }
+    if (!swap_passes) second_pass();
     if constexpr (!RED_EARLY) deposit_partials();
   }
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
