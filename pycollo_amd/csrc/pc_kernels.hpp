@@ -42,6 +42,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<B + 1, E>(f);
   }
 }
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_down(F&& f) {   // E-1, E-2, ..., B
+  if constexpr (B < E) {
+    f(ic<E - 1>{});
+    static_for_down<B, E - 1>(f);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // compile-time structure derived from the model's non-zero lists
@@ -1442,7 +1449,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       return (long long)(((unsigned long long)hi << 32) | lo);
     };
     const long long E0 = uni ? S_E(lsA) : uniform64(S_E(lsA)), E1 = uni ? S_E(nsec) : uniform64(S_E(nsec));
-    static_for<0, NY>([&](auto a_) {
+    auto defect_jacobian_of_state = [&](auto a_) {
       constexpr int a = decltype(a_)::value;
       if (!mine(PC_ITEM(St::IT_D + a))) return;
       constexpr int Da = St::D(a), Ca = St::C(a);
@@ -1553,7 +1560,13 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       flush_run(A.G + g0, s_out, len, t, TN);
       stage_sync();
       if constexpr (a < 7) PC_STAMP(11 + 2 * a);   // ... read back and its stores issued
-    });
+    };
+#ifdef PC_REVERSE_ODD   // A/B: odd tiles walk the states last to first, so the heavy states' flushes of the two halves
+                        // of the launch do not coincide (the price: two copies of this section in the code)
+    if (tile & 1) static_for_down<0, NY>(defect_jacobian_of_state);
+    else
+#endif
+    static_for<0, NY>(defect_jacobian_of_state);
   }
 
   PC_STAMP(5);   // Jacobian of the defect rows staged and stored
