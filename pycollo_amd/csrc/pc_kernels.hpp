@@ -1705,6 +1705,12 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
       // wave re-reading its granules of the stride until all carry this launch's tag
       const unsigned long long* gr = P.gran;
       unsigned spins = 0;
+      // The strides are walked in the order in which a launch DISPATCHES its tiles -- position b stands for tile
+      // xcd_major(b, nt), the tile workgroup b of the launch runs -- not in tile order: tiles 0 .. nt/8 all run on XCD 0
+      // and the last of them is dispatched at the very end of the launch, so a walk in tile order stood still at the
+      // second stride until the launch was over and then had every other stride left to do (39 k tiles: 153 strides,
+      // 42 us after the last tile).  The separate tail kernel sums in the same order, so that the builds stay bitwise
+      // equal; any fixed order is a correct sum.
       // SL tiles per lane and pass (tiles b0 + tid + TB s, s < SL): a pass is one memory round trip however many
       // tiles it covers, and behind a long bulk kernel the tail must not fall a round trip per stride behind; SL is
       // what the register budget allows (the kernel's VGPR count is the tiles' occupancy too).  Tile b belongs to
@@ -1718,8 +1724,10 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
           static_for<0, SL>([&](auto s_) {
             constexpr int sl = decltype(s_)::value;
             const int b = b0 + tid + TB * sl;
-            if (b < nt)
-              static_for<0, 2 * NRED>([&](auto i_) { raw[sl][decltype(i_)::value] = load_granule(gr + 2 * (int64_t)b * NRED + decltype(i_)::value); });
+            if (b < nt) {
+              const int64_t tile_b = xcd_major(b, nt);   // the b-th tile in DISPATCH order (see below)
+              static_for<0, 2 * NRED>([&](auto i_) { raw[sl][decltype(i_)::value] = load_granule(gr + 2 * tile_b * NRED + decltype(i_)::value); });
+            }
           });
           bool ok = true;
           static_for<0, SL>([&](auto s_) {
@@ -1765,7 +1773,7 @@ __device__ __forceinline__ void tail_phase_issue(const PcTailArgs& A, int ip, Ta
             const int b = b0 + u * 256;
             static_for<0, NRED>([&](auto r_) {
               constexpr int r = decltype(r_)::value;
-              tmp[u][r] = b < nt ? part[(int64_t)b * NRED + r] : 0.0;
+              tmp[u][r] = b < nt ? part[(int64_t)xcd_major(b, nt) * NRED + r] : 0.0;   // (same order as the resident walk)
             });
           });
           static_for<0, U>([&](auto u_) {
