@@ -321,7 +321,14 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     rk = np.concatenate([ekind, ekind[off]])
     ri = np.concatenate([eidx, eidx[off]])
     rc = np.concatenate([ecoef, ecoef[off]])
-    o2 = np.lexsort((rv, ru))
+    # row-major order of the entries, columns ascending inside a row: one sort of the combined key (no pair occurs
+    # twice -- checked -- so the order is unique; np.lexsort over the two keys took 60-90 of the 150 ms of a 15 k-node
+    # build, a merge sort of the one int64 key -- the entries arrive as a few long sorted runs -- 17)
+    key = ru * np.int64(nu) + rv
+    o2 = np.argsort(key, kind="stable")
+    ks = key[o2]
+    if len(ks) > 1 and np.any(ks[1:] == ks[:-1]):
+        raise RuntimeError("a KKT entry occurs twice in the symmetric expansion")
     mv_ptr = np.concatenate([[0], np.cumsum(np.bincount(ru, minlength=nu))]).astype(np.int64)
 
     return KktTables(
