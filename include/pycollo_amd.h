@@ -283,6 +283,17 @@ typedef struct {
   const uint8_t* last_of_phase;
 } pc_kkt_plan;
 int pc_kkt_plan_positions(const pc_kkt_plan* plan, int64_t n, const int64_t* u, const int64_t* v, int64_t* out);
+/* Host-only: the entry tables of pc_kkt_desc (dst, run_ptr, src_*, mv_*) from the CSR structures of H~ (hr, hc; lower
+ * triangle), G~ (jr, jc; rows scaled by row_scale[m]), the slack columns of the ns inequality rows ineq_rows and the fixed
+ * flags [nu], under the plan.  n = number of NLP variables, nv = n + ns.  counts[3] receives (n_src, n_dst, n_mv).
+ * Either call with dst == NULL for the counts alone and again with exact buffers, or once with buffers for the most
+ * there can be: nH + nG + ns entries for dst / src_* (run_ptr one more), twice that for mv_col / mv_kind / mv_idx /
+ * mv_coef, nu + 1 for mv_ptr. */
+int pc_kkt_plan_entries(const pc_kkt_plan* plan, int64_t n, int64_t nv, int64_t nH, const int64_t* hr, const int64_t* hc,
+                        int64_t nG, const int64_t* jr, const int64_t* jc, const double* row_scale, int64_t ns,
+                        const int64_t* ineq_rows, const uint8_t* fixed, int64_t* counts, int64_t* dst, int64_t* run_ptr,
+                        int32_t* src_kind, int32_t* src_idx, double* src_coef, int64_t* mv_ptr, int32_t* mv_col,
+                        int32_t* mv_kind, int32_t* mv_idx, double* mv_coef);
 const char* pc_kkt_last_error(void);
 int pc_kkt_create(const pc_kkt_desc* desc, const double* d_jac, const double* d_hess, int device, pc_kkt** out);
 void pc_kkt_destroy(pc_kkt* k);

@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pycollo_amd.h"
@@ -1084,41 +1086,122 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
 // Host integer work (no device): where in the value buffer the entry K[u, v] of the blocked matrix lives, for n pairs
 // of natural unknowns -- the rule pycollo_amd/kkt.py documents (leaf < chain < border; inside a class the lower block
 // first; inside a block the larger local index is the row).  -1 where the elimination order keeps the pair apart.
+static inline int64_t plan_position(const pc_kkt_plan* P, int64_t a, int64_t b) {
+  constexpr int LEAF = 0, CHAIN = 1, BORDER = 2;
+  if (a < 0 || a >= P->nu || b < 0 || b >= P->nu) throw std::runtime_error("unknown index out of range");
+  const int cu = P->cls[a], cv = P->cls[b];
+  const bool swap = cu > cv || (cu == cv && (P->blk[a] > P->blk[b] || (P->blk[a] == P->blk[b] && P->local[a] < P->local[b])));
+  if (swap) std::swap(a, b);
+  const int ca = P->cls[a], cb = P->cls[b];
+  const int64_t ba = P->blk[a], bb = P->blk[b], la = P->local[a], lb = P->local[b];
+  int64_t pos = -1;
+  if (ca == LEAF) {
+    const int64_t row = P->leafA_off[ba] + la * (P->m_l[ba] + P->w_l[ba]), left = P->leaf_left[ba];
+    if (cb == LEAF) {
+      if (ba == bb) pos = row + lb;
+    } else if (cb == CHAIN) {
+      if (bb == left) pos = row + P->m_l[ba] + lb;
+      else if (bb == left + 1) pos = row + P->m_l[ba] + P->nzb[left] + lb;
+    } else {
+      pos = row + P->m_l[ba] + P->nzb[left] + P->nzb[left + 1] + lb;
+    }
+  } else if (ca == CHAIN) {
+    const int64_t row = P->chainD_off[ba] + la * (P->nzb[ba] + P->wc[ba]);
+    if (cb == CHAIN) {
+      if (ba == bb) pos = row + lb;
+      else if (bb == ba + 1 && !P->last_of_phase[ba]) pos = row + P->nzb[ba] + lb;
+    } else if (cb == BORDER) {
+      pos = row + P->nzb[ba] + P->nzb_next[ba] + lb;
+    }
+  } else if (cb == BORDER) {
+    pos = P->border_off + la * P->nb + lb;
+  }
+  return pos;
+}
+
 int pc_kkt_plan_positions(const pc_kkt_plan* P, int64_t n, const int64_t* u, const int64_t* v, int64_t* out) {
   return guarded([&] {
     if (!P || !u || !v || !out || n < 0) throw std::runtime_error("null argument");
-    constexpr int LEAF = 0, CHAIN = 1, BORDER = 2;
-    for (int64_t e = 0; e < n; ++e) {
-      int64_t a = u[e], b = v[e];
-      if (a < 0 || a >= P->nu || b < 0 || b >= P->nu) throw std::runtime_error("unknown index out of range");
-      const int cu = P->cls[a], cv = P->cls[b];
-      const bool swap = cu > cv || (cu == cv && (P->blk[a] > P->blk[b] || (P->blk[a] == P->blk[b] && P->local[a] < P->local[b])));
-      if (swap) std::swap(a, b);
-      const int ca = P->cls[a], cb = P->cls[b];
-      const int64_t ba = P->blk[a], bb = P->blk[b], la = P->local[a], lb = P->local[b];
-      int64_t pos = -1;
-      if (ca == LEAF) {
-        const int64_t row = P->leafA_off[ba] + la * (P->m_l[ba] + P->w_l[ba]), left = P->leaf_left[ba];
-        if (cb == LEAF) {
-          if (ba == bb) pos = row + lb;
-        } else if (cb == CHAIN) {
-          if (bb == left) pos = row + P->m_l[ba] + lb;
-          else if (bb == left + 1) pos = row + P->m_l[ba] + P->nzb[left] + lb;
-        } else {
-          pos = row + P->m_l[ba] + P->nzb[left] + P->nzb[left + 1] + lb;
-        }
-      } else if (ca == CHAIN) {
-        const int64_t row = P->chainD_off[ba] + la * (P->nzb[ba] + P->wc[ba]);
-        if (cb == CHAIN) {
-          if (ba == bb) pos = row + lb;
-          else if (bb == ba + 1 && !P->last_of_phase[ba]) pos = row + P->nzb[ba] + lb;
-        } else if (cb == BORDER) {
-          pos = row + P->nzb[ba] + P->nzb_next[ba] + lb;
-        }
-      } else if (cb == BORDER) {
-        pos = P->border_off + la * P->nb + lb;
+    for (int64_t e = 0; e < n; ++e) out[e] = plan_position(P, u[e], v[e]);
+  });
+}
+
+// The entry tables of pc_kkt_desc in one pass of host C++ (pycollo_amd/kkt.py::build_tables states the rule in NumPy
+// and the CPU tests hold this against it): the lower-triangle entries of K -- H~ (hr, hc), the scaled G~ (row nv + jr,
+// column jc), the slack columns (row nv + ineq_rows[i], column n + i, value -1) -- minus those that touch a fixed unknown;
+// sorted by their position in the value buffer into runs (dst, run_ptr, src_*), and expanded symmetrically into a CSR
+// over the unknowns with ascending columns (mv_*).  Two calls: with dst == NULL the three counts are returned
+// (n_src, n_dst, n_mv), then the caller allocates and calls again.
+int pc_kkt_plan_entries(const pc_kkt_plan* P, int64_t n, int64_t nv, int64_t nH, const int64_t* hr, const int64_t* hc,
+                        int64_t nG, const int64_t* jr, const int64_t* jc, const double* row_scale, int64_t ns,
+                        const int64_t* ineq_rows, const uint8_t* fixed, int64_t* counts, int64_t* dst, int64_t* run_ptr,
+                        int32_t* src_kind, int32_t* src_idx, double* src_coef, int64_t* mv_ptr, int32_t* mv_col,
+                        int32_t* mv_kind, int32_t* mv_idx, double* mv_coef) {
+  return guarded([&] {
+    if (!P || !counts || !fixed || (nH && (!hr || !hc)) || (nG && (!jr || !jc || !row_scale)) || (ns && !ineq_rows))
+      throw std::runtime_error("null argument");
+    struct Ent { int64_t d, u, v; int32_t kind, idx; double coef; };
+    std::vector<Ent> E;
+    E.reserve((size_t)(nH + nG + ns));
+    auto add = [&](int64_t u, int64_t v, int kind, int64_t idx, double coef) {
+      if (u < 0 || u >= P->nu || v < 0 || v >= P->nu) throw std::runtime_error("KKT entry outside the unknowns");
+      if (fixed[u] || fixed[v]) return;
+      const int64_t d = plan_position(P, u, v);
+      if (d < 0) throw std::runtime_error("KKT entry (" + std::to_string(u) + ", " + std::to_string(v) +
+                                          ") couples two blocks the elimination order keeps apart");
+      if (idx >= (int64_t)1 << 30) throw std::runtime_error("source index out of range");
+      E.push_back(Ent{d, u, v, kind, (int32_t)idx, coef});
+    };
+    for (int64_t e = 0; e < nH; ++e) add(hr[e], hc[e], 1 /* SRC_H */, e, 1.0);
+    for (int64_t e = 0; e < nG; ++e) add(nv + jr[e], jc[e], 0 /* SRC_G */, e, row_scale[jr[e]]);
+    for (int64_t i = 0; i < ns; ++i) add(nv + ineq_rows[i], n + i, 2 /* SRC_ONE */, 0, -1.0);
+    const int64_t ne = (int64_t)E.size();
+    // order by destination, entries of one destination in the order they were listed (what a stable argsort gives)
+    // (as pairs (destination, entry number): the keys travel with the elements, no indirect comparisons)
+    std::vector<std::pair<int64_t, int64_t>> key((size_t)ne);
+    for (int64_t e = 0; e < ne; ++e) key[e] = {E[e].d, e};
+    std::sort(key.begin(), key.end());
+    std::vector<int64_t> so((size_t)ne);
+    for (int64_t e = 0; e < ne; ++e) so[e] = key[e].second;
+    key.clear();
+    key.shrink_to_fit();
+    int64_t n_dst = 0, n_mv = 0;
+    for (int64_t k = 0; k < ne; ++k) {
+      if (k == 0 || E[so[k]].d != E[so[k - 1]].d) ++n_dst;
+      n_mv += E[k].u != E[k].v ? 2 : 1;
+    }
+    counts[0] = ne; counts[1] = n_dst; counts[2] = n_mv;
+    if (!dst) return;
+    if (!run_ptr || !src_kind || !src_idx || !src_coef || !mv_ptr || !mv_col || !mv_kind || !mv_idx || !mv_coef)
+      throw std::runtime_error("null output");
+    int64_t r = 0;
+    for (int64_t k = 0; k < ne; ++k) {
+      const Ent& x = E[so[k]];
+      if (k == 0 || x.d != E[so[k - 1]].d) { dst[r] = x.d; run_ptr[r] = k; ++r; }
+      src_kind[k] = x.kind; src_idx[k] = x.idx; src_coef[k] = x.coef;
+    }
+    run_ptr[r] = ne;
+    // symmetric CSR: rows by counting, columns ascending inside a row (pairs are unique -- checked)
+    const int64_t nu = P->nu;
+    std::vector<int64_t> cnt((size_t)nu + 1, 0);
+    for (const Ent& x : E) { ++cnt[x.u + 1]; if (x.u != x.v) ++cnt[x.v + 1]; }
+    for (int64_t i = 0; i < nu; ++i) cnt[i + 1] += cnt[i];
+    for (int64_t i = 0; i <= nu; ++i) mv_ptr[i] = cnt[i];
+    std::vector<int64_t> fill(cnt.begin(), cnt.end() - 1);
+    std::vector<int64_t> who((size_t)n_mv);     // entry number, bit 62 set for the transposed copy
+    auto put = [&](int64_t row, int64_t col, int64_t e) { const int64_t p = fill[row]++; mv_col[p] = (int32_t)col; who[p] = e; };
+    for (int64_t e = 0; e < ne; ++e) { put(E[e].u, E[e].v, e); if (E[e].u != E[e].v) put(E[e].v, E[e].u, e); }
+    std::vector<std::pair<int32_t, int64_t>> rowbuf;
+    for (int64_t i = 0; i < nu; ++i) {
+      const int64_t a = mv_ptr[i], b = mv_ptr[i + 1];
+      rowbuf.clear();
+      for (int64_t p = a; p < b; ++p) rowbuf.emplace_back(mv_col[p], who[p]);
+      std::sort(rowbuf.begin(), rowbuf.end());
+      for (int64_t p = a; p < b; ++p) {
+        if (p > a && rowbuf[p - a].first == rowbuf[p - a - 1].first) throw std::runtime_error("a KKT entry occurs twice in the symmetric expansion");
+        const Ent& x = E[rowbuf[p - a].second];
+        mv_col[p] = rowbuf[p - a].first; mv_kind[p] = x.kind; mv_idx[p] = x.idx; mv_coef[p] = x.coef;
       }
-      out[e] = pos;
     }
   });
 }

@@ -231,21 +231,13 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
 
     # ---- matrix entries (natural unknown pairs), lower triangle of K ------------------------------------------
     jr, jc = (np.asarray(a, np.int64) for a in engine.evaluate_G_structure())
-    eu = np.concatenate([hr, nv + jr, nv + ineq_rows])
-    ev = np.concatenate([hc, jc, n + np.arange(ns, dtype=np.int64)])
-    ekind = np.concatenate([np.full(len(hr), SRC_H), np.full(len(jr), SRC_G), np.full(ns, SRC_ONE)]).astype(np.int32)
-    eidx = np.concatenate([np.arange(len(hr)), np.arange(len(jr)), np.zeros(ns, np.int64)]).astype(np.int64)
-    ecoef = np.concatenate([np.ones(len(hr)), np.asarray(row_scale, float)[jr], -np.ones(ns)])
-    keep = ~(fixed[eu] | fixed[ev])
-    eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
-
-    def dest_library(u, v):
-        """The same rule as ``dest_numpy`` below in one pass of host C++ (``pc_kkt_plan_positions``): the vectorised form
-        allocates ~100 temporaries of the entry count each, and their first-touch page faults were most of a table
-        build inside a solve (95 of 110 ms at config 2)."""
+    def make_plan():
+        """The elimination plan as the C structure ``pc_kkt_plan`` (the arrays are kept alive by the caller)."""
         from .engine import load_library
         lib = load_library()
         lib.pc_kkt_plan_positions.argtypes = [C.POINTER(_Plan), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pc_kkt_plan_entries.argtypes = [C.POINTER(_Plan), C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p] + [C.c_void_p] * 11
         lib.pc_kkt_last_error.restype = C.c_char_p
         keep = [np.ascontiguousarray(a, dtype=t) for a, t in (
             (cls, np.int8), (blk, np.int64), (local, np.int64), (leafA_off, np.int64), (m_l, np.int64), (w_l, np.int64),
@@ -258,6 +250,64 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
                             "wc", "last_of_phase"), keep):
             ctype = {np.dtype(np.int8): C.c_int8, np.dtype(np.int64): C.c_int64, np.dtype(np.uint8): C.c_uint8}[a.dtype]
             setattr(P, name, a.ctypes.data_as(C.POINTER(ctype)))
+        return lib, P, keep
+
+    if positions == "library":
+        # the entry tables in one pass of host C++ (pc_kkt_plan_entries): the NumPy statement below builds them from a
+        # dozen entry-sized temporaries, sorts twice and gathers nine times -- 150 ms for 15 k nodes, and several times
+        # that whenever the allocator has to fault the temporaries in afresh, which inside a solve is every time
+        lib, P, _keepalive = make_plan()
+        hr_c, hc_c, jr_c, jc_c = (np.ascontiguousarray(a, dtype=np.int64) for a in (hr, hc, jr, jc))
+        rs_c = np.ascontiguousarray(row_scale, dtype=np.float64)
+        iq_c = np.ascontiguousarray(ineq_rows, dtype=np.int64)
+        fx_c = np.ascontiguousarray(fixed, dtype=np.uint8)
+        counts = np.zeros(3, np.int64)
+
+        def call(*outs):
+            ok = lib.pc_kkt_plan_entries(C.byref(P), int(n), int(nv), len(hr_c), hr_c.ctypes.data, hc_c.ctypes.data, len(jr_c),
+                                         jr_c.ctypes.data, jc_c.ctypes.data, rs_c.ctypes.data, int(ns), iq_c.ctypes.data,
+                                         fx_c.ctypes.data, counts.ctypes.data, *[o.ctypes.data if o is not None else None for o in outs])
+            if not ok:
+                raise RuntimeError(lib.pc_kkt_last_error().decode())
+        # one call with outputs sized for the most there can be (np.empty touches no page), trimmed afterwards
+        cap = len(hr_c) + len(jr_c) + int(ns)
+        dst, run_ptr = np.empty(cap, np.int64), np.empty(cap + 1, np.int64)
+        src_kind, src_idx, src_coef = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float64)
+        mv_ptr, mv_col = np.empty(nu + 1, np.int64), np.empty(2 * cap, np.int32)
+        mv_kind, mv_idx, mv_coef = np.empty(2 * cap, np.int32), np.empty(2 * cap, np.int32), np.empty(2 * cap, np.float64)
+        call(dst, run_ptr, src_kind, src_idx, src_coef, mv_ptr, mv_col, mv_kind, mv_idx, mv_coef)
+        n_src, n_dst, n_mv = (int(c) for c in counts)
+        dst, run_ptr = dst[:n_dst], run_ptr[:n_dst + 1]
+        src_kind, src_idx, src_coef = src_kind[:n_src], src_idx[:n_src], src_coef[:n_src]
+        mv_col, mv_kind, mv_idx, mv_coef = mv_col[:n_mv], mv_kind[:n_mv], mv_idx[:n_mv], mv_coef[:n_mv]
+        ar = np.arange(nu, dtype=np.int64)
+        diag_pos = np.empty(nu, np.int64)
+        if not lib.pc_kkt_plan_positions(C.byref(P), nu, ar.ctypes.data, ar.ctypes.data, diag_pos.ctypes.data):
+            raise RuntimeError(lib.pc_kkt_last_error().decode())
+        return KktTables(
+            nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=nv, n_dual=m,
+            perm=perm, leaf_ptr=leaf_ptr, chain_ptr=chain_ptr, chain_phase_ptr=chain_phase_ptr, leaf_left=leaf_left,
+            leafA_off=np.asarray(leafA_off, np.int64), leafS_off=np.asarray(leafS_off, np.int64),
+            chainD_off=np.asarray(chainD_off, np.int64), chainS_off=np.asarray(chainS_off, np.int64),
+            border_off=int(border_off), total_vals=int(total),
+            dst=dst, run_ptr=run_ptr, src_kind=src_kind, src_idx=src_idx, src_coef=src_coef, diag_pos=diag_pos,
+            fixed=fixed.astype(np.uint8), mv_ptr=mv_ptr, mv_col=mv_col, mv_kind=mv_kind, mv_idx=mv_idx, mv_coef=mv_coef)
+
+    # ---- the same in NumPy: the statement of the rule (positions = "numpy" / "positions"; the CPU tests hold the library
+    #      against it).  "positions" takes only the position rule from the library, as round 3's first version did.
+    eu = np.concatenate([hr, nv + jr, nv + ineq_rows])
+    ev = np.concatenate([hc, jc, n + np.arange(ns, dtype=np.int64)])
+    ekind = np.concatenate([np.full(len(hr), SRC_H), np.full(len(jr), SRC_G), np.full(ns, SRC_ONE)]).astype(np.int32)
+    eidx = np.concatenate([np.arange(len(hr)), np.arange(len(jr)), np.zeros(ns, np.int64)]).astype(np.int64)
+    ecoef = np.concatenate([np.ones(len(hr)), np.asarray(row_scale, float)[jr], -np.ones(ns)])
+    keep = ~(fixed[eu] | fixed[ev])
+    eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
+
+    def dest_library(u, v):
+        """The same rule as ``dest_numpy`` below in one pass of host C++ (``pc_kkt_plan_positions``): the vectorised form
+        allocates ~100 temporaries of the entry count each, and their first-touch page faults were most of a table
+        build inside a solve (95 of 110 ms at config 2)."""
+        lib, P, _keepalive = make_plan()
         u = np.ascontiguousarray(u, dtype=np.int64)
         v = np.ascontiguousarray(v, dtype=np.int64)
         out = np.empty(len(u), np.int64)
@@ -302,7 +352,7 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
         out[k] = border_off + la[k] * nb + lb[k]
         return out
 
-    dest = {"library": dest_library, "numpy": dest_numpy}[positions]
+    dest = {"positions": dest_library, "numpy": dest_numpy}[positions]
     d = dest(eu, ev)
     if np.any(d < 0):
         bad = np.nonzero(d < 0)[0][0]

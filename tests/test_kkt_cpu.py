@@ -88,12 +88,17 @@ def test_block_elimination_matches_a_general_sparse_solve(built, name, kw, group
 
 @pytest.mark.parametrize("name,kw", CASES[:9])
 def test_plan_positions_in_the_library_follow_the_stated_rule(built, name, kw):
-    """``pc_kkt_plan_positions`` (host C++, what ``build_tables`` uses) against the vectorised statement of the same
-    rule kept beside it in ``kkt.py``: every table identical, for two leaf sizes."""
+    """``pc_kkt_plan_entries`` / ``pc_kkt_plan_positions`` (host C++, what ``build_tables`` uses) against the vectorised
+    statement of the same rules kept beside them in ``kkt.py``: every table identical in value and type, for two leaf
+    sizes -- the whole entry tables from the library, and the position rule alone."""
     import dataclasses
     eng, _, _, _, ineq, fixed, sc, _ = kkt_case(name, kw)
     for group in (1, None):
-        A = kkt.build_tables(eng, ineq, fixed, sc, group)
         B = kkt.build_tables(eng, ineq, fixed, sc, group, positions="numpy")
-        for f in dataclasses.fields(A):
-            assert np.array_equal(getattr(A, f.name), getattr(B, f.name)), f.name
+        for mode in ("library", "positions"):
+            A = kkt.build_tables(eng, ineq, fixed, sc, group, positions=mode)
+            for f in dataclasses.fields(A):
+                a, b = getattr(A, f.name), getattr(B, f.name)
+                assert np.array_equal(a, b), (mode, f.name)
+                if isinstance(b, np.ndarray):
+                    assert a.dtype == b.dtype, (mode, f.name, a.dtype, b.dtype)
