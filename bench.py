@@ -99,6 +99,7 @@ def sharded_config_lines(world, rank, local_rank, dev, tstream, args):
     for label, name, kw in (("config 4: shuttle, 20000 sections x 4 nodes", "shuttle", dict(K=20000, order=4)),
                             ("config 5: Delta III, 4 phases x 3125 sections x 5 nodes", "delta_iii", dict(K=3125, order=5))):
         sh = ShardedNlp(problems.REGISTRY[name](**kw), device=local_rank)
+        dist.barrier()   # every rank has its engine (a rank that had to compile the code object is waited for here)
         lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
         x = torch.from_numpy(np.random.default_rng(1234).uniform(lo, hi, sh.num_x)).to(dev)
         lam = torch.from_numpy(np.random.default_rng(1235).normal(size=sh.num_c)).to(dev)
@@ -167,6 +168,9 @@ def main():
     ap.add_argument("--host-calls", type=int, default=2000, help="timed host-pointer calls per variant (>= 1000)")
     ap.add_argument("--no-pin", action="store_true", help="leave the launching thread to the scheduler")
     ap.add_argument("--ragged", action="store_true", help="ph-refined style mesh: random section sizes, orders 4..8")
+    ap.add_argument("--refined", type=int, default=0, metavar="NODES",
+                    help="a mesh as ph refinement leaves it, about NODES nodes per phase (refinement.synthetic_refined_mesh, "
+                         "seeds 7, 8, ...): orders in runs, the mixed build")
     ap.add_argument("--generic", action="store_true", help="use the any-mesh kernels (no order specialisation)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N > 1 on one GPU")
     ap.add_argument("--check", action="store_true", help="N > 1: compare the sharded result with an unsharded one")
@@ -182,8 +186,13 @@ def main():
         from pycollo_amd.model import compile_model
         entry.build_library()
         pb = _pr.REGISTRY[args.problem](K=args.sections * max(1, args.gpus), order=args.order)
-        orders = tuple(0 for _ in pb.phases) if (args.ragged or args.generic) else tuple(args.order for _ in pb.phases)
-        print(codegen.build_code_object(compile_model(pb), orders))
+        orders = tuple(0 for _ in pb.phases) if (args.ragged or args.generic or args.refined) else tuple(args.order for _ in pb.phases)
+        mixed = None
+        if args.refined and not args.generic:
+            from pycollo_amd.engine import choose_spec_orders
+            _pr.with_refined_mesh(pb, args.refined)
+            mixed = tuple(choose_spec_orders(ph.mesh.resolved()[1]) for ph in pb.phases)
+        print(codegen.build_code_object(compile_model(pb), orders, mixed=mixed))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -226,6 +235,8 @@ def main():
         for ph in prob.phases:
             ph.mesh.mesh_section_sizes = rr.uniform(0.5, 1.5, K_total)
             ph.mesh.number_mesh_section_nodes = rr.integers(4, 9, K_total)
+    if args.refined:
+        problems.with_refined_mesh(prob, args.refined)
     # a dedicated (non-default) stream: the library treats a NULL stream as "use the handle's own stream",
     # and torch events only see the stream they are recorded on
     tstream = torch.cuda.Stream(device=dev)
@@ -252,10 +263,19 @@ def main():
         nph = len(prob.phases)
         workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {K_total} mesh sections x {args.order} Lobatto nodes "
                     f"= {eng.layout.phases[0].N} collocation nodes{' per phase' if nph > 1 else ''}")
+        if args.refined or args.ragged:
+            kind = "ph-refined (synthetic error field)" if args.refined else "random orders 4..8 per section"
+            workload = (f"{args.problem}, {nph} phase{'s' if nph > 1 else ''}, {kind} mesh, "
+                        f"{sum(m.K for m in eng.meshes)} sections, {sum(pl.N for pl in eng.layout.phases)} collocation nodes")
         extra = {"num_x": eng.num_x, "num_c": eng.num_c, "nnz_jac": eng.nnz_jac, "nnz_hess": eng.nnz_hess,
                  "tiles": info["n_tiles_total"], "threads_per_block": info["threads_per_block"], "waves_per_tile": info["waves_per_tile"],
                  "launches_per_eval": info["n_launches"], "lds_bytes_per_workgroup": info["lds_bytes_max"],
                  "launch_thread_cpu": pinned_cpu}
+        if any(eng.mixed):   # mixed build: which orders have a tile body, and how much of the mesh runs them
+            od = [eng.phase_tile_orders(p) for p in range(nph)]
+            extra["mixed_build"] = {"specialised_orders": [list(m) for m in eng.mixed],
+                                    "order_pure_tiles": int(sum(int((o > 0).sum()) for o in od)),
+                                    "any_order_tiles": int(sum(int((o == 0).sum()) for o in od))}
         if os.environ.get("PYCOLLO_AMD_BENCH_ADDR"):   # diagnostic: where the buffers landed
             extra["addr"] = {k: hex(t.data_ptr()) for k, t in (("x", x), ("lam", lam), ("c", c), ("G", G), ("H", H))}
     else:
@@ -427,9 +447,14 @@ def main():
         calls = int(max(20, min(args.host_calls, 4e9 / per_call)))
         host = host_leg(eng, x.cpu().numpy(), lam.cpu().numpy(), calls)
 
+    # (after every headline figure has been measured; a failure here -- the ranks are symmetric, so it is a failure on
+    #  every rank -- is reported in the line instead of costing it)
     sharded_configs = None
     if world > 1 and not args.no_sharded_configs:
-        sharded_configs = sharded_config_lines(world, rank, local_rank, dev, tstream, args)
+        try:
+            sharded_configs = sharded_config_lines(world, rank, local_rank, dev, tstream, args)
+        except Exception as exc:   # noqa: BLE001
+            sharded_configs = [{"error": f"{type(exc).__name__}: {exc}"[:300]}]
     if rank == 0:
         out = {"metric": "NLP-callback evals/sec (g + jac_g + hess)", "value": round(evals_per_s, 2), "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 6),

@@ -62,6 +62,13 @@ typedef struct {
   int32_t n_w;
   const int32_t* w_kind;
   const int32_t* w_idx;
+  /* mixed build (compiled_order == 0 only): the section orders the code object's tile kernels of this phase carry a
+   * specialised body for, next to the any-order body.  pc_create then cuts the tiles at order changes wherever the
+   * orders come in runs (what ph refinement leaves, pycollo/mesh_refinement.py:252-321) and every order-pure tile runs
+   * the body of its order.  n_spec = 0: the any-order kernel alone. */
+  int32_t n_spec;
+  int32_t spec_orders[4];
+  int32_t reserved_spec[3];
 } pc_phase_desc;
 
 typedef struct {
@@ -210,6 +217,9 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
 int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end);
 /* n_tiles, number of partial sums per tile, and (optional) first section of every tile [n_tiles+1] */
 int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nred, int32_t* tile_k0);
+/* mixed build (pc_phase_desc::n_spec > 0): the section order whose tile body runs every tile [n_tiles], 0 = the
+ * any-order body; all zero for a phase that is not mixed */
+int pc_phase_tile_orders(const pc_handle* h, int phase, int32_t* tile_order);
 /* redirect the per-tile partial sums of one phase, double [n_tiles][nred], into caller-owned device
  * memory so that they can travel in the same all-gather as the output segments (NULL = internal) */
 int pc_set_partials_buffer(pc_handle* h, int phase, double* d_partials);
@@ -309,6 +319,49 @@ int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, 
  * names the solver, pycollo/backend.py:1703-1711).  n_solves (may be NULL): back-substitutions performed. */
 int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const double* rhs, int max_steps, double* x,
                          int32_t* n_solves);
+/* The same three with every vector in device memory, queued on the handle's stream (no host copy of a vector; the
+ * factorisation still returns its two pivot counts).  pc_kkt_set_stream moves the handle onto the caller's stream --
+ * the evaluation's -- so that one stream orders evaluation, assembly and solve. */
+int pc_kkt_set_stream(pc_kkt* k, void* stream);
+int pc_kkt_factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t* n_pos, int32_t* n_neg);
+int pc_kkt_matvec_device(pc_kkt* k, int use_hess, const double* d_dvec, const double* d_x, double* d_y);
+int pc_kkt_solve_refined_device(pc_kkt* k, int use_hess, const double* d_dvec_true, const double* d_rhs, int max_steps,
+                                double* d_x, int32_t* n_solves);
+
+/* ---- a device-resident interior-point iteration --------------------------
+ * The reference enters its NLP solver once per solve (pycollo/backend.py:1807-1827: ca.nlpsol "ipopt"; legacy
+ * pycollo/nlp.py:84-115) and IPOPT iterates in native code, calling the callbacks and its linear solver
+ * (backend.py:1703-1711).  Here the iterate v = [x ; slacks], lambda, the bound multipliers, the step and every
+ * right-hand side stay in device memory; one call per part of an iteration, a few scalars back each.  The algorithm
+ * -- and its scalar logic: filter, barrier update, termination -- is pycollo_amd/ipm.py's. */
+typedef struct pc_ipm pc_ipm;
+typedef struct {
+  int64_t n, m, ns;                 /* NLP variables, constraints, slacks (inequality rows) */
+  const int64_t* ineq_rows;         /* [ns] */
+  const double *vl, *vu;            /* [n + ns] bounds on v */
+  const uint8_t *hasl, *hasu, *fixed;   /* [n + ns] finite lower / upper bound, fixed unknown */
+  const double *row_scale, *rhs_c;  /* [m] IPOPT-style gradient-based row scaling; equality right-hand sides */
+  double obj_scale;                 /* the objective's scaling factor */
+} pc_ipm_desc;
+int pc_ipm_create(pc_handle* h, pc_kkt* k, const pc_ipm_desc* desc, pc_ipm** out);
+void pc_ipm_destroy(pc_ipm* s);
+int pc_ipm_set_state(pc_ipm* s, const double* v, const double* lambda, const double* zl, const double* zu);
+int pc_ipm_get_state(pc_ipm* s, double* v, double* lambda, double* zl, double* zu, double* c, double* g);   /* NULL: skipped */
+/* evaluate J, grad J, g, jac_g at the current v; out3 = scaled objective, sum |c|, max |c| */
+int pc_ipm_eval_point(pc_ipm* s, double* out3);
+/* out10 = max |grad L| over free unknowns, max |c|, sum |c|, max / min of (v - vl) zl, max / min of (vu - v) zu,
+ * sum |lambda|, sum zl, sum zu -- E_mu of Waechter & Biegler eq. (5) follows for any mu */
+int pc_ipm_errors(pc_ipm* s, double* out10);
+/* the Newton step for barrier parameter mu (after pc_ipm_errors at this point): Hessian, KKT assembly, factorisation
+ * with the inertia-correcting regularisation loop (delta_w schedule from dw_last), refined solve, bound-multiplier
+ * steps, fraction-to-the-boundary limits.  out8 = dw (< 0: regularisation failed), alpha_max, alpha_z, grad phi . dv,
+ * mu x barrier sum at v, factorisations, back-substitutions, non-finite flag */
+int pc_ipm_newton(pc_ipm* s, double mu, double tau, double dw_last, double* out8);
+/* trial point v + alpha dv: out3 = scaled objective, sum |c|, mu x barrier sum there */
+int pc_ipm_trial(pc_ipm* s, double alpha, double mu, double* out3);
+/* accept the last trial point: v, lambda (+= alpha), z (+= alpha_z, kept near the central path); grad J, jac_g at the new v */
+int pc_ipm_accept(pc_ipm* s, double alpha, double alpha_z, double mu);
+
 /* Evaluate at (x, obj_factor, lambda) and leave g, jac_g and the Lagrangian Hessian in device memory; only J,
  * grad J (dense n, may be NULL) and g (may be NULL) come back.  lambda == NULL: g and jac_g only. */
 int pc_eval_resident(pc_handle* h, const double* x, double obj_factor, const double* lambda, double* f, double* grad,

@@ -278,8 +278,30 @@ def _point_struct(pt: PointModel) -> str:
     return "\n".join(lines)
 
 
-def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) -> str:
+def _norm_mixed(model: Model, orders, mixed):
+    """Per phase the sorted tuple of section orders a mixed build specialises (empty: the phase is not mixed)."""
+    if mixed is None:
+        return tuple(() for _ in model.phases)
+    mixed = tuple(tuple(sorted({int(n) for n in m})) for m in mixed)
+    if len(mixed) != len(model.phases):
+        raise ValueError("one tuple of specialised orders (or an empty one) per phase is required")
+    for o, m in zip(orders, mixed):
+        if m and int(o) != 0:
+            raise ValueError("a phase is either compiled for one order or mixed (orders[p] == 0)")
+        if any(n < 2 or n > 20 for n in m):
+            raise ValueError("section orders lie in [2, 20]")
+    return mixed
+
+
+def generate_source(model: Model, orders=None, heavy_cap: bool | None = None, mixed=None) -> str:
+    """``mixed[p]`` non-empty: phase p's mesh has sections of several orders and its tile kernels carry one body per
+    listed order next to the any-order body (pc::bulk_mix picks per tile from the tile's record)."""
     orders = tuple(orders) if orders is not None else tuple(0 for _ in model.phases)
+    mixed = _norm_mixed(model, orders, mixed)
+    any_mixed = any(mixed)
+
+    def seq(pm):
+        return "std::integer_sequence<int, " + ", ".join(str(n) for n in mixed[pm.index]) + ">{}"
     if heavy_cap is None:
         heavy_cap = _heavy_cap_enabled()
     heavy_any = any(is_heavy(pm) for pm in model.phases)
@@ -339,41 +361,67 @@ def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) ->
     occ = _occupancy_attr()
     lead_sig = ('const double* xz, const double* lamd, const double* qa, const double* sec_h, int N, int K, '
                 'int tile_begin, int n_blocks, int wa, int wb')
+    # A heavy model's code object is compiled in parts, side by side (build_code_object: -DPC_PART=k, one module each):
+    # part 0 holds the per-phase kernels, the mesh-error kernels and the tails, every merged / resident / per-replica
+    # launch kernel is a part of its own.  PC_PART < 0: everything in one object.
+    parts.append("#ifndef PC_PART\n#define PC_PART -1\n#endif")
+    parts.append("#if PC_PART <= 0")
     for pm in model.phases:
         # leading scalars = struct PcLead, member by member: the command processor preloads them into SGPRs
         hv = _heavy_attr(is_heavy(pm), heavy_cap)
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}({lead_sig}, PcPhaseArgs a) {{')
-        parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, false, 0, -1, &ld);')
+        if mixed[pm.index] and len(model.phases) == 1:
+            parts.append('  const PcPhaseArgs& ka = pc::kernarg_phase_args();   // (a itself is not named: see there)')
+            parts.append('  const int blk = pc::xcd_major((int)blockIdx.x, n_blocks);')
+            parts.append(f'  pc::bulk_mix<gen::Phase{pm.index}, false, 0, 0>({seq(pm)}, ka.tile_rec + blk, ka, false, 0, blk);')
+        else:   # (the per-phase kernels of a multi-phase mixed build keep the any-order body: only the merged launch is specialised)
+            parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+            parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}>(a, false, 0, -1, &ld);')
         parts.append('}')
+    parts.append("#endif")
     if len(model.phases) == 1:
         pm = model.phases[0]
         parts.append("// resident-tail build: block 0 runs the tail beside the tiles, one launch per evaluation")
         hv = _heavy_attr(is_heavy(pm), heavy_cap)
+        parts.append(f'#if PC_PART < 0 || PC_PART == {1}')
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}_r({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
         parts.append('  const int ntb = (wa >> 28) & 7;   // leading workgroups that run the tail')
         parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
-        parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
-        parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - ntb, n_blocks), &ld);')
+        if mixed[pm.index]:
+            parts.append('  const PcPhaseArgs& ka = pc::kernarg_phase_args();')
+            parts.append('  const int blk = pc::xcd_major((int)blockIdx.x - ntb, n_blocks);')
+            parts.append(f'  pc::bulk_mix<gen::Phase{pm.index}, true, 0, 0>({seq(pm)}, ka.tile_rec + blk, ka, false, 0, blk);')
+        else:
+            parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+            parts.append(f'  pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true>(a, false, 0, pc::xcd_major((int)blockIdx.x - ntb, n_blocks), &ld);')
         parts.append('}')
+        parts.append('#endif')
         # The same launch with the replica index as a template argument, one kernel per waves-per-tile count: a
         # replica's copy of the tile body then holds only the items dealt to it (everything else is dead code in that
         # copy) -- 6-8 % on every workload that shares tiles (config 2, W = 4: 4.45-4.7 -> 4.14-4.32 us).  pc_create
         # picks pc_bulk_p0_r_w<W> when the code object has it (which W exist: _static_w_list).
         static_ws = _static_w_list(pm, single_phase=True)
         for wn in static_ws:
+            parts.append(f'#if PC_PART < 0 || PC_PART == {2 + static_ws.index(wn)}')
             parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hv}pc_bulk_p{pm.index}_r_w{wn}({lead_sig}, PcPhaseArgs a, PcTailArgs t) {{')
             parts.append('  const int ntb = (wa >> 28) & 7;')
             parts.append('  if ((int)blockIdx.x < ntb) { gen::Tail::run<true>(t, nullptr, (int)sizeof(PcBulkArgs), (int)blockIdx.x, ntb); return; }')
-            parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
+            if mixed[pm.index]:
+                parts.append('  const PcPhaseArgs& ka = pc::kernarg_phase_args();')
+            else:
+                parts.append('  const PcLead ld{xz, lamd, qa, sec_h, N, K, tile_begin, n_blocks, wa, wb};')
             parts.append(f'  if (((wa >> 8) & 0xf) != {wn}) return;   // (built for exactly that many waves per tile; the host checks too)')
             parts.append('  const int blk = pc::xcd_major((int)blockIdx.x - ntb, n_blocks);')
             parts.append('  switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {')
             for wv in range(wn):
-                parts.append(f'    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true, {wn}, {wv}>(a, false, 0, blk, &ld); return;')
+                if mixed[pm.index]:
+                    parts.append(f'    case {wv}: pc::bulk_mix<gen::Phase{pm.index}, true, {wn}, {wv}>({seq(pm)}, ka.tile_rec + blk, ka, false, 0, blk); return;')
+                else:
+                    parts.append(f'    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, true, {wn}, {wv}>(a, false, 0, blk, &ld); return;')
             parts.append('    default: return;')
             parts.append('  }')
             parts.append('}')
+            parts.append('#endif')
     else:
         np_ = len(model.phases)
 
@@ -387,39 +435,52 @@ def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) ->
             for i, pm in enumerate(model.phases):
                 cond = f"if (b < fb{i + 1}) " if i + 1 < np_ else ""
                 args = f"(ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch)"
+                margs = f"({seq(pm)}, trec + b, ph[{i}], true, fb{i}, b, nullptr, x, lam, c, G, H, flags, epoch)" if mixed[pm.index] else ""
+
+                def call(wn_, wv_):
+                    if mixed[pm.index]:
+                        return f"pc::bulk_mix<gen::Phase{pm.index}, {rs}, {wn_}, {wv_}>{margs}"
+                    return f"pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}, {wn_}, {wv_}>{args}"
                 if wn > 0:
                     out.append(f"  {cond}{{ switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {{")
                     for wv in range(wn):
-                        out.append(f"    case {wv}: pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}, {wn}, {wv}>{args}; return;")
+                        out.append(f"    case {wv}: {call(wn, wv)}; return;")
                     out.append("    default: return; } }")
                 else:
-                    out.append(f"  {cond}{{ pc::bulk<gen::Phase{pm.index}, {int(orders[pm.index])}, {rs}>{args}; return; }}")
+                    out.append(f"  {cond}{{ {call(0, 0)}; return; }}")
             return out
         parts.append("// every phase in one launch: a workgroup finds its phase from the cumulative block counts")
         # The members of PcMultiArgs travel as separate scalar parameters (same order, same offsets: the host still
         # hands over the struct) and reach pc::bulk as values: as ONE by-value struct whose address is passed on, a
         # large kernel keeps it in scratch memory (seen: 112 B per lane, a scratch set-up on every wave of the launch).
         multi_sig = ("const double* x, const double* lam, double* c, double* G, double* H, const PcPhaseArgs* ph, int flags, "
-                     "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tail_blocks")
+                     "int n_phases, " + ", ".join(f"int fb{i}" for i in range(9)) + ", unsigned epoch, int tail_blocks, const PcTileRec* trec")
         parts.append("static_assert(PC_MAX_PHASES + 1 == 9, \"pc_bulk_all spells PcMultiArgs::first_block out\");")
         hva = _heavy_attr(heavy_any, heavy_cap)
+        parts.append(f'#if PC_PART < 0 || PC_PART == {1}')
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + hva + 'pc_bulk_all(' + multi_sig + ') {')
         parts += all_body(False)
         parts.append("}")
+        parts.append('#endif')
         parts.append("// the same with the resident tail as block 0")
+        parts.append(f'#if PC_PART < 0 || PC_PART == {2}')
         parts.append('extern "C" __global__ void __launch_bounds__(256) ' + occ + hva + 'pc_bulk_all_r(' + multi_sig + ', PcTailArgs t) {')
         parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
         parts += all_body(True)
         parts.append("}")
+        parts.append('#endif')
         # replica index compiled in (see pc_bulk_p<i>_r_w<W> above): W = 2 always -- for heavy models this is the two-wave
         # build --, W = 4 when every phase is light or medium
         multi_ws = sorted(set.intersection(*[set(_static_w_list(pm)) for pm in model.phases]))
         for wn in multi_ws:
+            parts.append(f'#if PC_PART < 0 || PC_PART == {3 + multi_ws.index(wn)}')
             parts.append(f'extern "C" __global__ void __launch_bounds__(256) {occ}{hva}pc_bulk_all_r_w{wn}(' + multi_sig + ', PcTailArgs t) {')
             parts.append('  if ((int)blockIdx.x < tail_blocks) { gen::Tail::run<true>(t, nullptr, (int)((sizeof(PcMultiArgs) + 7) & ~7), (int)blockIdx.x, tail_blocks); return; }')
             parts += all_body(True, wn)
             parts.append("}")
+            parts.append('#endif')
     parts.append("")
+    parts.append("#if PC_PART <= 0")
     for pm in model.phases:
         parts.append(f'extern "C" __global__ void __launch_bounds__(256) pc_mesh_err_p{pm.index}(PcRefineArgs a) '
                      f'{{ pc::mesh_error<gen::Phase{pm.index}>(a); }}')
@@ -434,8 +495,27 @@ def generate_source(model: Model, orders=None, heavy_cap: bool | None = None) ->
     parts.append('  const PcTailLead ld{x, partials0, scal0, x_off0, n_tiles0, N0, flags, block_threads};')
     parts.append('  gen::Tail::run<false, true>(a, &ld);')
     parts.append('}')
+    parts.append("#endif")
     parts.append("")
     return "\n".join(parts)
+
+
+def n_parts(model: Model) -> int:
+    """Parts a model's code object is compiled in (generate_source: PC_PART): 1 unless a phase is heavy."""
+    if not any(is_heavy(pm) for pm in model.phases) or os.environ.get("PYCOLLO_AMD_SPLIT_BUILD", "1") == "0":
+        return 1
+    if len(model.phases) == 1:
+        return 2 + len(_static_w_list(model.phases[0], single_phase=True))
+    return 3 + len(sorted(set.intersection(*[set(_static_w_list(pm)) for pm in model.phases])))
+
+
+def part_paths(code_object: str) -> list[str]:
+    """The modules of a code object: the file itself and its siblings <base>.p<k>.hsaco (pc_create loads them all)."""
+    out, k = [code_object], 1
+    while os.path.exists(f"{code_object[:-6]}.p{k}.hsaco"):
+        out.append(f"{code_object[:-6]}.p{k}.hsaco")
+        k += 1
+    return out
 
 
 def _waves_per_eu() -> int:
@@ -506,14 +586,18 @@ def hipcc_path() -> str | None:
     return None
 
 
-def _orders_tag(model: Model, orders) -> str:
+def _orders_tag(model: Model, orders, mixed=None) -> str:
     orders = tuple(int(o) for o in orders) if orders is not None else tuple(0 for _ in model.phases)
     if len(orders) != len(model.phases):
         raise ValueError("one section order (or 0) per phase is required")
-    return "n" + "_".join(str(o) for o in orders)
+    tag = "n" + "_".join(str(o) for o in orders)
+    mixed = _norm_mixed(model, orders, mixed)
+    if any(mixed):
+        tag += "-m" + "_".join(".".join(str(n) for n in m) if m else "x" for m in mixed)
+    return tag
 
 
-def code_object_path(model: Model, orders=None) -> str:
+def code_object_path(model: Model, orders=None, mixed=None) -> str:
     occ = f"_w{_waves_per_eu()}" if _waves_per_eu() > 0 else ""
     if _fp_contract() != "off":
         occ += "_fc" + _fp_contract()
@@ -523,18 +607,20 @@ def code_object_path(model: Model, orders=None) -> str:
         occ += "_nocap"
     if not _heavy_w4_enabled():
         occ += "_nohw4"
+    if HEAVY_SCRATCH_LIMIT != 128:          # (decides whether a heavy model's kernels keep their register cap)
+        occ += f"_sl{HEAVY_SCRATCH_LIMIT}"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]
-    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders)}{occ}.hsaco")
+    return os.path.join(CACHE, f"model_{model.digest}_{_kernels_stamp()}_{_orders_tag(model, orders, mixed)}{occ}.hsaco")
 
 
-def build_code_object(model: Model, orders=None, force: bool = False, verbose: bool = False) -> str:
+def build_code_object(model: Model, orders=None, force: bool = False, verbose: bool = False, mixed=None) -> str:
     """Return the path of the gfx950 code object for ``model``, compiling it if it is not cached.
 
     ``orders[p] = n > 0`` specialises phase p's kernel for meshes whose sections all have n nodes;
     0 keeps it generic (any mesh)."""
     os.makedirs(CACHE, exist_ok=True)
-    out = code_object_path(model, orders)
+    out = code_object_path(model, orders, mixed)
     if os.path.exists(out) and not force:
         return out
     hipcc = hipcc_path()
@@ -555,31 +641,43 @@ def build_code_object(model: Model, orders=None, force: bool = False, verbose: b
     # spills more than HEAVY_SCRATCH_LIMIT bytes per lane the model does not fit (space station) and the object is
     # built again without the cap.
     attempts = [True, False] if (any(is_heavy(pm) for pm in model.phases) and _heavy_cap_enabled()) else [False]
+    nparts = n_parts(model)
+    part_out = [out] + [f"{out[:-6]}.p{k}.hsaco" for k in range(1, nparts)]
     for cap in attempts:
+        # (the source of an attempt is per process: another process may be compiling the other attempt of the same object)
         with open(src + tmp_tag, "w") as f:
-            f.write(generate_source(model, orders, heavy_cap=cap))
-        os.replace(src + tmp_tag, src)           # (whole file or none: another process may be compiling the same source)
+            f.write(generate_source(model, orders, heavy_cap=cap, mixed=mixed))
         # -ffp-contract=off: no fused multiply-add, so V*x~ + r and every model expression round exactly like
         # the reference's CasADi / NumPy arithmetic (tests/unit/test_iteration.py:302 asserts J == 100 exactly)
-        cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
-               "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
-               f"-I{CSRC}", "-o", tmp_out, src] + [f"-D{d}" for d in _extra_defines()]
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{res.stderr[-4000:]}")
-        if verbose:
-            print(res.stderr)
-        resources = _parse_resources(res.stderr)
+        base = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
+                "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
+                f"-I{CSRC}", "-x", "hip"] + [f"-D{d}" for d in _extra_defines()]
+        # a heavy model's object is compiled in parts (generate_source: PC_PART), side by side: one module per launch kernel
+        procs = [subprocess.Popen(base + [f"-DPC_PART={k if nparts > 1 else -1}", "-o", part_out[k] + tmp_tag, src + tmp_tag],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(nparts)]
+        resources = {}
+        for pr in procs:
+            _, err = pr.communicate()
+            if pr.returncode != 0:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                raise RuntimeError(f"hipcc failed for {src}:\n{err[-4000:]}")
+            if verbose:
+                print(err)
+            resources.update(_parse_resources(err))
         worst = max((k.get("scratch", 0) for name, k in resources.items() if name.startswith("pc_bulk")), default=0)
         if not cap or worst <= HEAVY_SCRATCH_LIMIT:
             break
+    os.replace(src + tmp_tag, src)               # (kept for inspection: tools/isa_lines.py)
     # what the compiler made of every kernel travels with the object: pc_create's launch shape depends on it (a
     # two-wave build that did not fit 256 registers must not be launched as one)
-    resources["_build"] = {"heavy_cap": bool(cap)}
+    resources["_build"] = {"heavy_cap": bool(cap), "parts": nparts, "scratch_limit": HEAVY_SCRATCH_LIMIT}
     with open(resources_path(out) + tmp_tag, "w") as f:
         json.dump(resources, f, indent=1, sort_keys=True)
     os.replace(resources_path(out) + tmp_tag, resources_path(out))
-    os.replace(tmp_out, out)
+    for k in range(nparts - 1, -1, -1):          # the object itself last: its presence says the build is complete
+        os.replace(part_out[k] + tmp_tag, part_out[k])
     return out
 
 
@@ -627,7 +725,7 @@ def two_wave_occupancy(model: Model, code_object: str) -> int:
     return int(k.get("occupancy", 0))
 
 
-def kernel_resources(model: Model, orders=None) -> dict:
+def kernel_resources(model: Model, orders=None, mixed=None) -> dict:
     """Registers and scratch memory of every kernel of the model's code object, as hipcc reports them
     (``-Rpass-analysis=kernel-resource-usage``): {kernel: {"vgprs", "sgprs", "scratch", "occupancy"}}.  A bulk kernel
     with scratch memory is a bug of the templates (an array subscripted by a run-time value), not a tuning matter:
@@ -640,7 +738,7 @@ def kernel_resources(model: Model, orders=None) -> dict:
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, "m.hip")
         with open(src, "w") as f:
-            f.write(generate_source(model, orders))
+            f.write(generate_source(model, orders, mixed=mixed))
         cmd = [hipcc, f"--offload-arch={ARCH}", "--genco", "-O3", "-std=c++17", f"-ffp-contract={_fp_contract()}",
                "-mllvm", f"-amdgpu-kernarg-preload-count={_preload_count()}", "-Rpass-analysis=kernel-resource-usage",
                f"-I{CSRC}", "-o", os.path.join(tmp, "m.hsaco"), src] + [f"-D{d}" for d in _extra_defines()]

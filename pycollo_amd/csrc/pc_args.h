@@ -10,6 +10,23 @@
 #define PC_FLAG_G 2
 #define PC_FLAG_H 4
 
+// One record per workgroup of a launch over a phase whose sections differ in order and whose code object carries
+// order-specialised tile bodies next to the any-order one ("mixed" build, codegen): which body runs the tile and where
+// the tile sits in the mesh, so that an order-pure tile needs no section tables.  Records are in launch order (the
+// launched tile ranges of the phases one after the other): workgroup b of the launch reads record b.
+struct PcTileRec {
+  int32_t phase;     // phase of the tile
+  int32_t tile;      // tile index inside its phase
+  int32_t order;     // n > 0: every section of the tile has n nodes and the code object has a body for n; 0: any-order body
+  int32_t k0, nsec;  // first section, number of sections
+  int32_t n0;        // first node
+  int32_t nprev;     // nodes of section k0 - 1 (the tile's first node closes it); 0 at k0 == 0
+  int32_t qa_prev;   // offset of A_nprev inside the packed A tables
+  int64_t E0;        // sec_E[k0]
+  double w_prev;     // last quadrature weight of order nprev
+  int32_t reserved[4];
+};
+
 #define PC_MAX_GOFF 32
 #define PC_MAX_HOFF 96
 #define PC_MAX_SCAL 96
@@ -39,6 +56,7 @@ struct PcPhaseArgs {
   unsigned long long* erec;      // [n_rec][2] edge-node Hessian entries an endpoint term is added to (all phases)
   const double* tab;      // device copy of scal | goff | hoff (packed, used entries only): staged into LDS by
                           // the kernels of models whose tables do not fit the scalar register file
+  const PcTileRec* tile_rec;  // mixed build: the records of this launch's tiles of this phase (record of workgroup 0 first)
   int64_t x_off, s_off;   // first x index of the phase / of the static parameters
   int64_t c_off, c_path_off, c_int_off;
   double t_fixed[2];
@@ -72,16 +90,17 @@ struct PcPhaseArgs {
 //                staged by the kernels of models whose tables do not fit the scalar register file
 //   mesh_tables  the kernel handles any mesh (compiled order 0) and stages the tile's section tables and the
 //                per-order table offsets; an order-specialised kernel does index arithmetic instead
+//   mixed        order-specialised body inside a mixed build: the section before the tile may have another order
 // LDS per tile is what bounds the waves a CU holds for the multi-state models: nothing is reserved that the
 // kernel at hand does not use.
 struct LdsPlan {
-  int qa, qw, off, tab, h, E, s, kr, f, yu, fs, lam, red, out, total;
+  int qa, qw, off, tab, h, E, s, kr, cp, f, yu, fs, lam, red, out, total;
 };
 #ifdef __HIPCC__
 __host__ __device__
 #endif
 inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int NRED, int lds_out, int tab_doubles,
-                        bool mesh_tables) {
+                        bool mesh_tables, bool mixed = false) {
   LdsPlan p;
   int o = 0;
   p.qa = o; o += qa_total;
@@ -92,6 +111,7 @@ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int
   p.E = o; o += mesh_tables ? TB + 2 : 0;                 // int64 entries
   p.s = o; o += mesh_tables ? (TB + 4) / 2 + 1 : 0;       // int32 entries, (TB+3) of them
   p.kr = o; o += mesh_tables ? (TB + 1) / 2 + 1 : 0;      // int32 entries
+  p.cp = o; o += (mixed && !mesh_tables) ? PC_MAX_ORDER : 0;   // order-pure tile of a mixed mesh: the previous section's last A column
   p.fs = o; o += NFS * TB;
   p.red = o; o += (NRED > 0 ? NRED : 1) * 16;
   // f, y and the staged multipliers are dead once the defect values are formed; the output staging buffer
@@ -106,6 +126,34 @@ inline LdsPlan lds_plan(int TB, int qa_total, int qw_total, int NY, int NFS, int
   }
   p.total = o;
   return p;
+}
+
+// Row groups of the order-specialised tile bodies (pc::bulk, "row groups"): in how many passes over the section rows
+// a state's defect-Jacobian block of a tile of n-node sections is staged and flushed, given the longest row of any
+// state (D n + C doubles).  Two staging regions per workgroup (the two-wave build) must fit PC_STAGE_BUDGET doubles --
+// what leaves the workgroup inside a quarter of a CU's LDS next to its tables.  One pass while a tile of at least 85 %
+// of the full tile's rows fits (the host then shortens the tile a little: Delta III at order 5 runs 56-node tiles);
+// else the fewest passes with which the full tile fits.  The kernels and the host's LDS sizing (pc_desc.hpp) both
+// call this.
+#define PC_STAGE_BUDGET 4480   // doubles: 2 regions x 17.5 KiB
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int pc_row_passes(int n, int max_row_len) {
+  if (n < 3 || max_row_len <= 0) return 1;
+  const int nq = 63 / (n - 1);   // sections of a full tile
+  if (20 * (PC_STAGE_BUDGET / 2 / max_row_len) >= 17 * nq * (n - 1)) return 1;
+  int np = 2;
+  while (np < n - 1 && 2 * nq * ((n - 1 + np - 1) / np) * max_row_len > PC_STAGE_BUDGET) ++np;
+  return np;
+}
+// rows a pass holds
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+constexpr int pc_row_group(int n, int max_row_len) {
+  const int np = pc_row_passes(n, max_row_len);
+  return (n - 1 + np - 1) / np;
 }
 
 // The first 14 dwords of pc_bulk_p<i>'s argument block, passed as leading scalar kernel parameters: the command
@@ -144,6 +192,7 @@ struct PcMultiArgs {
   uint32_t epoch;                         // tag of this launch's granules (resident-tail build)
   int32_t tail_blocks;                    // resident-tail build: leading workgroups that run the tail (1, or one per part
                                           //   of a heavy endpoint block); the tiles follow
+  const PcTileRec* trec;                  // mixed build: one record per tile workgroup of the launch, else null
 };
 #define PC_MAX_POINT 96           // endpoint (point) variables: y(t0), y(tF), q, t of every phase, s
 #define PC_MAX_ENDPOINT_ROWS 32   // endpoint constraint rows

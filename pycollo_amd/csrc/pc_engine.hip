@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -16,6 +17,8 @@
 #include "pc_args.h"
 #include "pc_pattern.hpp"
 #include "pc_desc.hpp"
+
+struct pc_kkt;   // (pc_kkt.hip; the interior-point state below drives it through the exported calls)
 
 namespace {
 
@@ -85,6 +88,7 @@ struct PhaseDev {
   hipFunction_t fn = nullptr;
   hipFunction_t fn_res = nullptr;    // single-phase problems: bulk kernel with the resident tail as block 0
   int lds_bytes = 0, n_tiles = 0, nfs = 0;
+  std::function<int(int)> lds_for;   // LDS bytes of this phase's workgroups with w staging regions
   int tile_begin = 0, tile_end = 0;  // launched tile range (whole phase unless sharded)
   double* partials_ext = nullptr;    // caller-owned partial-sum buffer (sharded exchange), else `partials`
   std::vector<double> scal_host;
@@ -153,10 +157,16 @@ struct pc_handle {
   // device
   hipStream_t stream = nullptr;
   hipModule_t module = nullptr;
+  std::vector<hipModule_t> more_modules;   // a heavy model's code object comes in parts (<base>.p<k>.hsaco, codegen.n_parts)
   hipFunction_t tail_fn = nullptr;
   hipFunction_t tail_big_fn = nullptr;   // same kernel with the partial-sum loads of several strides in flight
   hipFunction_t bulk_all_fn = nullptr;   // multi-phase problems: every phase's bulk kernel in one launch
   DevBuf<char> d_phase_args;             // [n_phases] PcPhaseArgs read by pc_bulk_all
+  bool mixed = false;                    // some phase runs the mixed build: per-tile records pick the tile body
+  std::vector<PcTileRec> trec_all;       // records of every tile, phase after phase
+  std::vector<size_t> trec_base;         // [n_phases] first record of each phase in trec_all
+  DevBuf<PcTileRec> d_trec;              // records of the launched tile ranges, in launch order
+  std::vector<int> trec_first;           // [n_phases] first record of each phase in d_trec
   bool args_dirty = true;                // scaling / tile range / partials buffer changed since the last upload
   // host-side argument blocks, filled once per change of scaling / tile range / partials buffer; a call only
   // patches the caller's pointers, the flags and sigma into them
@@ -305,6 +315,7 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   a.erec = h->d_erec.p;
   a.erec0 = D.erec0;
   a.tab = D.tab.p;
+  a.tile_rec = (h->mixed && h->d_trec.p) ? h->d_trec.p + h->trec_first[ip] : nullptr;
   a.x_off = P.x_off;
   a.s_off = Q.s_off;
   a.c_off = P.c_off;
@@ -338,6 +349,18 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     res = D.tile_begin == 0 && D.tile_end == D.n_tiles && !D.partials_ext;
   }
   if (h->host_args_dirty) {
+    if (h->mixed) {   // the records of the launched tile ranges, in launch order (pc_args.h::PcTileRec)
+      std::vector<PcTileRec> recs;
+      h->trec_first.assign(Q.ph.size(), 0);
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+        auto& D = *h->pd[ip];
+        h->trec_first[ip] = (int)recs.size();
+        for (int t = D.tile_begin; t < D.tile_end; ++t) recs.push_back(h->trec_all[h->trec_base[ip] + t]);
+      }
+      if (recs.empty()) recs.push_back(PcTileRec{});
+      HIP_OK(hipDeviceSynchronize());   // no launch in flight may still read the old records
+      h->d_trec.upload(recs);
+    }
     h->host_bulk_args.resize(Q.ph.size());
     for (size_t ip = 0; ip < Q.ph.size(); ++ip)
       fill_phase_args(h, ip, h->host_bulk_args[ip].a, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h->pd[ip]->wpt);
@@ -377,6 +400,7 @@ void launch_all(pc_handle* h, const double* d_x, const double* d_lam, double* d_
     m.flags = flags;
     m.n_phases = (int32_t)Q.ph.size();
     m.epoch = h->epoch;
+    m.trec = h->mixed ? h->d_trec.p : nullptr;
     int nb = 0;
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       m.first_block[ip] = nb;
@@ -577,6 +601,18 @@ void copy_down(pc_handle* h, size_t begin, size_t end) {   // [begin, end) of th
                         h->stream));
 }
 
+// a kernel of the handle's code object, whichever of its modules holds it
+hipError_t find_fn(pc_handle* h, hipFunction_t* fn, const char* name) {
+  *fn = nullptr;
+  hipError_t e = hipModuleGetFunction(fn, h->module, name);
+  for (size_t i = 0; e != hipSuccess && i < h->more_modules.size(); ++i) {
+    (void)hipGetLastError();
+    e = hipModuleGetFunction(fn, h->more_modules[i], name);
+  }
+  if (e != hipSuccess) *fn = nullptr;
+  return e;
+}
+
 template <class F>
 int guarded(F&& f) {
   try {
@@ -666,6 +702,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     // LDS hold four tiles.  The tile capacity is the largest that allows it (Delta III, order 5: 60 rows of 40 doubles per
     // replica; 4 x 12.5 k nodes 30.6 -> 23.2 us).  PYCOLLO_AMD_TWO_WAVE=0 turns the mode off; an explicit
     // PYCOLLO_AMD_WPT / PYCOLLO_AMD_TILE_NODES leaves the choice to the caller.
+    for (auto& P : Q.ph) h->mixed = h->mixed || !P.spec_orders.empty();
     h->two_wave = d->two_wave_occupancy >= 2 && TB == 64 && !std::getenv("PYCOLLO_AMD_WPT") &&
                   !std::getenv("PYCOLLO_AMD_TILE_NODES");
     if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE")) h->two_wave = h->two_wave && std::atoi(env) != 0;
@@ -684,10 +721,55 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_MAX_TILES")) max_tiles = std::atoll(env);
       h->two_wave = h->two_wave && tiles64 > 400 && tiles64 <= max_tiles;
     }
-    if (h->two_wave) {
+    constexpr int kQuarterCu = 30 * 1280;
+    if (h->mixed) {
+      // Mixed build: tiles are cut per order (pc_pattern.hpp::build_tiles_mixed) under row caps that keep a workgroup's
+      // LDS inside the budget -- a quarter CU for the two-wave build (below), else what a workgroup may request -- and
+      // the two-wave build is kept when every wave of the launch is then resident at once, as for a uniform mesh.
+      if (const char* env = std::getenv("PYCOLLO_AMD_MIX_MIN_RUN_ROWS"))
+        for (auto& P : Q.ph) P.min_run_rows = std::max(1, std::atoi(env));
+      auto cut = [&](int W, int budget) {
+        int64_t tiles = 0;
+        for (auto& P : Q.ph) {
+          if (!P.spec_orders.empty()) {
+            pcp::phase_set_caps(P, 64, W, qa_n, qw_n, budget);
+            // A launch is one generation of waves and lasts as long as its slowest one: a tile of several orders runs
+            // the any-order body, which takes about twice as long per row as an order-specialised one -- such tiles are
+            // kept to half the rows so that they finish with the others (measured: with 63-row any-order tiles among
+            // 835 order-pure ones the mixed build ran no faster than the any-order kernel alone, 51.3 / 50.6 us)
+            int mix_rows = 32;
+            if (const char* env = std::getenv("PYCOLLO_AMD_MIX_CAP_ROWS")) mix_rows = std::max(8, std::atoi(env));
+            P.mix_cap_rows = std::min(P.mix_cap_rows, mix_rows);
+          }
+          pcp::build_tiles(P, TC);
+          tiles += (int64_t)P.tile_k0.size() - 1;
+        }
+        return tiles;
+      };
+      if (h->two_wave) {
+        // (phases of a single order inside a mixed problem: one tile capacity for them, as below)
+        int tc = 64;
+        auto need_uniform = [&](int t) {
+          int mx = 0;
+          for (auto& P : Q.ph)
+            if (P.spec_orders.empty())
+              mx = std::max(mx, phase_lds_bytes(P, 64, qa_n, qw_n, 2 * phase_lds_out(P, t - 1, t), P.compiled_order == 0));
+          return mx;
+        };
+        while (tc > std::max(max_nk, 32) && need_uniform(tc) > kQuarterCu) --tc;
+        TC = tc;
+        const int64_t tiles = cut(2, kQuarterCu);
+        int64_t max_waves = 2048;   // every wave of the launch resident at once (two per SIMD)
+        if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_MAX_WAVES")) max_waves = std::atoll(env);
+        if (need_uniform(tc) > kQuarterCu || 2 * tiles > max_waves) {
+          h->two_wave = false;
+          TC = TB;
+        }
+      }
+      if (!h->two_wave) cut(1, h->lds_limit);
+    } else if (h->two_wave) {
       // four workgroups per CU: a quarter of the 160 KiB less two allocation granules of 1280 B -- measured, Delta III
       // 4 x 12.5 k nodes: 37 272 B per workgroup 23.2 us, 39 832 B (nominally still a quarter) 26.8 us
-      constexpr int kQuarterCu = 30 * 1280;
       int tc = 64;
       while (tc > std::max(max_nk, 32) && lds_need(64, tc, 2) > kQuarterCu) --tc;
       // ... and every wave of the launch resident at once (2048 wave slots at two per SIMD): with smaller tiles than
@@ -709,6 +791,31 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     }
     h->TC = TC;
     pcp::build_all(Q, TC);
+    if (h->mixed) {   // one record per tile: which body runs it and where it sits in the mesh
+      for (auto& P : Q.ph)
+        for (int k = 0; k < P.K; ++k)
+          if (h->qa_off[P.n_k[k]] < 0) throw std::runtime_error("no quadrature table for a section order in use");
+      h->trec_base.assign(Q.ph.size(), 0);
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+        auto& P = Q.ph[ip];
+        h->trec_base[ip] = h->trec_all.size();
+        for (size_t t = 0; t + 1 < P.tile_k0.size(); ++t) {
+          PcTileRec r{};
+          const int k0 = P.tile_k0[t];
+          r.phase = (int32_t)ip;
+          r.tile = (int32_t)t;
+          r.order = t < P.tile_order.size() ? P.tile_order[t] : 0;
+          r.k0 = k0;
+          r.nsec = P.tile_k0[t + 1] - k0;
+          r.n0 = P.sec_s[k0];
+          r.nprev = k0 > 0 ? P.n_k[k0 - 1] : 0;
+          r.qa_prev = r.nprev ? h->qa_off[r.nprev] : 0;
+          r.E0 = P.sec_E[k0];
+          r.w_prev = r.nprev ? h->qw[h->qw_off[r.nprev] + r.nprev - 1] : 0.0;
+          h->trec_all.push_back(r);
+        }
+      }
+    }
     if (Q.point_x.size() > PC_MAX_POINT || Q.n_b > PC_MAX_ENDPOINT_ROWS)
       throw std::runtime_error("too many endpoint variables / endpoint constraints for the tail kernel's argument block");
     if (Q.tail_owned.size() > PC_TAIL_OWNED_MAX)
@@ -749,6 +856,16 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, phase_max_tile_rows(P), std::min(TC, phase_max_tile_rows(P) + 1));   // the largest tile's runs
+      bool any_pure = false, any_generic = false;
+      if (!P.spec_orders.empty()) D.lds_out = phase_lds_out_tiles(P, &any_pure, &any_generic);   // every row with its own order
+      // LDS of the phase's workgroups with w staging regions: the larger of the tile bodies the phase's tiles run
+      D.lds_for = [&P, &D, TB, qa_n, qw_n, mesh_tables, any_pure, any_generic](int w) {
+        if (P.spec_orders.empty()) return phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, mesh_tables);
+        int b = 0;
+        if (any_generic) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, true, true));
+        if (any_pure) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, false, true));
+        return b;
+      };
       if (const char* env = std::getenv("PYCOLLO_AMD_LDS_ROWS_EXTRA"))   // experiments: staging sized for that many more rows
         D.lds_out = phase_lds_out(P, phase_max_tile_rows(P) + std::atoi(env), std::min(TC, phase_max_tile_rows(P) + 1));
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
@@ -772,9 +889,9 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
           if (v == 1 || v == 2 || v == 4) D.wpt = v;
         }
         if (h->two_wave) D.wpt = 2;
-        while (D.wpt > 1 && phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * D.wpt, mesh_tables) > h->lds_limit) D.wpt /= 2;
+        while (D.wpt > 1 && D.lds_for(D.wpt) > h->lds_limit) D.wpt /= 2;
       }
-      D.lds_bytes = phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * D.wpt, mesh_tables);
+      D.lds_bytes = D.lds_for(D.wpt);
       h->lds_max = std::max(h->lds_max, D.lds_bytes);
       if (D.lds_bytes > h->lds_limit)
         throw std::runtime_error("tile needs more dynamic LDS than a workgroup may request; use a smaller "
@@ -798,7 +915,8 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
           auto& P = Q.ph[ip];
           auto& D = *h->pd[ip];
-          mx = std::max(mx, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, P.compiled_order == 0));
+          (void)P;
+          mx = std::max(mx, D.lds_for(w));
         }
         return mx;
       };
@@ -824,20 +942,34 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     if (!d->code_object || !d->tail_kernel) throw std::runtime_error("code_object and tail_kernel are required");
     HIP_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_OK(hipModuleLoad(&h->module, d->code_object));
-    HIP_OK(hipModuleGetFunction(&h->tail_fn, h->module, d->tail_kernel));
-    if (hipModuleGetFunction(&h->tail_big_fn, h->module, (std::string(d->tail_kernel) + "_big").c_str()) != hipSuccess)
+    {
+      const std::string path = d->code_object, ext = ".hsaco";
+      const std::string base = path.size() > ext.size() && path.compare(path.size() - ext.size(), ext.size(), ext) == 0
+                                   ? path.substr(0, path.size() - ext.size()) : path;
+      for (int k = 1; k < 16; ++k) {
+        const std::string part = base + ".p" + std::to_string(k) + ext;
+        FILE* f = std::fopen(part.c_str(), "rb");
+        if (!f) break;
+        std::fclose(f);
+        hipModule_t m = nullptr;
+        HIP_OK(hipModuleLoad(&m, part.c_str()));
+        h->more_modules.push_back(m);
+      }
+    }
+    HIP_OK(find_fn(h.get(), &h->tail_fn, d->tail_kernel));
+    if (find_fn(h.get(), &h->tail_big_fn, (std::string(d->tail_kernel) + "_big").c_str()) != hipSuccess)
       h->tail_big_fn = nullptr;
     if (Q.ph.size() > 1) {
       bool merge = true;
       if (const char* env = std::getenv("PYCOLLO_AMD_MERGE")) merge = std::atoi(env) != 0;
-      if (!merge || hipModuleGetFunction(&h->bulk_all_fn, h->module, "pc_bulk_all") != hipSuccess) h->bulk_all_fn = nullptr;
+      if (!merge || find_fn(h.get(), &h->bulk_all_fn, "pc_bulk_all") != hipSuccess) h->bulk_all_fn = nullptr;
       if (h->bulk_all_fn) {
         h->d_phase_args.alloc(Q.ph.size() * sizeof(PcPhaseArgs));
         h->n_launches = 2;
-        if (hipModuleGetFunction(&h->bulk_all_res_fn, h->module, "pc_bulk_all_r") != hipSuccess) h->bulk_all_res_fn = nullptr;
+        if (find_fn(h.get(), &h->bulk_all_res_fn, "pc_bulk_all_r") != hipSuccess) h->bulk_all_res_fn = nullptr;
         if (h->bulk_all_res_fn && h->wpt_all > 1) {   // the same launch with the replica index compiled in
           hipFunction_t fw = nullptr;
-          if (hipModuleGetFunction(&fw, h->module, ("pc_bulk_all_r_w" + std::to_string(h->wpt_all)).c_str()) == hipSuccess && fw)
+          if (find_fn(h.get(), &fw, ("pc_bulk_all_r_w" + std::to_string(h->wpt_all)).c_str()) == hipSuccess && fw)
             h->bulk_all_res_fn = fw;
           else
             (void)hipGetLastError();
@@ -852,12 +984,12 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       auto& P = Q.ph[ip];
       auto& D = *h->pd[ip];
-      HIP_OK(hipModuleGetFunction(&D.fn, h->module, P.bulk_kernel.c_str()));
-      if (Q.ph.size() == 1 && hipModuleGetFunction(&D.fn_res, h->module, (P.bulk_kernel + "_r").c_str()) != hipSuccess)
+      HIP_OK(find_fn(h.get(), &D.fn, P.bulk_kernel.c_str()));
+      if (Q.ph.size() == 1 && find_fn(h.get(), &D.fn_res, (P.bulk_kernel + "_r").c_str()) != hipSuccess)
         D.fn_res = nullptr;   // code object without the resident-tail variant: two launches per evaluation
       if (D.fn_res && D.wpt > 1) {   // the same kernel with the replica index compiled in (codegen: light / medium models)
         hipFunction_t fw = nullptr;
-        if (hipModuleGetFunction(&fw, h->module, (P.bulk_kernel + "_r_w" + std::to_string(D.wpt)).c_str()) == hipSuccess && fw)
+        if (find_fn(h.get(), &fw, (P.bulk_kernel + "_r_w" + std::to_string(D.wpt)).c_str()) == hipSuccess && fw)
           D.fn_res = fw;
         else
           (void)hipGetLastError();
@@ -970,6 +1102,7 @@ void pc_destroy(pc_handle* h) {
   h->pd.clear();
   if (h->ev_small) (void)hipEventDestroy(h->ev_small);
   if (h->ev_G) (void)hipEventDestroy(h->ev_G);
+  for (hipModule_t m : h->more_modules) (void)hipModuleUnload(m);
   if (h->module) (void)hipModuleUnload(h->module);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -988,7 +1121,7 @@ int pc_get_info(const pc_handle* h, pc_info* info) {
     for (auto& D : h->pd) nt += D->n_tiles;
     info->n_tiles_total = nt;
     info->threads_per_block = h->TB;
-    info->lds_bytes_max = h->lds_max;
+    info->lds_bytes_max = (h->Q.ph.size() > 1 && h->lds_all > 0) ? h->lds_all : h->lds_max;   // the merged launch's when there is one
     info->n_launches = h->n_launches;
     info->waves_per_tile = 1;
     for (auto& D : h->pd) info->waves_per_tile = std::max(info->waves_per_tile, (int32_t)D->wpt);
@@ -1046,6 +1179,7 @@ int pc_eval_all_device(pc_handle* h, const double* d_x, double obj_factor, const
                        double* d_jac, double* d_hess, void* stream) {
   return guarded([&] {
     require_device(h);
+    h->fc_valid = h->small_synced = h->G_synced = false;   // these launches write the handle's f block: a companion host-pointer call must re-evaluate
     check_timeout(h);   // a previous device-API evaluation whose tail gave up: say so before queueing more work
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
@@ -1064,6 +1198,7 @@ int pc_launch_bulk_device(pc_handle* h, const double* d_x, const double* d_lambd
                           double* d_hess, void* stream) {
   return guarded([&] {
     require_device(h);
+    h->fc_valid = h->small_synced = h->G_synced = false;   // these launches write the handle's f block: a companion host-pointer call must re-evaluate
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, 1.0,
                true, false);
@@ -1074,6 +1209,7 @@ int pc_launch_bulk_flags_device(pc_handle* h, const double* d_x, const double* d
                                 double* d_hess, int flags, void* stream) {
   return guarded([&] {
     require_device(h);
+    h->fc_valid = h->small_synced = h->G_synced = false;   // these launches write the handle's f block: a companion host-pointer call must re-evaluate
     if (flags & ~(PC_FLAG_C | PC_FLAG_G | PC_FLAG_H)) throw std::runtime_error("flags must be a combination of 1 (g), 2 (jac_g), 4 (hess)");
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, flags, st, 1.0, true, false);
@@ -1084,6 +1220,7 @@ int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, co
                           double* d_jac, double* d_hess, void* stream) {
   return guarded([&] {
     require_device(h);
+    h->fc_valid = h->small_synced = h->G_synced = false;   // these launches write the handle's f block: a companion host-pointer call must re-evaluate
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, nullptr, PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st,
                obj_factor, false, true);
@@ -1114,6 +1251,14 @@ int pc_phase_tiles(const pc_handle* h, int phase, int32_t* n_tiles, int32_t* nre
     if (n_tiles) *n_tiles = (int32_t)P.tile_k0.size() - 1;
     if (nred) *nred = P.nred;
     if (tile_k0) std::memcpy(tile_k0, P.tile_k0.data(), P.tile_k0.size() * sizeof(int32_t));
+  });
+}
+
+int pc_phase_tile_orders(const pc_handle* h, int phase, int32_t* tile_order) {
+  return guarded([&] {
+    if (!h || phase < 0 || phase >= (int)h->Q.ph.size() || !tile_order) throw std::runtime_error("phase out of range or null output");
+    auto& P = h->Q.ph[phase];
+    for (size_t t = 0; t + 1 < P.tile_k0.size(); ++t) tile_order[t] = t < P.tile_order.size() ? P.tile_order[t] : 0;
   });
 }
 
@@ -1440,7 +1585,7 @@ int pc_mesh_error(pc_handle* h, int phase, const double* x, int n_orders, const 
     auto& D = *h->pd[phase];
     hipFunction_t fn = nullptr;
     const std::string name = "pc_mesh_err_p" + std::to_string(phase);
-    HIP_OK(hipModuleGetFunction(&fn, h->module, name.c_str()));
+    HIP_OK(find_fn(h, &fn, name.c_str()));
     PcRefineArgs a;
     std::memset(&a, 0, sizeof(a));
     for (int i = 0; i <= PC_MAX_ORDER; ++i) a.offBE[i] = a.offA[i] = -1;
@@ -1537,3 +1682,5 @@ int pc_read_symbol(pc_handle* h, const char* name, void* dst, size_t bytes) {
 }
 
 }  // extern "C"
+
+#include "pc_ipm.hpp"   // the device-resident interior-point state (same translation unit: it uses launch_all)

@@ -42,13 +42,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<B + 1, E>(f);
   }
 }
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for_down(F&& f) {   // E-1, E-2, ..., B
-  if constexpr (B < E) {
-    f(ic<E - 1>{});
-    static_for_down<B, E - 1>(f);
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // compile-time structure derived from the model's non-zero lists
@@ -336,96 +329,27 @@ __device__ __forceinline__ void lds_barrier() {
 // wave instruction), counted from the run's FIRST element.  A run starts wherever the CSR layout puts it (8-byte
 // granularity): the 16-byte stores are simply issued at that address -- global memory takes them unaligned, a wave's
 // 64 stores still cover one contiguous KiB -- and the LDS side is read as two 8-byte halves.  Every batch of
-// PC_FLUSH_DEPTH wave-instructions issues ALL its LDS reads (lanes past the end masked) before the first store, and the
-// odd last element rides with the first batch: a run costs one LDS round trip per batch and nothing else.  (Round 2
-// peeled an element for alignment, ran the remainder one pair at a time and peeled the tail: up to six exposed LDS
-// round trips per run, ~10 runs per wave -- a third of a tile wave's life at two waves per SIMD.)
-#if defined(PC_EXP_NOSTORE)   // timing experiment: the staged runs are read back from LDS but never stored (results are wrong)
-#define PC_RUN_STORE(p, v) asm volatile("" ::"v"(v), "v"(p))
-#elif defined(PC_NT_STORES)   // experiment: streaming (non-temporal) stores for the CSR runs
-#define PC_RUN_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define PC_RUN_STORE(p, v) (*(p) = (v))
-#endif
+// PC_FLUSH_DEPTH wave-instructions issues ALL its LDS reads before the first store, and the odd last element rides
+// with the first batch: a run costs one LDS round trip per batch and nothing else.  (Measured and dropped, records in
+// profiles/r03_ab_*.txt: an alignment peel, a software-pipelined batch loop, non-temporal stores, a predicate on every
+// store.)
 typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 #ifndef PC_FLUSH_DEPTH
 #define PC_FLUSH_DEPTH 4
 #endif
-typedef double pc_d2_a16 __attribute__((ext_vector_type(2), aligned(16)));
-#ifdef PC_FLUSH_PEEL   // A/B: round 2's form -- one element peeled for 16-byte alignment, remainder pair by pair, tail peeled
-__device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
-                                          int TB) {
-  if (len <= 0) return;
-  const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
-  if (head && tid == 0) dst[0] = src[0];
-  dst += head;
-  src += head;
-  len -= head;
-  const int pairs = len >> 1;
-  int e = tid;
-  for (; e + (PC_FLUSH_DEPTH - 1) * TB < pairs; e += PC_FLUSH_DEPTH * TB) {   // LDS reads in flight before the first store issues
-    pc_d2_a8 a[PC_FLUSH_DEPTH];
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * (e + q * TB));
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) *reinterpret_cast<pc_d2_a16*>(dst + 2 * (e + q * TB)) = a[q];
-  }
-  for (; e < pairs; e += TB) {
-    const pc_d2_a8 a0 = *reinterpret_cast<const pc_d2_a8*>(src + 2 * e);
-    *reinterpret_cast<pc_d2_a16*>(dst + 2 * e) = a0;
-  }
-  if ((len & 1) && tid == TB - 1) dst[len - 1] = src[len - 1];
-}
-#else
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
                                           int TB) {
   // The length is the same in every lane, but on a mesh of mixed orders it is computed from LDS tables, i.e. in a vector
   // register: the compiler then treats the batch loop and the chunk tests below as divergent (exec-mask loops).
   len = __builtin_amdgcn_readfirstlane(len);
   if (len <= 0) return;
-#ifdef PC_FLUSH_ALIGN   // A/B: peel one element so that the 16-byte stores are 16-byte aligned (read with the first batch too)
-  const int head = (int)((reinterpret_cast<uintptr_t>(dst) >> 3) & 1u);
-  double first = 0.0;
-  double* const dst0 = dst;
-  if (head && tid == 1) first = src[0];
-  dst += head;
-  src += head;
-  len -= head;
-#endif
   const int pairs = len >> 1;
   const bool odd = (len & 1) && tid == 0;
   double last = 0.0;
   if (odd) last = src[len - 1];
   int b0 = 0;   // first pair of the batch: wave-uniform, so the loop and the choice below are scalar branches
-#ifndef PC_FLUSH_PRED_ALL
   // full batches: every lane reads and stores, nothing is predicated (a predicated store is a compare, an exec-mask
   // save / restore and a branch around one instruction: two thirds of the flush's instructions when every store had one)
-#ifdef PC_FLUSH_PIPELINED   // A/B: the next batch's LDS reads are issued before this batch's stores
-  if (b0 + PC_FLUSH_DEPTH * TB <= pairs) {
-    pc_d2_a8 a[PC_FLUSH_DEPTH], nx[PC_FLUSH_DEPTH];
-    {
-      const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
-#pragma unroll
-      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[q * TB];
-    }
-    for (;;) {
-      const int b1 = b0 + PC_FLUSH_DEPTH * TB;
-      const bool more = b1 + PC_FLUSH_DEPTH * TB <= pairs;
-      if (more) {
-        const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b1 + tid);
-#pragma unroll
-        for (int q = 0; q < PC_FLUSH_DEPTH; ++q) nx[q] = sp[q * TB];
-      }
-      pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
-#pragma unroll
-      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(dp + q * TB, a[q]);
-      b0 = b1;
-      if (!more) break;
-#pragma unroll
-      for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = nx[q];
-    }
-  }
-#else
   for (; b0 + PC_FLUSH_DEPTH * TB <= pairs; b0 += PC_FLUSH_DEPTH * TB) {
     const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
     pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
@@ -433,41 +357,78 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[q * TB];
 #pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) PC_RUN_STORE(dp + q * TB, a[q]);
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) dp[q * TB] = a[q];
   }
-#endif
-#endif
-  for (; b0 < pairs; b0 += PC_FLUSH_DEPTH * TB) {   // the last, partial batch (one pass unless PC_FLUSH_PRED_ALL)
+  if (b0 < pairs) {   // the last, partial batch
     const int e0 = b0 + tid;
     pc_d2_a8 a[PC_FLUSH_DEPTH];
     // (unconditional reads at clamped indices: a read under `if` makes its register a conditional definition, and the
     //  compiler then waits for LDS before every single read)
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * min(e0 + q * TB, pairs - 1));
-#ifdef PC_FLUSH_PRED_ALL
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q)
-      if (e0 + q * TB < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (e0 + q * TB)), a[q]);
-#else
     // chunk q of the batch is full, partial or empty -- a wave-uniform fact (scalar compares and branches); only the
     // one partial chunk stores under a lane predicate
 #pragma unroll
     for (int q = 0; q < PC_FLUSH_DEPTH; ++q) {
       const int c0 = b0 + q * TB;
       if (c0 + TB <= pairs) {
-        PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)), a[q]);
+        *reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)) = a[q];
       } else if (c0 < pairs) {
-        if (c0 + tid < pairs) PC_RUN_STORE(reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)), a[q]);
+        if (c0 + tid < pairs) *reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)) = a[q];
       }
     }
-#endif
   }
   if (odd) dst[len - 1] = last;
-#ifdef PC_FLUSH_ALIGN
-  if (head && tid == 1) dst0[0] = first;
-#endif
 }
-#endif
+
+// The same copy for a run staged in pieces: `nq` chunks of L doubles lie back to back in LDS and go to dst, dst + GS,
+// dst + 2 GS, ... (pc::bulk, "row groups": chunk = the rows of one pass of one section, GS = all rows of a section).
+// One chunk at a time, in a scalar loop: a wave moves a chunk with ceil(L / 128) 16-byte store instructions whose lane
+// offsets never change (the chunk's base advances in scalar registers) and whose last one carries a compile-time lane
+// mask -- two instructions per KiB, like flush_run.  (A first version mapped staging element e to chunk e / L per lane:
+// eight address instructions per store, a third more instructions in the whole tile body -- Delta III order 5, two
+// passes: 23.3 -> 34.2 us.)  The next chunk's LDS reads are issued before this chunk's stores.
+template <int L, int GS>
+__device__ __forceinline__ void flush_chunks(double* __restrict__ dst, const double* __restrict__ src, int nq, int t, int TN) {
+  nq = __builtin_amdgcn_readfirstlane(nq);
+  if (nq <= 0) return;
+  if (TN == 64) {
+    constexpr int FULL = L / 128, REM = L % 128, NR = FULL + (REM > 0 ? 1 : 0);
+    const double* sp = src + 2 * t;
+    double* dp = dst + 2 * t;
+    pc_d2_a8 a[NR], nx[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) a[i] = *reinterpret_cast<const pc_d2_a8*>(sp + 128 * i);
+    for (int q = 0; q < nq; ++q) {
+      if (q + 1 < nq) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) nx[i] = *reinterpret_cast<const pc_d2_a8*>(sp + L + 128 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < FULL; ++i) *reinterpret_cast<pc_d2_a8*>(dp + 128 * i) = a[i];
+      if constexpr (REM > 1) {
+        if (2 * t + 1 < REM) *reinterpret_cast<pc_d2_a8*>(dp + 128 * FULL) = a[FULL];
+      }
+      if constexpr (REM % 2 == 1) {
+        if (2 * t == REM - 1) dp[128 * FULL] = a[FULL].x;
+      }
+      sp += L;
+      dp += GS;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) a[i] = nx[i];
+    }
+    return;
+  }
+  // wider workgroups (tiles of 128 / 256 nodes): the same per chunk, a runtime stride
+  for (int q = 0; q < nq; ++q) {
+    const double* sp = src + (long long)q * L;
+    double* dp = dst + (long long)q * GS;
+    for (int o = 2 * t; o < L; o += 2 * TN) {
+      if (o + 1 < L) *reinterpret_cast<pc_d2_a8*>(dp + o) = *reinterpret_cast<const pc_d2_a8*>(sp + o);
+      else dp[o] = sp[o];
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // bulk kernel
@@ -596,14 +557,24 @@ extern "C" __device__ unsigned long long pc_stamps[PC_STAMPS_WAVES * 24];
 // flags and the granule tag arrive as plain values (mx .. mepoch: the members of PcMultiArgs the kernel needs --
 // handed over as a pointer to the struct, a large kernel keeps the whole struct in scratch memory), the workgroup's
 // tile from its index relative to the phase's first block.
-template <class M, int UN, bool RES = false, int WN = 0, int WIDX = 0>
+//
+// MIX: the phase's sections differ in order and this code object carries one tile body per frequent order next to the
+// any-order one (bulk_mix below picks per tile).  The host cuts tiles at order changes where the orders come in runs --
+// which is what ph refinement leaves: subdivided and merged stretches are runs of the minimum order,
+// pycollo/mesh_refinement.py:252-321 -- so such a tile runs the body compiled for its order (UN > 0), its place in the
+// mesh arriving as scalars from the tile's record (r_*: PcTileRec) instead of section tables.  The one thing an
+// order-pure tile still owes a neighbour of another order is its first node, which closes the section before the
+// tile: that lane's adjoint weight and quadrature weight take the previous section's own last A column / weight.
+template <class M, int UN, bool RES = false, int WN = 0, int WIDX = 0, bool MIX = false>
 __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, int first_block = 0, int block = -1,
                                      const PcLead* LD = nullptr, const double* mx = nullptr, const double* mlam = nullptr,
                                      double* mc = nullptr, double* mG = nullptr, double* mH = nullptr, int mflags = 0,
-                                     unsigned mepoch = 0) {
+                                     unsigned mepoch = 0, int r_k0 = 0, int r_nsec = 0, int r_n0 = 0, int r_nprev = 0,
+                                     int r_qaprev = 0, long long r_E0 = 0, double r_wprev = 0.0) {
   using St = S<M>;
   constexpr int NY = St::NY, NZ = St::NZ, NQ = St::NQ, NP = St::NP, NS = St::NS, NT = St::NT;
   constexpr int NFN = St::NFN, NV = St::NV, NJ = St::NJ, NH = St::NH, NFS = St::NFS, NRED = St::NRED;
+  constexpr bool PURE = MIX && UN > 0;   // order-pure tile of a mixed mesh: geometry relative to the tile's record
   BulkIn<St> A;
   // part 1: what the node loads are addressed with.  pc_bulk_p<i> gets these as leading scalar arguments, which the
   // command processor preloads into SGPRs (LD); the other launches read them from their argument block like the rest.
@@ -627,12 +598,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
 #ifdef PC_STAMPS
   const int pc_stamp_slot = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
 #endif
-#ifdef PC_STAGGER   // experiment: the wave in the odd hardware slot of its SIMD starts PC_STAGGER x 64 clocks late
-  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) {   // HW_REG_HW_ID, WAVE_ID[3:0]
-#pragma unroll 1
-    for (int i_ = 0; i_ < PC_STAGGER; i_ += 16) __builtin_amdgcn_s_sleep(16);   // 16 x 64 clocks a turn
-  }
-#endif
   PC_STAMP(0);
   PC_STAMP(9);   // constant-rate clock at the start (the pair 0 / 9 of two waves gives the shader clock rate)
   const int N = A.N;
@@ -644,7 +609,12 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   const int un = UN > 0 ? UN : A.uni_n;
   const bool uni = UN > 0 || un > 0;
   int k0, k1, n0, n1;
-  if (uni) {
+  if constexpr (PURE) {
+    k0 = r_k0;
+    k1 = r_k0 + r_nsec;
+    n0 = r_n0;
+    n1 = r_n0 + r_nsec * (UN - 1);
+  } else if (uni) {
     k0 = tile * A.spt;
     k1 = min(k0 + A.spt, A.K);
     n0 = k0 * (un - 1);
@@ -689,6 +659,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     A.qa_total = KB.qa_total; A.qw_total = KB.qw_total;
     A.lds_out = KB.lds_out;
     A.qw0 = KB.qw_off[UN > 0 ? UN : 0];
+    if constexpr (PURE) {   // (the lead words of a mixed launch describe no order)
+      A.qa0 = KB.qa_off[UN];
+      A.qwabs = KB.qa_total + KB.qw_off[UN];
+    }
     static_for<0, St::NSCAL>([&](auto i_) { A.scal[decltype(i_)::value] = KB.scal[decltype(i_)::value]; });
     static_for<0, NFN>([&](auto i_) { A.goff[decltype(i_)::value] = KB.goff[decltype(i_)::value]; });
     static_for<0, 3 * NZ + NS * NZ>([&](auto i_) { A.hoff[decltype(i_)::value] = KB.hoff[decltype(i_)::value]; });
@@ -713,11 +687,16 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   const int nsec = k1 - kp;              // staged sections (previous one included)
   constexpr int QA_N = UN > 0 ? (UN - 1) * UN : 0;   // a compile-time order stages just its own A_n and w_n, at the
   double r_h = 0.0, r_qa = 0.0, r_qw = 0.0;          // start of the LDS table areas (QAO = QWO = 0)
+  const bool odd_prev = PURE && has_prev && r_nprev != UN;   // (wave-uniform)
+  const int lsA = has_prev ? 1 : 0;                  // first section of the tile (local index)
+  double r_cp = 0.0;
   double r_lam[2 * (NY > 0 ? NY : 1)];
   int lam0 = 0, lam_cnt = 0;   // first staged defect row; rows staged (<= TB + PC_MAX_ORDER - 2: two chunks)
   auto aux_loads = [&]() {
     r_h = tid < nsec ? A.sec_h[kp + tid] : 0.0;   // widths are data even on a uniform-order mesh
-    if (uni) {
+    if constexpr (PURE) {
+      lam0 = has_prev ? n0 - (r_nprev - 1) : n0;
+    } else if (uni) {
       lam0 = kp * (un - 1);
     } else {
       lam0 = A.sec_s[kp];
@@ -741,8 +720,11 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       r_qa = tid < QA_N ? A.qa[A.qa0 + tid] : 0.0;
       r_qw = tid < UN ? A.qa[A.qwabs + tid] : 0.0;
     }
+    if constexpr (PURE) {   // last column of the previous section's A table when that section has another order
+      if (odd_prev) r_cp = tid < r_nprev - 1 ? A.qa[r_qaprev + tid * r_nprev + r_nprev - 1] : 0.0;
+    }
   };
-  const bool early_aux = LD != nullptr && UN > 0;
+  const bool early_aux = LD != nullptr && UN > 0 && !MIX;
   if (early_aux) aux_loads();
   // (only what this build of the kernel can use: everything pinned is live in SGPRs from here on, and the file has
   //  ~100 of them -- an over-full pin list is loaded in several dependent batches and partly spilled to VGPR lanes)
@@ -768,11 +750,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     if constexpr (NRED > 0) { if constexpr (RES) pin2(A.gran); else pin2(A.partials); }
     if constexpr (!M::T0_FREE) pin2(A.t_fixed[0]);
     if constexpr (!M::TF_FREE) pin2(A.t_fixed[1]);
-#ifdef PC_PIN_ALL   // A/B switch: the earlier, over-full pin list
-    pin2(A.hslot0); pin2(A.hslotN); pin2(A.tab); pin2(A.s_off); pin2(A.c_path_off);
-    pin2(A.c_int_off); pin2(A.t_fixed[0]); pin2(A.t_fixed[1]);
-    pin_array<St::NSCAL>(pin2, A.scal); pin_array<3 * NZ + NS * NZ>(pin2, A.hoff);
-#endif
     // The per-variable constants (scaling, run offsets) are hoisted too while they fit the scalar register file
     // next to the above.  A model with many variables would have them spilled to VGPR lanes (the shuttle kernel
     // carried 2000 v_readlane, whole 16-register tuples reloaded per use): such a model reads them from an LDS
@@ -808,7 +785,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   const int w = WN > 0 ? WIDX : (W > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0);   // wave-uniform: branches on it are scalar
   // (tables only some kernels stage -- the scal | goff | hoff copy sized by the model, the section tables of the
   //  any-order kernels -- take no LDS in the others: LDS per tile is what bounds the waves a CU holds)
-  const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W, St::NSCAL + NFN + 3 * NZ + NS * NZ, UN == 0);
+  const LdsPlan lp = lds_plan(TN, A.qa_total, A.qw_total, NY, NFS, NRED, A.lds_out * W, St::NSCAL + NFN + 3 * NZ + NS * NZ, UN == 0, MIX);
+  double* s_cp = smem + lp.cp;
   double* s_qa = smem + lp.qa;
   double* s_qw = smem + lp.qw;
   int* s_off = reinterpret_cast<int*>(smem + lp.off);   // [0..20] qa_off, [21..41] qw_off (any-mesh kernels)
@@ -918,6 +896,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     if (tid < A.qw_total) s_qw[tid] = r_qw;
   }
   if (tid < nsec) s_h[tid] = r_h;
+  if constexpr (PURE) {
+    if (odd_prev && tid < r_nprev - 1) s_cp[tid] = r_cp;
+  }
   if constexpr (!PINNED) {   // scal | goff | hoff, packed by the host in exactly this order
     for (int i = tid; i < St::NSCAL + NFN + NHO; i += TB) s_tab[i] = A.tab[i];
   }
@@ -952,12 +933,18 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   block_sync();
 
   // section accessors (local index ls counts from section kp)
-  auto S_s = [&](int ls) -> int { return uni ? (kp + ls) * (un - 1) : s_s[ls]; };
+  auto S_s = [&](int ls) -> int {
+    if constexpr (PURE) return ls >= lsA ? n0 + (ls - lsA) * (UN - 1) : n0 - (r_nprev - 1);
+    return uni ? (kp + ls) * (un - 1) : s_s[ls];
+  };
   // (UN > 0 spelled out: the loops over a section's rows must see a compile-time trip count even when this
   //  lambda is inlined late -- otherwise they stay rolled and every array they index lands in scratch memory)
   auto S_n = [&](int ls) -> int { return UN > 0 ? UN : (uni ? un : s_s[ls + 1] - s_s[ls] + 1); };
   auto S_h = [&](int ls) -> double { return s_h[ls]; };
-  auto S_E = [&](int ls) -> long long { return uni ? (long long)(kp + ls) * (un - 1) * un : s_E[ls]; };
+  auto S_E = [&](int ls) -> long long {
+    if constexpr (PURE) return r_E0 + (long long)((ls - lsA) * (UN - 1) * UN);
+    return uni ? (long long)(kp + ls) * (un - 1) * un : s_E[ls];
+  };
 
   // ---- uniform scalars ------------------------------------------------------------------------
   double t0 = A.t_fixed[0], tF = A.t_fixed[1];
@@ -981,6 +968,8 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   int ls_r = -1, pos_r = 0, n_r = UN > 0 ? UN : 2, ls_s = 0, n_s = UN > 0 ? UN : 2;
   bool has_start = false;
   double w_node = 0.0;
+  // the first lane of an order-pure tile whose previous section has another order (see MIX above)
+  const bool prev_lane = odd_prev && t == 0;
   if (active) {
     static_for<0, NZ>([&](auto b_) {
       constexpr int b = decltype(b_)::value;
@@ -991,7 +980,9 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       v[NZ + l] = sc[St::O_VS + l] * v[NZ + l] + sc[St::O_RS + l];
     });
     PC_STAMP(1);   // node values have arrived
-    if (uni) {
+    if constexpr (PURE) {
+      ls_r = t == 0 ? lsA - 1 : lsA + (t - 1) / (UN - 1);
+    } else if (uni) {
       const int g = node - kp * (un - 1);           // node index relative to the first staged section
       ls_r = (node == 0) ? -1 : (g - 1) / (un - 1);
     } else {
@@ -1003,7 +994,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     if (ls_r >= 0) {
       n_r = S_n(ls_r);
       pos_r = node - S_s(ls_r);
-      w_node = S_h(ls_r) * s_qw[QWO(n_r) + pos_r];
+      w_node = prev_lane ? S_h(ls_r) * r_wprev : S_h(ls_r) * s_qw[QWO(n_r) + (prev_lane ? 0 : pos_r)];
     }
     if (has_start) {
       n_s = S_n(ls_s);
@@ -1025,7 +1016,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
     for (int j = 0; j < NC; ++j) cr[j] = cs[j] = 0.0;
     if (active) {
       const double* At = s_qa + QAO(UN);
-      if (ls_r >= 0) {
+      if (ls_r >= 0 && !prev_lane) {
         const double h = S_h(ls_r);
 #pragma unroll
         for (int j = 1; j < UN; ++j) cr[j - 1] = h * At[(j - 1) * UN + pos_r];
@@ -1045,8 +1036,15 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       constexpr int a = decltype(a_)::value;
       const double* la = s_lam + a * (TN + PC_MAX_ORDER);
       double acc = 0.0;
+      if constexpr (PURE) {
+        if (prev_lane) {   // the section before the tile: its own order's last A column, rows lam0 .. lam0 + nprev - 2
+          double a2 = 0.0;
+          for (int j = 0; j < r_nprev - 1; ++j) a2 += la[j] * s_cp[j];
+          acc += S_h(0) * a2;
+        }
+      }
       if constexpr (HOIST) {
-        if (ls_r >= 0) {
+        if (ls_r >= 0 && !prev_lane) {
           const int base = S_s(ls_r) - lam0;
 #pragma unroll
           for (int j = 1; j < UN; ++j) acc += la[base + j - 1] * cr[j - 1];
@@ -1059,7 +1057,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
           acc += a2;
         }
       } else {
-        if (ls_r >= 0) {
+        if (ls_r >= 0 && !prev_lane) {
           const double* At = s_qa + QAO(n_r);
           const int base = S_s(ls_r) - lam0;
           double a2 = 0.0;
@@ -1226,23 +1224,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       hess_second();
     }
   };
-  // Every wave of a launch walks the same phases at the same time, so the run stores arrive in bursts (all defect-
-  // Jacobian runs within a third of the launch) that the memory system cannot absorb while it idles during the
-  // evaluation phases.  With PC_SWAP_PASSES every other tile does its second pass FIRST: half the tiles store Hessian
-  // runs while the other half evaluate first partials, and so on.  Same results bit for bit (the passes share nothing
-  // but their inputs); the two barriers keep the staging buffer of one replica off the tables another still reads.
-#ifdef PC_SWAP_PASSES
-  const bool swap_passes = SPLIT && (tile & 1) != 0 && wantG && wantH;
-#else
-  constexpr bool swap_passes = false;
-#endif
-  if constexpr (SPLIT) {
-    if (swap_passes) {   // (a second call site of the pass: the default build has one)
-      block_sync();
-      second_pass();
-      block_sync();
-    }
-  }
   if (active) {
     if constexpr (SPLIT) M::eval_fj(v, F, Jv);
     else M::eval(v, mult, F, Jv, Hv);
@@ -1440,7 +1421,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   //      entries are produced column-wise / row-wise into the staging buffer, then the tile's
   //      contiguous CSR run of that state is written to HBM fully coalesced
   if (wantG) {
-    const int lsA = has_prev ? 1 : 0;                       // first section of the tile (local index)
     // (wave-uniform values read from an LDS table on a mixed-order mesh: as scalars, so that the run's start address,
     //  its length and the row offsets below are scalar arithmetic)
     auto uniform64 = [](long long v) -> long long {
@@ -1449,6 +1429,20 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       return (long long)(((unsigned long long)hi << 32) | lo);
     };
     const long long E0 = uni ? S_E(lsA) : uniform64(S_E(lsA)), E1 = uni ? S_E(nsec) : uniform64(S_E(nsec));
+    // Row groups (order-specialised bodies): a state's block is staged and flushed in NPASS passes over the section
+    // rows -- pass g holds rows j in [1 + g RG, 1 + (g + 1) RG) of EVERY section of the tile, section after section, so
+    // every lane still produces its column in every pass and the staging buffer is RG / (n - 1) of the whole block.
+    // The staged piece of one section is contiguous in the CSR run too (rows of a section follow each other), so the
+    // flush copies chunks of RG rows (flush_chunks).  NPASS is pc_row_passes' choice (pc_args.h; the host sizes the
+    // LDS with the same function): 1 unless a full tile's block is too large for two staging regions per workgroup --
+    // the high orders ph refinement ends on (7 .. 9 nodes: 82 doubles a row for Delta III) need 41 KB in one piece.
+    constexpr int RSTRIDE_MAX = [] {
+      int m = 0;
+      for (int a = 0; a < NY; ++a) m = St::D(a) * (UN > 0 ? UN : 0) + St::C(a) > m ? St::D(a) * (UN > 0 ? UN : 0) + St::C(a) : m;
+      return m;
+    }();
+    constexpr int NPASS = UN > 0 ? pc_row_passes(UN, RSTRIDE_MAX) : 1;
+    constexpr int RG = UN > 0 ? (UN - 1 + NPASS - 1) / NPASS : 0;
     auto defect_jacobian_of_state = [&](auto a_) {
       constexpr int a = decltype(a_)::value;
       if (!mine(PC_ITEM(St::IT_D + a))) return;
@@ -1460,15 +1454,91 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         const int eloc = uni ? (ls - lsA) * (n - 1) * n : (int)(S_E(ls) - E0);
         return Da * eloc + Ca * (S_s(ls) - n0) + (j - 1) * (Da * n + Ca);
       };
+      // row a of dF/dz with every factor that does not depend on the CSR row folded in once:
+      // W_a * stretch * (df_a/dz_b * V_b); an entry is then one multiply by h_k A[j][pos]
+      double js[Da > 0 ? Da : 1];
+      const double WS = Wd * stretch, WV = Wd * sc[St::O_VZ + a];
       if (active) {
-        // row a of dF/dz with every factor that does not depend on the CSR row folded in once:
-        // W_a * stretch * (df_a/dz_b * V_b); an entry is then one multiply by h_k A[j][pos]
-        double js[Da > 0 ? Da : 1];
-        const double WS = Wd * stretch, WV = Wd * sc[St::O_VZ + a];
         static_for<0, NZ>([&](auto b_) {
           constexpr int b = decltype(b_)::value;
           if constexpr (PC_CE(St::dep(a, b))) js[PC_CE(St::ndep_before(a, b))] = WS * (Jv[PC_CE(St::jidx(a, b))] * sc[St::O_VZ + b]);
         });
+      }
+      // q, t and s columns of a lane's own row, written at staging offset rs (behind the row's z blocks)
+      auto param_cols = [&](int rs) {
+        if constexpr (NT + PC_CE(St::nxdep(a)) > 0) {
+          const int n = UN > 0 ? UN : n_r, jr = pos_r, sk = S_s(ls_r) - n0;
+          auto dfdw = [&](auto l_) -> double {   // W stretch V_l h_k sum_i A[j][i] df_a/dw_l(z_i)
+            constexpr int l = decltype(l_)::value;
+            const double* Arow = s_qa + QAO(n) + (jr - 1) * n;
+            double as = 0.0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
+            return Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
+          };
+          static_for<0, NT>([&](auto jt_) {
+            constexpr int jt = decltype(jt_)::value;
+            double val = Wd * dst[jt] * accf[a];
+            constexpr int lt = PC_CE(St::tpar(jt));   // f_a depends on this time itself
+            if constexpr (lt >= 0) {
+              if constexpr (PC_CE(St::dep(a, NZ + (lt >= 0 ? lt : 0)))) val += dfdw(ic<(lt >= 0 ? lt : 0)>{});
+            }
+            s_out[rs + PC_CE(St::nqdep(a)) + jt] = val;
+          });
+          static_for<0, NS>([&](auto l_) {
+            constexpr int l = decltype(l_)::value;
+            if constexpr (!St::is_t(l) && PC_CE(St::dep(a, NZ + l))) s_out[rs + PC_CE(St::xpos(a, l))] = dfdw(l_);
+          });
+        }
+      };
+      const int64_t g0 = goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
+      if constexpr (NPASS > 1) {
+        constexpr int RS = Da * UN + Ca;   // doubles per row
+        static_for<0, NPASS>([&](auto g_) {
+          constexpr int g = decltype(g_)::value;
+          constexpr int JLO = 1 + g * RG, JHI = (JLO + RG < UN) ? JLO + RG : UN, RGG = JHI - JLO;
+          if constexpr (RGG > 0) {
+            if (active) {
+              // this lane's column in the rows JLO .. JHI-1 of section ls (staging: section q's piece at q * RGG rows)
+              auto write_cols = [&](int ls, int pos, const double* cc) {
+                const double h = HOIST ? 0.0 : S_h(ls);
+                const double* At = s_qa;
+                const int rs0 = (ls - lsA) * (RGG * RS);
+                static_for<JLO, JHI>([&](auto j_) {
+                  constexpr int jj = decltype(j_)::value;
+                  const double coef = HOIST ? cc[jj - 1] : h * At[(jj - 1) * UN + pos];
+                  static_for<0, NZ>([&](auto b_) {
+                    constexpr int b = decltype(b_)::value;
+                    if constexpr (PC_CE(St::dep(a, b))) {
+                      constexpr int before = PC_CE(St::ndep_before(a, b));
+                      constexpr int extra = (PC_CE(St::own_sparse(a)) && a < b) ? 2 : 0;
+                      double val = coef * js[before];
+                      if constexpr (a == b) val += WV * ((pos == 0 ? 1.0 : 0.0) - (pos == jj ? 1.0 : 0.0));
+                      s_out[rs0 + (jj - JLO) * RS + before * UN + extra + pos] = val;
+                    }
+                  });
+                });
+              };
+              if (ls_r >= lsA) write_cols(ls_r, pos_r, cr);
+              if (has_start) write_cols(ls_s, 0, cs);
+              if (t >= 1 && pos_r >= JLO && pos_r < JHI) {   // this lane's own row belongs to the group
+                const int rs = (ls_r - lsA) * (RGG * RS) + (pos_r - JLO) * RS;
+                if constexpr (PC_CE(St::own_sparse(a))) {
+                  s_out[rs + PC_CE(St::ndep_before(a, a)) * UN] = WV;
+                  s_out[rs + PC_CE(St::ndep_before(a, a)) * UN + 1] = -WV;
+                }
+                param_cols(rs + Da * UN + (PC_CE(St::own_sparse(a)) ? 2 : 0));
+              }
+            }
+            stage_sync();
+            flush_chunks<RGG * RS, (UN - 1) * RS>(A.G + g0 + (JLO - 1) * RS, s_out, k1 - k0, t, TN);
+            stage_sync();
+          }
+        });
+        if constexpr (a < 7) PC_STAMP(11 + 2 * a);
+        return;
+      }
+      if (active) {
         auto write_cols = [&](int ls, int pos, int n_in, const double* cc) {
           const int n = UN > 0 ? UN : n_in;
           const double h = HOIST ? 0.0 : S_h(ls);
@@ -1479,11 +1549,7 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
 #pragma unroll
           for (int j = 1; j < n; ++j) {
             const double coef = HOIST ? cc[j - 1] : h * At[(j - 1) * n + pos];
-#ifdef PC_ROWOFF_IN_LOOP   // A/B: the earlier form
-            const int rs = row_off(ls, j, n);
-#else
             const int rs = rs1 + (j - 1) * rstride;
-#endif
             static_for<0, NZ>([&](auto b_) {
               constexpr int b = decltype(b_)::value;
               if constexpr (PC_CE(St::dep(a, b))) {
@@ -1498,21 +1564,6 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
         };
         if (ls_r >= lsA) write_cols(ls_r, pos_r, n_r, cr);
         if (has_start) write_cols(ls_s, 0, n_s, cs);
-#ifdef PC_OWN_SPARSE_BY_COLUMN   // A/B: the earlier form, the two D entries written by the lanes that own their columns
-        if constexpr (PC_CE(St::own_sparse(a))) {
-          auto d_cols = [&](int ls, int pos, int n_in) {
-            const int n = UN > 0 ? UN : n_in;
-#pragma unroll
-            for (int j = 1; j < n; ++j) {
-              const int o = row_off(ls, j, n) + PC_CE(St::ndep_before(a, a)) * n;
-              if (pos == 0) s_out[o] = WV;
-              if (pos == j) s_out[o + 1] = -WV;
-            }
-          };
-          if (ls_r >= lsA) d_cols(ls_r, pos_r, n_r);
-          if (has_start) d_cols(ls_s, 0, n_s);
-        }
-#else
         // a state whose own derivative does not depend on it has just the two D entries in its own columns (section
         // start: +W V, node j: -W V): both written by the lane that owns the ROW -- one predicated block per state
         // instead of two predicated stores per row and column pass
@@ -1524,54 +1575,24 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
             s_out[o + 1] = -WV;
           }
         }
-#endif
-        if constexpr (NT + PC_CE(St::nxdep(a)) > 0) {
-          if (rowthr) {   // q, t and s columns of this lane's own row
-            const int n = UN > 0 ? UN : n_r, j = pos_r, sk = S_s(ls_r) - n0;
-            const int rs = row_off(ls_r, j, n) + Da * n + (PC_CE(St::own_sparse(a)) ? 2 : 0);
-            auto dfdw = [&](auto l_) -> double {   // W stretch V_l h_k sum_i A[j][i] df_a/dw_l(z_i)
-              constexpr int l = decltype(l_)::value;
-              const double* Arow = s_qa + QAO(n) + (j - 1) * n;
-              double as = 0.0;
-#pragma unroll
-              for (int i = 0; i < n; ++i) as += Arow[i] * s_fs[PC_CE(St::fs_slot(a, l)) * TN + sk + i];
-              return Wd * stretch * sc[St::O_VS + l] * (S_h(ls_r) * as);
-            };
-            static_for<0, NT>([&](auto jt_) {
-              constexpr int jt = decltype(jt_)::value;
-              double val = Wd * dst[jt] * accf[a];
-              constexpr int lt = PC_CE(St::tpar(jt));   // f_a depends on this time itself
-              if constexpr (lt >= 0) {
-                if constexpr (PC_CE(St::dep(a, NZ + (lt >= 0 ? lt : 0)))) val += dfdw(ic<(lt >= 0 ? lt : 0)>{});
-              }
-              s_out[rs + PC_CE(St::nqdep(a)) + jt] = val;
-            });
-            static_for<0, NS>([&](auto l_) {
-              constexpr int l = decltype(l_)::value;
-              if constexpr (!St::is_t(l) && PC_CE(St::dep(a, NZ + l))) s_out[rs + PC_CE(St::xpos(a, l))] = dfdw(l_);
-            });
-          }
+        if (rowthr) {   // q, t and s columns of this lane's own row
+          const int n = UN > 0 ? UN : n_r;
+          param_cols(row_off(ls_r, pos_r, n) + Da * n + (PC_CE(St::own_sparse(a)) ? 2 : 0));
         }
       }
       stage_sync();
       if constexpr (a < 7) PC_STAMP(10 + 2 * a);   // state a's block produced into the staging buffer
       const int len = (int)((long long)Da * (E1 - E0)) + Ca * T;
-      const int64_t g0 = goff[St::GO_D + a] + (int64_t)Da * E0 + (int64_t)Ca * n0;
       flush_run(A.G + g0, s_out, len, t, TN);
       stage_sync();
       if constexpr (a < 7) PC_STAMP(11 + 2 * a);   // ... read back and its stores issued
     };
-#ifdef PC_REVERSE_ODD   // A/B: odd tiles walk the states last to first, so the heavy states' flushes of the two halves
-                        // of the launch do not coincide (the price: two copies of this section in the code)
-    if (tile & 1) static_for_down<0, NY>(defect_jacobian_of_state);
-    else
-#endif
     static_for<0, NY>(defect_jacobian_of_state);
   }
 
   PC_STAMP(5);   // Jacobian of the defect rows staged and stored
   if constexpr (SPLIT) {         // second pass: second partials, the Hessian runs built from them, then the sums
-    if (!swap_passes) second_pass();
+    second_pass();
     if constexpr (!RED_EARLY) deposit_partials();
   }
   // two-launch build: the waves' sums meet here, at the end, so that no replica waits for another mid-kernel
@@ -1591,6 +1612,31 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
   PC_STAMP(8);   // this wave's stores have left
 }
 #undef PC_ITEM
+
+// The by-value PcPhaseArgs of pc_bulk_p<i>, read where it lies in the kernarg segment (behind the lead scalars).  A
+// kernel that names the parameter itself gets a private copy of the 2.2 KB block once enough tile bodies read it (the
+// compiler stops splitting the aggregate: seen with the twelve bodies of a mixed four-wave kernel, 2 240 B of scratch).
+__device__ __forceinline__ const PcPhaseArgs& kernarg_phase_args() {
+  typedef const __attribute__((address_space(4))) char* kseg_t;
+  return *(const PcPhaseArgs*)((kseg_t)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(PcLead));
+}
+
+// Mixed build: run the tile of workgroup `block` with the body compiled for its order (ORD...: the orders this code
+// object specialises for the phase) or, for a tile that spans sections of several orders, with the any-order body.
+// The record is read with scalar loads (the workgroup index is uniform) and the choice is a chain of scalar branches.
+template <class M, bool RES, int WN, int WIDX, int... ORD>
+__device__ __forceinline__ void bulk_mix(std::integer_sequence<int, ORD...>, const PcTileRec* rec, const PcPhaseArgs& KA,
+                                         bool MULTI, int first_block, int block, const PcLead* LD = nullptr,
+                                         const double* mx = nullptr, const double* mlam = nullptr, double* mc = nullptr,
+                                         double* mG = nullptr, double* mH = nullptr, int mflags = 0, unsigned mepoch = 0) {
+  const int order = rec->order, k0 = rec->k0, nsec = rec->nsec, n0 = rec->n0, nprev = rec->nprev, qaprev = rec->qa_prev;
+  const long long E0 = rec->E0;
+  const double wprev = rec->w_prev;
+  const bool done = (... || (order == ORD ? (bulk<M, ORD, RES, WN, WIDX, true>(KA, MULTI, first_block, block, LD, mx, mlam, mc, mG, mH,
+                                                                              mflags, mepoch, k0, nsec, n0, nprev, qaprev, E0, wprev), true)
+                                          : false));
+  if (!done) bulk<M, 0, RES, WN, WIDX, true>(KA, MULTI, first_block, block, LD, mx, mlam, mc, mG, mH, mflags, mepoch);
+}
 
 // ---------------------------------------------------------------------------------------------
 // tail pieces (one workgroup): the separate `pc_tail` launch, or block 0 of a resident-tail bulk launch

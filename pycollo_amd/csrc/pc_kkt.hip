@@ -804,7 +804,8 @@ int guarded(F&& f) {
 
 struct pc_kkt {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;        // the stream the work is queued on: own_stream, or a caller's (pc_kkt_set_stream)
+  hipStream_t own_stream = nullptr;    // created and destroyed with the handle
   const double* d_G = nullptr;
   const double* d_H = nullptr;
   int64_t nu = 0, n_dst = 0, total = 0;
@@ -887,7 +888,8 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     KHIP(hipSetDevice(device));
     k = new pc_kkt();
     k->device = device;
-    KHIP(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+    KHIP(hipStreamCreateWithFlags(&k->own_stream, hipStreamNonBlocking));
+    k->stream = k->own_stream;
     k->d_G = d_jac;
     k->d_H = d_hess;
     k->nu = d->nu;
@@ -1211,24 +1213,22 @@ void pc_kkt_destroy(pc_kkt* k) {
   (void)hipSetDevice(k->device);
   if (k->stream) {
     (void)hipStreamSynchronize(k->stream);
-    (void)hipStreamDestroy(k->stream);
+    (void)hipStreamSynchronize(k->stream);
+    (void)hipStreamDestroy(k->own_stream);
   }
   delete k;
 }
 
-int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, int32_t* n_neg) {
-  return guarded([&] {
-    if (!k || !dvec) throw std::runtime_error("null argument");
-    KHIP(hipSetDevice(k->device));
+// assembly + factorisation on the handle's stream with the diagonal in device memory; the pivot signs come back
+static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t* n_pos, int32_t* n_neg) {
+  {
     hipStream_t st = k->stream;
-    std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
-    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     KHIP(hipMemsetAsync(k->vals.p, 0, (size_t)k->total * sizeof(double), st));
     if (k->n_dst)
       hipLaunchKernelGGL(kkt_scatter, dim3((unsigned)((k->n_dst + 255) / 256)), dim3(256), 0, st, k->vals.p, k->dst.p, k->run_ptr.p,
                          k->src_kind.p, k->src_idx.p, k->src_coef.p, k->d_G, k->d_H, use_hess, k->n_dst);
     hipLaunchKernelGGL(kkt_diag, dim3((unsigned)((k->nu + 255) / 256)), dim3(256), 0, st, k->vals.p, k->diag_pos.p, k->fixed.p,
-                       k->dvec.p, k->nu);
+                       d_dvec, k->nu);
     if (k->n_leaf) {
       KArgs la = k->args;
       la.lds_doubles = k->lds_leaf_full / 8;
@@ -1252,6 +1252,42 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
     if (n_pos) *n_pos = (int32_t)p;
     if (n_neg) *n_neg = (int32_t)q;
     k->factored = true;
+  }
+}
+
+int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, int32_t* n_neg) {
+  return guarded([&] {
+    if (!k || !dvec) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, k->stream));
+    factor_device(k, use_hess, k->dvec.p, n_pos, n_neg);
+  });
+}
+
+// ---- the same with every vector in device memory (the device-resident interior-point iteration, pc_ipm.hip) ----
+int pc_kkt_set_stream(pc_kkt* k, void* stream) {
+  return guarded([&] {
+    if (!k) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    KHIP(hipStreamSynchronize(k->stream));
+    if (stream) k->stream = (hipStream_t)stream;   // (the handle's own stream stays allocated; it is destroyed with the handle)
+  });
+}
+
+int pc_kkt_factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t* n_pos, int32_t* n_neg) {
+  return guarded([&] {
+    if (!k || !d_dvec) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    factor_device(k, use_hess, d_dvec, n_pos, n_neg);
+  });
+}
+
+int pc_kkt_matvec_device(pc_kkt* k, int use_hess, const double* d_dvec, const double* d_x, double* d_y) {
+  return guarded([&] {
+    if (!k || !d_dvec || !d_x || !d_y) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    matvec_device<0>(k, use_hess, d_dvec, d_x, nullptr, d_y);
   });
 }
 
@@ -1291,20 +1327,13 @@ int pc_kkt_matvec(pc_kkt* k, int use_hess, const double* dvec, const double* x, 
 // only while it at least halves the residual's 2-norm and stays finite) in ONE call: rhs and dvec_true go up once, x
 // comes down once, and per correction only two doubles (the residual norm and a non-finite count) cross the bus.
 // Round 2 made eight host calls of this (k.solve / k.matvec), each with its own vector copies and stream wait.
-int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const double* rhs, int max_steps, double* x,
-                         int32_t* n_solves) {
-  return guarded([&] {
-    if (!k || !dvec_true || !rhs || !x) throw std::runtime_error("null argument");
-    if (!k->factored) throw std::runtime_error("pc_kkt_solve_refined before pc_kkt_factor");
-    KHIP(hipSetDevice(k->device));
+// the refined solve with right-hand side and true diagonal in device memory; returns the device vector that holds x
+static double* solve_refined_device(pc_kkt* k, int use_hess, const double* d_dvec, const double* d_rhs, int max_steps, int* n_solves) {
+  {
     hipStream_t st = k->stream;
     const int64_t nu = k->nu;
     const unsigned nbk = (unsigned)((nu + 255) / 256);
     const int nred = (int)std::min<int64_t>(256, (nu + 255) / 256);
-    std::memcpy(k->h_a.p, rhs, nu * sizeof(double));
-    std::memcpy(k->h_b.p, dvec_true, nu * sizeof(double));
-    KHIP(hipMemcpyAsync(k->w_rhs.p, k->h_a.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
-    KHIP(hipMemcpyAsync(k->w_dvec.p, k->h_b.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
     auto norms = [&](const double* d_r, const double* d_t, double& sumsq, double& bad) {
       hipLaunchKernelGGL(kkt_norm_partial, dim3(nred), dim3(256), 0, st, d_r, d_t, k->w_part.p, nu);
       hipLaunchKernelGGL(kkt_norm_final, dim3(1), dim3(64), 0, st, k->w_part.p, nred, k->w_norm.p);
@@ -1317,15 +1346,15 @@ int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const
     double* res = k->w_res.p;
     double* trial = k->w_trial.p;
     double* res_t = k->w_dx.p;      // (the correction is formed in vout, the trial's residual lands here)
-    solve_device(k, k->w_rhs.p, sol);
-    matvec_device<1>(k, use_hess, k->w_dvec.p, sol, k->w_rhs.p, res);
+    solve_device(k, d_rhs, sol);
+    matvec_device<1>(k, use_hess, d_dvec, sol, d_rhs, res);
     int solves = 1;
     double nres = 0.0, bad = 0.0;
     if (max_steps > 0) norms(res, sol, nres, bad);
     for (int it = 0; it < max_steps; ++it) {
       solve_device(k, res, k->vout.p);
       hipLaunchKernelGGL(kkt_add, dim3(nbk), dim3(256), 0, st, sol, k->vout.p, trial, nu);
-      matvec_device<1>(k, use_hess, k->w_dvec.p, trial, k->w_rhs.p, res_t);
+      matvec_device<1>(k, use_hess, d_dvec, trial, d_rhs, res_t);
       ++solves;
       double nt = 0.0, bad_t = 0.0;
       norms(res_t, trial, nt, bad_t);
@@ -1336,9 +1365,41 @@ int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const
       std::swap(res, res_t);
       nres = nt;
     }
+    if (n_solves) *n_solves = solves;
+    return sol;
+  }
+}
+
+int pc_kkt_solve_refined(pc_kkt* k, int use_hess, const double* dvec_true, const double* rhs, int max_steps, double* x,
+                         int32_t* n_solves) {
+  return guarded([&] {
+    if (!k || !dvec_true || !rhs || !x) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_solve_refined before pc_kkt_factor");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    const int64_t nu = k->nu;
+    std::memcpy(k->h_a.p, rhs, nu * sizeof(double));
+    std::memcpy(k->h_b.p, dvec_true, nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->w_rhs.p, k->h_a.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    KHIP(hipMemcpyAsync(k->w_dvec.p, k->h_b.p, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    int solves = 0;
+    const double* sol = solve_refined_device(k, use_hess, k->w_dvec.p, k->w_rhs.p, max_steps, &solves);
     KHIP(hipMemcpyAsync(k->h_b.p, sol, nu * sizeof(double), hipMemcpyDeviceToHost, st));
     KHIP(hipStreamSynchronize(st));
     std::memcpy(x, k->h_b.p, nu * sizeof(double));
+    if (n_solves) *n_solves = solves;
+  });
+}
+
+int pc_kkt_solve_refined_device(pc_kkt* k, int use_hess, const double* d_dvec_true, const double* d_rhs, int max_steps,
+                                double* d_x, int32_t* n_solves) {
+  return guarded([&] {
+    if (!k || !d_dvec_true || !d_rhs || !d_x) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_solve_refined_device before a factorisation");
+    KHIP(hipSetDevice(k->device));
+    int solves = 0;
+    const double* sol = solve_refined_device(k, use_hess, d_dvec_true, d_rhs, max_steps, &solves);
+    KHIP(hipMemcpyAsync(d_x, sol, k->nu * sizeof(double), hipMemcpyDeviceToDevice, k->stream));
     if (n_solves) *n_solves = solves;
   });
 }

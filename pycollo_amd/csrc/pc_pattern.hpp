@@ -45,6 +45,11 @@ struct Phase {
   std::string bulk_kernel;
   int eval_ops = 0;             // launch-shape hint (pc_phase_desc::eval_ops)
   int compiled_order = 0;       // > 0: the phase's kernel is specialised for sections of exactly that many nodes
+  // mixed build: the section orders the phase's kernels carry a body for, next to the any-order body (empty: not mixed)
+  std::vector<int32_t> spec_orders;
+  int cap_rows[PC_MAX_ORDER + 1] = {};   // defect rows an order-pure tile of order n may hold (0: tile capacity - 1)
+  int mix_cap_rows = 0;                  // ... and a tile of several orders (0: tile capacity - 1)
+  int min_run_rows = 24;                 // a run of equal sections gets tiles of its own from this many rows
   // derived
   int n_z = 0, n_t = 0, n_fn = 0, n_v = 0, N = 0;
   std::vector<int32_t> sec_s;   // [K+1]
@@ -57,6 +62,7 @@ struct Phase {
   std::vector<int32_t> hsum_local;   // hsum_slot as indices into Problem::tail_owned
   int64_t gq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int32_t> tile_k0;
+  std::vector<int32_t> tile_order;   // [n_tiles] mixed build: the order whose body runs the tile, 0 = the any-order body
   int nred = 0;
 
   bool dep(int r, int c) const { return jmask[(size_t)r * n_v + c] != 0; }
@@ -174,7 +180,69 @@ inline void finalize_phase_tables(Phase& P, int n_s) {
   for (size_t e = 0; e < P.hess_row.size(); ++e) P.nred += P.hess_col[e] >= P.n_z ? 1 : 0;
 }
 
+// Mixed build (Phase::spec_orders): tiles are cut at order changes where the orders come in runs, so that a tile of
+// equal sections runs the body compiled for its order.  ph refinement leaves exactly such meshes: a section that is
+// subdivided becomes k sections of the minimum order and a merged stretch likewise (pycollo/mesh_refinement.py:
+// 252-321), the others keep individual orders.  A run of at least min_run_rows rows of an order with a body is cut into
+// tiles of its own (nearly equal section counts, at most cap_rows[n] rows); what lies between such runs is cut greedily
+// into tiles of at most mix_cap_rows rows -- any of those that happens to hold one order with a body is marked as such.
+inline void build_tiles_mixed(Phase& P, int TB) {
+  auto has_body = [&](int n) { return std::find(P.spec_orders.begin(), P.spec_orders.end(), n) != P.spec_orders.end(); };
+  auto cap = [&](int n) {
+    int c = P.cap_rows[n] > 0 ? std::min(P.cap_rows[n], TB - 1) : TB - 1;
+    return std::max(n - 1, (c / (n - 1)) * (n - 1));
+  };
+  const int mix_cap = P.mix_cap_rows > 0 ? std::min(P.mix_cap_rows, TB - 1) : TB - 1;
+  P.tile_k0.clear();
+  P.tile_order.clear();
+  P.tile_k0.push_back(0);
+  auto close_tile = [&](int k_end) {   // the open tile ends before section k_end
+    const int k_begin = P.tile_k0.back();
+    if (k_end <= k_begin) return;
+    int n = P.n_k[k_begin];
+    for (int k = k_begin; k < k_end; ++k) n = (P.n_k[k] == n) ? n : 0;
+    if (n > 0 && !(has_body(n) && (k_end - k_begin) * (n - 1) <= cap(n))) n = 0;
+    P.tile_k0.push_back(k_end);
+    P.tile_order.push_back(n);
+  };
+  auto greedy = [&](int ka, int kb) {   // sections [ka, kb) between two qualifying runs
+    int rows = 0;
+    for (int k = ka; k < kb; ++k) {
+      const int r = P.n_k[k] - 1;
+      if (rows + r > mix_cap && rows > 0) {
+        close_tile(k);
+        rows = 0;
+      }
+      rows += r;
+    }
+    close_tile(kb);
+  };
+  int pend = 0, k = 0;
+  while (k < P.K) {
+    const int n = P.n_k[k];
+    int e = k;
+    while (e < P.K && P.n_k[e] == n) ++e;
+    if (has_body(n) && (e - k) * (n - 1) >= P.min_run_rows) {
+      greedy(pend, k);
+      const int spt = cap(n) / (n - 1), nt = (e - k + spt - 1) / spt;
+      int at = k;
+      for (int i = 0; i < nt; ++i) {
+        at += (e - k) / nt + (i < (e - k) % nt ? 1 : 0);
+        close_tile(at);
+      }
+      pend = e;
+    }
+    k = e;
+  }
+  greedy(pend, P.K);
+}
+
 inline void build_tiles(Phase& P, int TB) {
+  if (!P.spec_orders.empty()) {
+    build_tiles_mixed(P, TB);
+    return;
+  }
+  P.tile_order.clear();
   P.tile_k0.clear();
   P.tile_k0.push_back(0);
   int rows = 0;

@@ -43,7 +43,8 @@ class _PhaseDesc(C.Structure):
                 ("n_jac", C.c_int32), ("jac_row", _i32p), ("jac_col", _i32p),
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
                 ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("n_edge_rec", C.c_int32 * 2),
-                ("eval_ops", C.c_int32), ("n_w", C.c_int32), ("w_kind", _i32p), ("w_idx", _i32p)]
+                ("eval_ops", C.c_int32), ("n_w", C.c_int32), ("w_kind", _i32p), ("w_idx", _i32p),
+                ("n_spec", C.c_int32), ("spec_orders", C.c_int32 * 4), ("reserved_spec", C.c_int32 * 3)]
 
 
 class _ProblemDesc(C.Structure):
@@ -111,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.pc_launch_bulk_flags_device.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.pc_set_tile_range.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.pc_phase_tiles.argtypes = [vp, C.c_int, _i32p, _i32p, vp]
+    lib.pc_phase_tile_orders.argtypes = [vp, C.c_int, vp]
     lib.pc_set_partials_buffer.argtypes = [vp, C.c_int, vp]
     lib.pc_synchronize.argtypes = [vp]
     lib.pc_check.argtypes = [vp]
@@ -128,6 +130,32 @@ def load_library() -> C.CDLL:
 
 def _i32(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.int32).reshape(-1))
+
+
+MIX_MIN_RUN_ROWS = 24      # pc_pattern.hpp Phase::min_run_rows: a run of equal sections gets tiles of its own from here
+MIX_MIN_NODES = int(os.environ.get("PYCOLLO_AMD_MIX_MIN_NODES", "20000"))   # smaller NLPs keep the any-order kernel
+
+
+def choose_spec_orders(n_k, max_orders: int = 4, min_share: float = 0.05) -> tuple:
+    """Section orders worth a tile body of their own on a mesh of mixed orders: those whose sections come in runs
+    (>= MIX_MIN_RUN_ROWS defect rows of equal sections in a row, pc_pattern.hpp::build_tiles_mixed) covering at least
+    ``min_share`` of the phase's rows; at most ``max_orders`` of them, by coverage.  ph refinement leaves such meshes:
+    subdivided and merged stretches are runs of the minimum order (pycollo/mesh_refinement.py:252-321)."""
+    n_k = np.asarray(n_k, dtype=np.int64)
+    if n_k.size == 0 or np.all(n_k == n_k[0]):
+        return ()
+    cut = np.flatnonzero(np.diff(n_k)) + 1
+    starts = np.concatenate([[0], cut])
+    lengths = np.diff(np.concatenate([starts, [n_k.size]]))
+    order = n_k[starts]
+    rows = lengths * (order - 1)
+    total = float(np.sum(n_k - 1))
+    cover = {}
+    for o, r in zip(order, rows):
+        if r >= MIX_MIN_RUN_ROWS:
+            cover[int(o)] = cover.get(int(o), 0) + int(r)
+    picks = sorted((o for o, r in cover.items() if r >= min_share * total), key=lambda o: -cover[o])[:max_orders]
+    return tuple(sorted(picks))
 
 
 def _ptr(a, typ):
@@ -156,7 +184,7 @@ class NlpEngine:
 
     def __init__(self, problem: ProblemSpec | Model, meshes: list[PhaseMesh] | None = None, *, device: int | None = 0,
                  threads_per_block: int = 0, quad: QuadratureTables | None = None, build: bool = True,
-                 specialise: bool = True):
+                 specialise: bool = True, mixed="auto"):
         self.model = problem if isinstance(problem, Model) else compile_model(problem)
         self.quad = quad or QuadratureTables(self.model.quadrature_method)
         if meshes is None:
@@ -174,9 +202,18 @@ class NlpEngine:
         self.orders = tuple(int(m.n[0]) if np.all(m.n == m.n[0]) else 0 for m in meshes)
         if not specialise:
             self.orders = tuple(0 for _ in meshes)
+        # ... and a phase whose sections differ in order gets the mixed build when its orders come in runs (large NLPs
+        # only: a code object per set of orders is not worth compiling for a mesh of a few hundred nodes).
+        # mixed: "auto" | None | one tuple of orders per phase
+        if mixed == "auto":
+            big = sum(int(np.sum(m.n - 1)) + 1 for m in meshes) >= MIX_MIN_NODES
+            mixed = (tuple(choose_spec_orders(m.n) if o == 0 else () for m, o in zip(meshes, self.orders))
+                     if (specialise and big and self.device >= 0) else None)
+        self.mixed = (tuple(tuple(int(n) for n in mm) for mm in mixed) if mixed is not None and any(mixed)
+                      else tuple(() for _ in meshes))
         if self.device >= 0:
-            code_object = (codegen.build_code_object(self.model, self.orders) if build
-                           else codegen.code_object_path(self.model, self.orders))
+            code_object = (codegen.build_code_object(self.model, self.orders, mixed=self.mixed) if build
+                           else codegen.code_object_path(self.model, self.orders, self.mixed))
             if not os.path.exists(code_object):
                 raise RuntimeError(f"code object {code_object} is missing")
         self.code_object = code_object
@@ -217,6 +254,9 @@ class NlpEngine:
             d.n_hess, d.hess_row, d.hess_col = len(hr), _ptr(hr, _i32p), _ptr(hc, _i32p)
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
             d.compiled_order = self.orders[i] if self.device >= 0 else 0
+            d.n_spec = len(self.mixed[i])
+            for j, n in enumerate(self.mixed[i]):
+                d.spec_orders[j] = n
             d.eval_ops = pm.eval_ops
             if pm.w_kind:
                 wk, wi = _i32(pm.w_kind), _i32(pm.w_idx)
@@ -436,6 +476,7 @@ class NlpEngine:
     def evaluate_all_device(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None):
         def addr(t):
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._cached_x = None   # (the launch overwrites the handle's f block)
         self._check(self._lib.pc_eval_all_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
                                                  addr(d_G), addr(d_H), stream))
 
@@ -449,6 +490,7 @@ class NlpEngine:
         keep = (d_x, d_lam, d_c, d_G, d_H)       # the buffers must outlive the callable
 
         def call(obj_factor=1.0, _keep=keep):
+            self._cached_x = None
             if not fn(h, px, obj_factor, pl, pc, pG, pH, stream):
                 raise RuntimeError("pc_eval_all_device failed: " + err().decode())
         return call
@@ -457,6 +499,7 @@ class NlpEngine:
         """Profiling aid: only the bulk kernels of :meth:`evaluate_all_device`."""
         def addr(t):
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._cached_x = None   # (the launch overwrites the handle's f block)
         self._check(self._lib.pc_launch_bulk_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
                                                     stream))
 
@@ -464,12 +507,14 @@ class NlpEngine:
         """The tile kernels for a subset of the outputs: ``flags`` = 1 (c~) | 2 (G~) | 4 (H~)."""
         def addr(t):
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._cached_x = None   # (the launch overwrites the handle's f block)
         self._check(self._lib.pc_launch_bulk_flags_device(self._h, addr(d_x), addr(d_lam), addr(d_c), addr(d_G), addr(d_H),
                                                           int(flags), stream))
 
     def launch_tail_only(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None):
         def addr(t):
             return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._cached_x = None   # (the launch overwrites the handle's f block)
         self._check(self._lib.pc_launch_tail_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
                                                     addr(d_G), addr(d_H), stream))
 
@@ -483,6 +528,13 @@ class NlpEngine:
         k0 = np.empty(n.value + 1, dtype=np.int32)
         self._check(self._lib.pc_phase_tiles(self._h, phase, C.byref(n), C.byref(r), k0.ctypes.data))
         return k0, r.value
+
+    def phase_tile_orders(self, phase: int) -> np.ndarray:
+        """Mixed build: the section order whose tile body runs every tile of the phase (0 = the any-order body)."""
+        k0, _ = self.phase_tiles(phase)
+        out = np.zeros(len(k0) - 1, dtype=np.int32)
+        self._check(self._lib.pc_phase_tile_orders(self._h, phase, out.ctypes.data))
+        return out
 
     def set_partials_buffer(self, phase: int, d_partials):
         ptr = d_partials.data_ptr() if hasattr(d_partials, "data_ptr") else d_partials

@@ -388,6 +388,7 @@ class InteriorPointSolver:
                 # (BacktrackingLineSearch -> STOP_AT_ACCEPTABLE_POINT): no restoration from a converged point whose
                 # remaining error is the linear solver's floor
                 status = "acceptable"
+                self.counts["acceptable_after_failed_line_search"] = 1   # (surfaced by solve_ocp: not the requested tolerance)
                 break
             if not accepted:
                 # feasibility restoration, reduced to its core: Gauss-Newton steps on ||c||_1 (minimum-norm
@@ -594,6 +595,282 @@ class GpuInteriorPointSolver(InteriorPointSolver):
             self.kkt.close()
             self.kkt = None
         return res
+
+
+class _IpmDesc(__import__("ctypes").Structure):
+    import ctypes as _C
+    _fields_ = [("n", _C.c_int64), ("m", _C.c_int64), ("ns", _C.c_int64), ("ineq_rows", _C.c_void_p),
+                ("vl", _C.c_void_p), ("vu", _C.c_void_p), ("hasl", _C.c_void_p), ("hasu", _C.c_void_p), ("fixed", _C.c_void_p),
+                ("row_scale", _C.c_void_p), ("rhs_c", _C.c_void_p), ("obj_scale", _C.c_double)]
+
+
+class ResidentInteriorPointSolver(GpuInteriorPointSolver):
+    """The same algorithm with the ITERATION on the device as well (``csrc/pc_ipm.hpp``): v, lambda, z, the step and
+    every right-hand side stay in device memory; per iteration this loop makes four or five C calls -- error measures,
+    Newton step (Hessian, assembly, factorisation with the regularisation loop, refined solve, step limits), one call
+    per line-search trial point, acceptance -- and reads a handful of scalars.  The filter, the barrier update and the
+    termination tests are the scalar logic of :meth:`InteriorPointSolver.solve`, unchanged; the rare restoration branch
+    pulls the state to the host, runs the parent's code and pushes it back.  The reference's boundary: one call into
+    IPOPT per solve (pycollo/backend.py:1807-1827)."""
+
+    def solve(self, x0) -> IpmResult:
+        import ctypes as C
+        self.engine.set_prefetch_jac(False)
+        try:
+            return self._solve_resident(x0, C)
+        finally:
+            self.engine.set_prefetch_jac(True)
+            if getattr(self, "_ipm", None):
+                self.engine._lib.pc_ipm_destroy(self._ipm)
+                self._ipm = None
+            if self.kkt is not None:
+                self.kkt.close()
+                self.kkt = None
+
+    def _solve_resident(self, x0, C) -> IpmResult:
+        t_start = time.perf_counter()
+        lib = self.engine._lib
+        for name in ("pc_ipm_create", "pc_ipm_set_state", "pc_ipm_get_state", "pc_ipm_eval_point", "pc_ipm_errors",
+                     "pc_ipm_newton", "pc_ipm_trial", "pc_ipm_accept"):
+            getattr(lib, name).restype = C.c_int
+        lib.pc_ipm_destroy.restype = None
+        lib.pc_ipm_destroy.argtypes = [C.c_void_p]
+        lib.pc_ipm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pc_ipm_set_state.argtypes = [C.c_void_p] * 5
+        lib.pc_ipm_get_state.argtypes = [C.c_void_p] * 7
+        lib.pc_ipm_eval_point.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pc_ipm_errors.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pc_ipm_newton.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib.pc_ipm_trial.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        lib.pc_ipm_accept.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+
+        def check(ok):
+            if not ok:
+                raise RuntimeError(lib.pc_last_error().decode())
+
+        n, nv, m = self.n, self.nv, self.m
+        x0 = np.asarray(x0, float)
+        # ---- set-up on the host, exactly as InteriorPointSolver.solve: gradient-based scaling, slacks, interior push ----
+        self.sf, self.sc = 1.0, np.ones(m)
+        push = (1e-3, 1e-3) if self.warm_start else (1e-2, 1e-2)
+        x0c = self._push_interior(np.concatenate([x0, np.zeros(self.ns)]), *push)[:n]
+        x0c[self.fixed[:n]] = self.vl[:n][self.fixed[:n]]
+        g0 = np.nan_to_num(np.asarray(self.p.gradient(x0c), float), nan=0.0, posinf=0.0, neginf=0.0)
+        gmax = float(np.max(np.abs(g0))) if n else 0.0
+        if gmax > 100.0 and self.gradient_scaling:
+            self.sf = max(100.0 / gmax, 1e-8)
+        if m and self.gradient_scaling:
+            jv = np.abs(np.nan_to_num(np.asarray(self.p.jacobian(x0c), float), nan=0.0, posinf=0.0, neginf=0.0))
+            rowmax = np.zeros(m)
+            np.maximum.at(rowmax, self.jr, jv)
+            big = rowmax > 100.0
+            self.sc[big] = np.maximum(100.0 / rowmax[big], 1e-8)
+        if self.ns:
+            self.vl[n:] = np.where(self.cl[self.ineq] > -INF, self.sc[self.ineq] * self.cl[self.ineq], self.cl[self.ineq])
+            self.vu[n:] = np.where(self.cu[self.ineq] < INF, self.sc[self.ineq] * self.cu[self.ineq], self.cu[self.ineq])
+        v = np.concatenate([x0, np.zeros(self.ns)])
+        if self.ns:
+            v[n:] = (self.sc * np.asarray(self.p.constraints(x0), float))[self.ineq]
+        v = self._push_interior(v, 1e-3, 1e-3) if self.warm_start else self._push_interior(v)
+        v[self.fixed] = self.vl[self.fixed]
+        mu = self.mu_init
+        zl = np.where(self.hasl, 1.0, 0.0)
+        zu = np.where(self.hasu, 1.0, 0.0)
+        f, g = self._f(v[:n]), np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+        c, J = self._c(v), self._J(v[:n])
+        lam = self._ls_multipliers(J, g - zl + zu)
+        # ---- the device state ----
+        kkt = self._ensure_kkt()
+        keep = [np.ascontiguousarray(self.ineq, dtype=np.int64), np.ascontiguousarray(self.vl), np.ascontiguousarray(self.vu),
+                np.ascontiguousarray(self.hasl, dtype=np.uint8), np.ascontiguousarray(self.hasu, dtype=np.uint8),
+                np.ascontiguousarray(self.fixed, dtype=np.uint8), np.ascontiguousarray(self.sc), np.ascontiguousarray(self.rhs_c)]
+        d = _IpmDesc(n, m, self.ns, *[a.ctypes.data for a in keep], float(self.sf))
+        handle = C.c_void_p()
+        check(lib.pc_ipm_create(self.engine._h, kkt._h, C.byref(d), C.byref(handle)))
+        self._ipm = handle
+
+        def push_state():
+            check(lib.pc_ipm_set_state(handle, *(np.ascontiguousarray(a, dtype=np.float64).ctypes.data for a in (v, lam, zl, zu))))
+
+        def pull_state():
+            out = [np.empty(nv), np.empty(m), np.empty(nv), np.empty(nv), np.empty(m), np.empty(nv)]
+            check(lib.pc_ipm_get_state(handle, *(a.ctypes.data for a in out)))
+            return out
+
+        r3, r8, r10 = np.empty(3), np.empty(8), np.empty(10)
+        push_state()
+        check(lib.pc_ipm_eval_point(handle, r3.ctypes.data))
+        f, theta = float(r3[0]), float(r3[1])
+        filt: list[tuple[float, float]] = []
+        theta0 = theta
+        theta_max, theta_min = 1e4 * max(1.0, theta0), 1e-4 * max(1.0, theta0)
+        dw_last = 0.0
+        status, hist = "max_iter", []
+        k_eps, k_mu, th_mu, s_max, g_th, g_phi, eta = 10.0, 0.2, 1.5, 100.0, 1e-5, 1e-8, 1e-4
+        accept_count = restarts = it = 0
+        last_alpha = last_amax = 0.0
+        last_tag = ""
+        inf_pr = inf_du = np.inf
+        nz = max(1, int(self.hasl.sum() + self.hasu.sum()))
+        any_l, any_u = bool(self.hasl.any()), bool(self.hasu.any())
+
+        def errors(e, mu_):
+            sd = max(s_max, (e[7] + e[8] + e[9]) / (m + nz)) / s_max
+            scz = max(s_max, (e[8] + e[9]) / nz) / s_max
+            comp = 0.0
+            if any_l:
+                comp = max(comp, abs(e[3] - mu_), abs(e[4] - mu_))
+            if any_u:
+                comp = max(comp, abs(e[5] - mu_), abs(e[6] - mu_))
+            e_du = float(e[0]) if self.nf else 0.0
+            e_pr = float(e[1]) if m else 0.0
+            return max(e_du / sd, e_pr, comp / scz), e_pr, e_du
+
+        phase = {"setup": time.perf_counter() - t_start, "errors": 0.0, "line_search": 0.0, "newton": 0.0}
+        for it in range(self.max_iter + 1):
+            t_ph = time.perf_counter()
+            check(lib.pc_ipm_errors(handle, r10.ctypes.data))
+            e = r10.copy()
+            theta = float(e[2])
+            e0, inf_pr, inf_du = errors(e, 0.0)
+            phase["errors"] += time.perf_counter() - t_ph
+            hist.append((it, f, inf_pr, inf_du, mu))
+            if self.verbose:
+                print(f"{it:4d}  f {f: .8e}  inf_pr {inf_pr:.2e}  inf_du {inf_du:.2e}  lg(mu) {np.log10(mu):5.1f}  dw {dw_last:.1e}"
+                      f"  alpha {last_alpha:.2e} (max {last_amax:.2e}){last_tag}")
+            if e0 <= self.tol:
+                status = "optimal"
+                break
+            accept_count = accept_count + 1 if e0 <= self.acceptable_tol else 0
+            if accept_count >= 15:
+                status = "acceptable"
+                break
+            if it == self.max_iter:
+                break
+            while errors(e, mu)[0] <= k_eps * mu and mu > self.tol / 10:
+                mu = max(self.tol / 10, min(k_mu * mu, mu ** th_mu))
+                filt = []
+            tau = max(0.99, 1.0 - mu)
+            t_kkt = time.perf_counter()
+            self.counts["hessian"] += 1
+            check(lib.pc_ipm_newton(handle, mu, tau, dw_last, r8.ctypes.data))
+            dt = time.perf_counter() - t_kkt
+            self.kkt_seconds += dt
+            phase["newton"] += dt
+            self.counts["factorisations"] += int(r8[5])
+            self.counts["kkt_solves"] = self.counts.get("kkt_solves", 0) + int(r8[6])
+            self.counts["refined_solves"] = self.counts.get("refined_solves", 0) + 1
+            if r8[0] < 0.0:
+                status = "kkt_failure"
+                break
+            dw_last, a_max, a_z, dphi = float(r8[0]), float(r8[1]), float(r8[2]), float(r8[3])
+            phi = f + float(r8[4])
+            # filter line search: the scalar logic of InteriorPointSolver.solve, one device call per trial point
+            t_ph = time.perf_counter()
+            alpha, accepted = a_max, False
+            ft = th_t = phi_t = np.nan
+            while alpha > 1e-12:
+                self.counts["objective"] += 1
+                self.counts["constraints"] += 1
+                check(lib.pc_ipm_trial(handle, alpha, mu, r3.ctypes.data))
+                ft, th_t = float(r3[0]), float(r3[1])
+                phi_t = ft + float(r3[2])
+                if np.isfinite(ft) and np.isfinite(th_t) and np.isfinite(phi_t) and th_t <= theta_max:
+                    in_filter = any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt)
+                    if not in_filter:
+                        switching = dphi < 0 and alpha * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min
+                        if switching:
+                            if phi_t <= phi + eta * alpha * dphi:
+                                accepted = True
+                        elif th_t <= (1 - g_th) * theta or phi_t <= phi - g_phi * theta:
+                            accepted = True
+                            filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                        if accepted:
+                            break
+                alpha *= 0.5
+            phase["line_search"] += time.perf_counter() - t_ph
+            if not accepted and e0 <= self.acceptable_tol:
+                status = "acceptable"
+                self.counts["acceptable_after_failed_line_search"] = 1
+                break
+            if not accepted:
+                # restoration (rare): the state comes to the host, the parent's Gauss-Newton restoration / barrier restart
+                # runs on host vectors through the same GPU factorisation, the result goes back
+                v, lam, zl, zu, c, g = pull_state()
+                J = ("resident", 0)
+                filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                vr, cr_, Jr, ok_r = v.copy(), c, J, False
+                for _ in range(30):
+                    th_r = float(np.sum(np.abs(cr_)))
+                    self._J(vr[:n])              # G~ at the restoration point (the Newton step left the Hessian's launch behind it)
+                    try:
+                        dr = self._gn_step(Jr, cr_)
+                    except RuntimeError:
+                        break
+                    if not np.all(np.isfinite(dr)):
+                        break
+                    a = self._alpha_max(vr, dr, tau)
+                    moved = False
+                    while a > 1e-10:
+                        vt = vr + a * dr
+                        with np.errstate(all="ignore"):
+                            ct = self._c(vt)
+                        if np.all(np.isfinite(ct)) and float(np.sum(np.abs(ct))) < (1 - 1e-4 * a) * th_r:
+                            vr, cr_, moved = vt, ct, True
+                            break
+                        a *= 0.5
+                    if not moved:
+                        break
+                    th_t = float(np.sum(np.abs(cr_)))
+                    if th_t <= 0.9 * theta:
+                        with np.errstate(all="ignore"):
+                            ft = self._f(vr[:n])
+                            phi_t = self._barrier(vr, ft, mu)
+                        if np.isfinite(phi_t) and not any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt):
+                            ok_r = True
+                            break
+                if not ok_r:
+                    restarts += 1
+                    if restarts > 3:
+                        status = "restoration_failed"
+                        break
+                    if float(np.sum(np.abs(cr_))) < theta:
+                        v = vr
+                    mu = min(self.mu_init, max(100.0 * mu, 1e-6))
+                    filt = []
+                    v = self._push_interior(v, min(1e-2, mu), min(1e-2, mu))
+                    g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+                    self._J(v[:n])
+                    dlv, duv = np.where(self.hasl, v - self.vl, 1.0), np.where(self.hasu, self.vu - v, 1.0)
+                    zl = np.where(self.hasl, mu / dlv, 0.0)
+                    zu = np.where(self.hasu, mu / duv, 0.0)
+                    lam = self._ls_multipliers(J, g - zl + zu)
+                    last_alpha, last_amax, last_tag = 0.0, a_max, " r"
+                else:
+                    v = vr
+                    last_alpha, last_amax, last_tag = 0.0, a_max, " R"
+                    g = np.concatenate([self._g(v[:n]), np.zeros(self.ns)])
+                    self._J(v[:n])
+                    lam = self._ls_multipliers(J, g - zl + zu)
+                push_state()
+                check(lib.pc_ipm_eval_point(handle, r3.ctypes.data))
+                f = float(r3[0])
+                continue
+            last_alpha, last_amax, last_tag = alpha, a_max, ""
+            self.counts["gradient"] += 1
+            self.counts["jacobian"] += 1
+            check(lib.pc_ipm_accept(handle, alpha, a_z, mu))
+            f = ft
+        v, lam, zl, zu, c, g = pull_state()
+        ev = dict(self.counts)
+        ev["barrier_restarts"] = restarts
+        ev["kkt_seconds"] = self.kkt_seconds
+        ev["phase_seconds"] = {k: round(val, 6) for k, val in phase.items()}
+        ev["gpu_seconds"] = dict(self.times)
+        ev["resident_iteration"] = True
+        return IpmResult(x=v[:n].copy(), lam=(self.sc * lam / self.sf).copy(), objective=f / self.sf, status=status, iterations=it,
+                         inf_pr=inf_pr, inf_du=inf_du, mu=mu, seconds=time.perf_counter() - t_start, evaluations=ev, history=hist,
+                         zl=(zl[:n] / self.sf).copy(), zu=(zu[:n] / self.sf).copy())
 
 
 def solve_nlp(problem_obj, x0, lb, ub, cl, cu, **options) -> IpmResult:

@@ -131,17 +131,20 @@ class MeshIteration:
 
     # ---- solve -------------------------------------------------------------------------------------
     def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0, linear_solver: str = "gpu",
-                       warm_start: bool = False):
+                       warm_start: bool = False, host_retry: bool = False):
         """Solve the scaled NLP with the interior-point stand-in for IPOPT (``pycollo_amd.ipm``), driven through
         the cyipopt-protocol object exactly as ``ipopt.problem(...).solve(x0)`` would be (pycollo/nlp.py:84-115).
         ``linear_solver``: "gpu" -- the KKT systems are assembled from device-resident G~ / H~ and factorised on the
         GPU (``pycollo_amd.kkt``; the role of IPOPT's ``linear_solver`` option, pycollo/backend.py:1703-1711);
         "host" -- the callbacks deliver host arrays and SuperLU factorises (what a host-side IPOPT would do).
-        ``warm_start``: pycollo's setting of that name (settings.py:228, backend.py:1703-1709)."""
+        ``warm_start``: pycollo's setting of that name (settings.py:228, backend.py:1703-1709).
+        ``host_retry`` (off by default): repeat an NLP whose GPU-factorised solve did not succeed once more with the host
+        factorisation (a second full solve on SuperLU; reported through a RuntimeWarning and the result's flags)."""
         from .engine import PycolloGpuProblem
-        from .ipm import GpuInteriorPointSolver, InteriorPointSolver
+        from .ipm import GpuInteriorPointSolver, InteriorPointSolver, ResidentInteriorPointSolver
         pobj = PycolloGpuProblem(self.engine)
-        cls = {"gpu": GpuInteriorPointSolver, "host": InteriorPointSolver}[linear_solver]
+        # "resident": the GPU factorisation AND the iteration's vectors on the device (csrc/pc_ipm.hpp)
+        cls = {"gpu": GpuInteriorPointSolver, "host": InteriorPointSolver, "resident": ResidentInteriorPointSolver}[linear_solver]
         solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
                      tol=tol, max_iter=max_iter, verbose=verbose, warm_start=warm_start)
         # The model's SymPy graphs are millions of long-lived objects: a full collection walking them takes ~80 ms and
@@ -167,7 +170,7 @@ class MeshIteration:
             if was_enabled:
                 gc.enable()
             gc.unfreeze()
-        if linear_solver == "gpu" and not res.success:
+        if linear_solver in ("gpu", "resident") and not res.success and host_retry:
             # The two linear solvers round differently; on a degenerate NLP (a bang-bang solution on a coarse mesh) that
             # can send the filter line search into its restoration phase on one path and not on the other.  A failed
             # GPU-factorised solve is repeated once with the host factorisation before the mesh iteration is given up;

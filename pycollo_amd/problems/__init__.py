@@ -611,3 +611,17 @@ REGISTRY = {
     "tumour_anti_angiogenesis": tumour_anti_angiogenesis,
     "space_station": space_station,
 }
+
+
+def with_refined_mesh(prob: ProblemSpec, nodes_per_phase: int, seeds=None) -> ProblemSpec:
+    """Give every phase of ``prob`` a mesh as ph refinement leaves it (refinement.synthetic_refined_mesh: the ph rule
+    iterated on a synthetic error field), phase i from seed ``seeds[i]`` (default 7, 8, ...).  The workload of bench.py
+    --refined and of the refined-mesh parity tests (BASELINE.json configs[4]: "ph-adaptive mesh refinement to ~50k nodes")."""
+    from ..refinement import synthetic_refined_mesh
+    seeds = tuple(seeds) if seeds is not None else tuple(7 + i for i in range(len(prob.phases)))
+    for ph, seed in zip(prob.phases, seeds):
+        sizes, nodes = synthetic_refined_mesh(int(nodes_per_phase), int(seed))
+        ph.mesh.number_mesh_sections = int(nodes.size)
+        ph.mesh.mesh_section_sizes = sizes
+        ph.mesh.number_mesh_section_nodes = nodes
+    return prob

@@ -156,3 +156,47 @@ def next_phase_mesh(sizes, nodes, max_rel_err, *, mesh_tol=MESH_TOLERANCE, n_min
     flush_sub()
     new_sizes = np.asarray(new_sizes)
     return new_sizes / new_sizes.sum(), np.asarray(new_nodes, dtype=np.int64), False
+
+
+def synthetic_refined_mesh(target_nodes: int, seed: int = 7, *, K0: int = 10, n0: int = COLLOCATION_POINTS_MIN,
+                           mesh_tol: float = MESH_TOLERANCE, features: int = 6, max_iterations: int = 12):
+    """(sizes, nodes) of a mesh as the ph rule above leaves it, without a solve: ``next_phase_mesh`` iterated from a
+    coarse uniform mesh on a synthetic error field.  A section of n nodes and width h at tau is given the error
+    (h / ell(tau))^n -- what a solution with local time scale ell(tau) produces -- where ell is smooth with a few sharp
+    dips (``features`` of them, seeded), and its overall level is scanned for the converged mesh closest to
+    ``target_nodes`` nodes.  Workload generator for bench.py / the parity tests: the mesh has what refinement produces
+    (runs of n_min-node sections where sections were subdivided or merged, individual orders elsewhere,
+    mesh_refinement.py:252-321), which a random assignment of orders to sections has not."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-0.9, 0.9, features)
+    widths = rng.uniform(0.02, 0.15, features)
+    depth = rng.uniform(0.6, 2.0, features)     # decades
+
+    def log10_ell(tau):
+        v = 0.35 * np.sin(2.1 * tau + rng_phase)
+        for c, w, d in zip(centres, widths, depth):
+            v = v - d * np.exp(-0.5 * ((tau - c) / w) ** 2)
+        return v
+    rng_phase = rng.uniform(0, 2 * np.pi)
+
+    def run(level):
+        sizes, nodes = np.full(K0, 1.0 / K0), np.full(K0, n0, dtype=np.int64)
+        for _ in range(max_iterations):
+            edges = -1.0 + 2.0 * np.concatenate([[0.0], np.cumsum(sizes)])
+            mid, h = 0.5 * (edges[1:] + edges[:-1]), np.diff(edges)
+            err = (h / 10.0 ** (level + log10_ell(mid))) ** nodes
+            sizes, nodes, met = next_phase_mesh(sizes, nodes, err, mesh_tol=mesh_tol)
+            if met or int(np.sum(nodes - 1)) + 1 > 4 * target_nodes:
+                break
+        return sizes, nodes, met
+
+    # the level of ell (log10) is scanned: the node count of the converged mesh falls with it, in jumps
+    best = None
+    for level in np.linspace(-3.5, 2.5, 145):
+        sizes, nodes, met = run(level)
+        N = int(np.sum(nodes - 1)) + 1
+        if met and (best is None or abs(N - target_nodes) < abs(best[2] - target_nodes)):
+            best = (sizes, nodes, N)
+    if best is None:
+        raise RuntimeError("no level of the synthetic error field gives a converged mesh")
+    return best[0], best[1]

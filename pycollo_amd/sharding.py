@@ -243,7 +243,20 @@ class SegmentExchange:
             self._copy_runs(buf, self.send, self.pack_tab)
         elif n:
             torch.index_select(buf, 0, self.idx_me, out=self.send[:n])
-        if rehearsal:
+        if rehearsal and unpadded:
+            # rehearsal of the all-gatherv: the same per-rank broadcasts at exact lengths, staged through the host
+            ml = self.maxlen
+            recv = torch.zeros(self.recv.shape, dtype=self.recv.dtype)
+            send = self.send.cpu()
+            for q in range(self.world):
+                nq = self.plan.lengths[q]
+                if nq:
+                    piece = recv[q * ml:q * ml + nq]
+                    if q == self.rank:
+                        piece.copy_(send[:nq])
+                    dist.broadcast(piece, src=dist.get_global_rank(self.group, q) if self.group is not None else q, group=self.group)
+            self.recv.copy_(recv)
+        elif rehearsal:
             # rehearsal only (several ranks sharing one GPU cannot form an RCCL group): stage through the host
             recv = torch.empty(self.recv.shape, dtype=self.recv.dtype)
             dist.all_gather_into_tensor(recv, self.send.cpu(), group=self.group)

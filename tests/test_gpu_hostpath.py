@@ -154,3 +154,38 @@ def test_cyipopt_object_survives_direct_engine_calls(built):
     eng.evaluate_c(x2)                                    # protocol callback at another point, by hand
     assert_matches_oracle(ora, x, c=p.constraints(x), G=p.jacobian(x))
     eng.close()
+
+
+def test_cyipopt_object_survives_device_api_calls(built):
+    """The device-pointer entry points (pc_eval_all_device, pc_launch_*) write the handle's own J / grad J block:
+    a callback that follows one of them at the point of the previous callback must be re-evaluated, not served from
+    the cache (engine.cache_holds is cleared by every device-API wrapper, the library clears its own flag too)."""
+    import torch
+    from pycollo_amd.engine import PycolloGpuProblem
+    prob = problems.cart_pole(K=30, order=4)
+    eng = _engine(prob)
+    ora = OracleNlp(prob, golden_tables("lobatto"), V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
+    p = PycolloGpuProblem(eng)
+    rng = np.random.default_rng(29)
+    x, x2 = rng.uniform(-0.4, 0.4, eng.num_x), rng.uniform(-0.4, 0.4, eng.num_x)
+    lam = rng.normal(size=eng.num_c)
+    dev = torch.device("cuda", 0)
+    dx2, dl = torch.from_numpy(x2).to(dev), torch.from_numpy(lam).to(dev)
+    dc = torch.empty(eng.num_c, dtype=torch.float64, device=dev)
+    dG = torch.empty(eng.nnz_jac, dtype=torch.float64, device=dev)
+    dH = torch.empty(eng.nnz_hess, dtype=torch.float64, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    assert abs(p.objective(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+    assert eng.cache_holds(x)
+    eng.evaluate_all_device(dx2, 1.0, dl, dc, dG, dH, s.cuda_stream)     # overwrites the handle's f block with J(x2)
+    s.synchronize()
+    assert not eng.cache_holds(x)
+    assert abs(p.objective(x) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+    assert_matches_oracle(ora, x, c=p.constraints(x), g=p.gradient(x))
+    # the library's own flag: a protocol call with new_x = 0 straight after a device-API launch re-evaluates as well
+    eng.evaluate_J(x, new_x=True)
+    step = eng.bind_device(dx2, dl, dc, dG, dH, s.cuda_stream)
+    step(1.0)
+    s.synchronize()
+    assert abs(eng.evaluate_J(x, new_x=False) - ora.J(x)) <= TOL * max(1.0, abs(ora.J(x)))
+    eng.close()

@@ -1,0 +1,43 @@
+"""GPU tests of the device-resident interior-point iteration (csrc/pc_ipm.hpp, ipm.ResidentInteriorPointSolver): the
+same algorithm as the host-vector loop over the same GPU factorisation (ipm.GpuInteriorPointSolver) -- same iteration
+counts, same iterates to 1e-9 -- and the reference's end-to-end objectives through it."""
+import numpy as np
+import pytest
+
+from pycollo_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _iteration(name, kw):
+    from pycollo_amd.iteration import MeshIteration
+    return MeshIteration(problems.REGISTRY[name](**kw), device=0)
+
+
+@pytest.mark.parametrize("name,kw", [("hypersensitive", dict(K=200, order=6)), ("cart_pole", dict(K=100, order=4)),
+                                     ("brachistochrone", {}), ("shuttle", dict(K=20, order=5)),
+                                     ("sliding_mass", dict(num_phases=2, K=10, order=4)), ("tumour_anti_angiogenesis", dict(K=10, order=6))])
+def test_same_iterates_as_the_host_vector_loop(built, name, kw):
+    a = _iteration(name, kw).solve_with_ipm(max_iter=300, tol=1e-8, linear_solver="gpu")
+    b = _iteration(name, kw).solve_with_ipm(max_iter=300, tol=1e-8, linear_solver="resident")
+    assert a.status == b.status == "optimal"
+    assert b.evaluations.get("resident_iteration") is True
+    assert a.iterations == b.iterations
+    scale = max(1.0, float(np.max(np.abs(a.x))))
+    assert np.max(np.abs(a.x - b.x)) <= 1e-9 * scale
+    assert abs(a.objective - b.objective) <= 1e-9 * max(1.0, abs(a.objective))
+    # the whole history: objective, primal and dual infeasibility per iteration
+    for (ia, fa, pa, da, ma), (ib, fb, pb, db, mb) in zip(a.history, b.history):
+        assert ia == ib and ma == mb
+        assert abs(fa - fb) <= 1e-8 * max(1.0, abs(fa))
+        assert abs(pa - pb) <= 1e-8 * max(1.0, pa) and abs(da - db) <= 1e-7 * max(1.0, da)
+
+
+def test_reference_objectives_through_the_resident_loop(built):
+    """tests/integration/test_hypersensitive_problem.py:129-130 and test_brachistochrone.py:159-160 of the reference."""
+    from pycollo_amd.solve import solve_ocp
+    res = solve_ocp(problems.hypersensitive(), linear_solver="resident")
+    assert res.mesh_tolerance_met
+    np.testing.assert_allclose(res.objective, 3.36206, rtol=1e-5)
+    res = solve_ocp(problems.brachistochrone(), linear_solver="resident")
+    np.testing.assert_allclose(res.objective, 0.82434, rtol=1e-4)
