@@ -722,6 +722,22 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       h->two_wave = h->two_wave && tiles64 > 400 && tiles64 <= max_tiles;
     }
     constexpr int kQuarterCu = 30 * 1280;
+    // A two-wave launch is one generation of waves and lasts one wave's life, which grows with the tile's rows (its
+    // share of the flush): the tile capacity is the one that cuts the mesh into about 896 tiles (3.5 workgroups per CU,
+    // 1 792 of the chip's 2 048 wave slots) when that is smaller than what the LDS allows.  Measured on one box, Delta III
+    // 4 x 12.5 k nodes, tiles / us: order 4  796 / 25.8, 928 / 22.3, 984 / 22.4;  order 5  896 / 23.2, 964 / 26.0;  order 6
+    // 836 / 32.1, 912 / 29.3, 1000 / 28.8;  order 7  836 / 31.4, 928 / 27.7;  order 8  796 / 35.7, 896 / 32.0, 1020 / 33.6
+    // (profiles/r04_two_wave_tiles.txt).  PYCOLLO_AMD_TWO_WAVE_TILES overrides the target (0: the largest tile the LDS allows).
+    auto fill_tc = [&](int tc_max) {
+      int64_t want = 896;
+      if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_TILES")) want = std::atoll(env);
+      if (want <= 0) return tc_max;
+      int64_t rows = 0;
+      for (auto& P : Q.ph)
+        for (int k = 0; k < P.K; ++k) rows += P.n_k[k] - 1;
+      const int per = (int)((rows + want - 1) / want);
+      return std::max(std::max(max_nk, 24), std::min(tc_max, per + 1));
+    };
     if (h->mixed) {
       // Mixed build: tiles are cut per order (pc_pattern.hpp::build_tiles_mixed) under row caps that keep a workgroup's
       // LDS inside the budget -- a quarter CU for the two-wave build (below), else what a workgroup may request -- and
@@ -757,11 +773,15 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
           return mx;
         };
         while (tc > std::max(max_nk, 32) && need_uniform(tc) > kQuarterCu) --tc;
-        TC = tc;
-        const int64_t tiles = cut(2, kQuarterCu);
         int64_t max_waves = 2048;   // every wave of the launch resident at once (two per SIMD)
         if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_MAX_WAVES")) max_waves = std::atoll(env);
-        if (need_uniform(tc) > kQuarterCu || 2 * tiles > max_waves) {
+        // the smallest tile capacity from the chip-filling one upwards whose cut keeps every wave resident
+        bool fits = false;
+        for (int t = std::min(tc, fill_tc(tc)); t <= tc && !fits; ++t) {
+          TC = t;
+          fits = need_uniform(t) <= kQuarterCu && 2 * cut(2, kQuarterCu) <= max_waves;
+        }
+        if (!fits) {
           h->two_wave = false;
           TC = TB;
         }
@@ -775,15 +795,21 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       // ... and every wave of the launch resident at once (2048 wave slots at two per SIMD): with smaller tiles than
       // that allows, the one-wave-per-tile kernel -- itself two waves per SIMD -- is as fast or faster (Delta III order 6:
       // 1160 tiles of 45 nodes x 2 waves 34.0 us, 872 tiles x 1 wave 32.2 us; 4 x 25 k nodes, order 5: 42.7 / 42.2 us)
-      int64_t tiles_tc = 0;
-      for (auto& P : Q.ph) {
-        int64_t N = 1, nmax = 2;
-        for (int k = 0; k < P.K; ++k) { N += P.n_k[k] - 1; nmax = std::max<int64_t>(nmax, P.n_k[k]); }
-        const int64_t per_tile = std::max<int64_t>(1, ((tc - 1) / (nmax - 1)) * (nmax - 1));
-        tiles_tc += (N - 1 + per_tile - 1) / per_tile;
-      }
-      if (lds_need(64, tc, 2) <= kQuarterCu && 2 * tiles_tc <= 2048) TC = tc;
-      else h->two_wave = false;
+      auto tiles_at = [&](int t) {
+        int64_t tiles_tc = 0;
+        for (auto& P : Q.ph) {
+          int64_t N = 1, nmax = 2;
+          for (int k = 0; k < P.K; ++k) { N += P.n_k[k] - 1; nmax = std::max<int64_t>(nmax, P.n_k[k]); }
+          const int64_t per_tile = std::max<int64_t>(1, ((t - 1) / (nmax - 1)) * (nmax - 1));
+          tiles_tc += (N - 1 + per_tile - 1) / per_tile;
+        }
+        return tiles_tc;
+      };
+      bool fits = false;
+      if (lds_need(64, tc, 2) <= kQuarterCu)
+        for (int t = std::min(tc, fill_tc(tc)); t <= tc && !fits; ++t)
+          if (2 * tiles_at(t) <= 2048) { TC = t; fits = true; }
+      if (!fits) h->two_wave = false;
     }
     if (const char* env = std::getenv("PYCOLLO_AMD_TILE_NODES")) {
       const int v = std::atoi(env);

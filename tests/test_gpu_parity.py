@@ -284,7 +284,10 @@ def _ph_refined(prob, K, seed=7, lo=4, hi=9):
 def _full_problem(name, kw):
     kw = dict(kw)
     refined = kw.pop("refined", False)
+    ph_nodes = kw.pop("ph_nodes", 0)
     prob = problems.REGISTRY[name](**kw)
+    if ph_nodes:   # the ph rule iterated on a synthetic error field: orders in runs -> the mixed build (tests/test_gpu_mixed.py)
+        return problems.with_refined_mesh(prob, ph_nodes)
     return _ph_refined(prob, kw["K"]) if refined else prob
 
 
@@ -293,7 +296,8 @@ def _full_problem(name, kw):
 # (4 x 2500 sections of 4..8 nodes, ~50 k nodes: the any-order kernels)
 FULL = [("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=5000, order=4)),
         ("shuttle", dict(K=20000, order=4)), ("delta_iii", dict(K=3125, order=5)),
-        ("delta_iii", dict(K=2500, order=4, refined=True))]
+        ("delta_iii", dict(K=2500, order=4, refined=True)),      # orders 4..8 at random, section by section: any-order kernels
+        ("delta_iii", dict(ph_nodes=12500))]                      # a mesh as the ph rule leaves it, ~50 k nodes: the mixed build
 
 
 @pytest.mark.parametrize("name,kw", FULL)
@@ -305,6 +309,10 @@ def test_full_size_properties(built, tab, name, kw):
     eng = _engine(prob)
     if name == "delta_iii":
         assert sum(pl.N for pl in eng.layout.phases) > 49000
+    if "ph_nodes" in kw:
+        assert all(eng.mixed) and eng.info["waves_per_tile"] == 2      # mixed build, two waves per tile
+        od = np.concatenate([eng.phase_tile_orders(p) for p in range(len(prob.phases))])
+        assert np.mean(od > 0) > 0.85
     ora = OracleNlp(prob, tab, V_ocp=eng.V_ocp, r_ocp=eng.r_ocp, W_ocp=eng.W_ocp, w_J=1.0)
     rng = np.random.default_rng(1234)
     lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)   # keep |r| away from 0 for mu/r^3
@@ -344,7 +352,8 @@ def test_full_size_properties(built, tab, name, kw):
                                            ("delta_iii", dict(K=40, order=4), 2),
                                            ("shuttle", dict(K=20000, order=4), 8),              # config 4 as BASELINE shards it
                                            ("delta_iii", dict(K=3125, order=5), 8),             # config 5, uniform mesh
-                                           ("delta_iii", dict(K=2500, order=4, refined=True), 8)])   # config 5, ph-refined
+                                           ("delta_iii", dict(K=2500, order=4, refined=True), 8),    # config 5, random orders
+                                           ("delta_iii", dict(ph_nodes=12500), 8)])                  # config 5, ph-refined: mixed build
 def test_sharded_ranks_reassemble_bitwise(built, name, kw, world):
     """Emulate `world` ranks on one GPU: each rank's bulk kernels run over its tile range into a NaN-filled
     buffer, the plan's segments are merged (what the all-gather + unpack do), the tail runs on the merged

@@ -83,10 +83,14 @@ def test_generated_source_is_straight_line_fp64():
     assert "pc_bulk_p0_r_w2(" in src and "pc_bulk_p0_r_w4(" in src
 
 
-@pytest.mark.parametrize("name,kw,orders", [("hypersensitive", dict(K=10, order=6), (6,)), ("cart_pole", dict(K=10, order=4), (4,)),
-                                            ("two_phase_transfer", {}, (0, 0)), ("time_coupled_transfer", {}, (3, 4)), ("double_pendulum", {}, (4,)),
-                                            ("delta_iii", dict(K=10, order=5), (5, 5, 5, 5))])
-def test_kernels_use_no_scratch_memory(name, kw, orders):
+@pytest.mark.parametrize("name,kw,orders,mixed", [
+    ("hypersensitive", dict(K=10, order=6), (6,), None), ("cart_pole", dict(K=10, order=4), (4,), None),
+    ("two_phase_transfer", {}, (0, 0), None), ("time_coupled_transfer", {}, (3, 4), None), ("double_pendulum", {}, (4,), None),
+    ("delta_iii", dict(K=10, order=5), (5, 5, 5, 5), None),
+    # mixed builds (a body per listed order next to the any-order one in every launch kernel: up to twelve bodies)
+    ("hypersensitive", {}, (0,), ((4, 6),)), ("shuttle", {}, (0,), ((4, 6),)), ("two_phase_transfer", {}, (0, 0), ((4, 6), (4, 6))),
+    ("delta_iii", {}, (0, 0, 0, 0), ((4, 6),) * 4)])
+def test_kernels_use_no_scratch_memory(name, kw, orders, mixed):
     """A run-time subscript into a register array sends the array -- and with it the dispatch -- to scratch memory
     (it cost the resident-tail kernel 2.5 us of a 4.6 us evaluation before it was found; hundreds of bytes per lane):
     every bulk / tail kernel of the headline models must compile to zero scratch bytes.  One deliberate exception: a
@@ -95,7 +99,7 @@ def test_kernels_use_no_scratch_memory(name, kw, orders):
     from pycollo_amd import codegen, problems
     from pycollo_amd.model import compile_model
     model = compile_model(problems.REGISTRY[name](**kw))
-    res = codegen.code_object_resources(codegen.build_code_object(model, orders))   # what the compiler reported at build time
+    res = codegen.code_object_resources(codegen.build_code_object(model, orders, mixed=mixed))   # what the compiler reported at build time
     assert any(k.endswith("_r") for k in res), sorted(res)
     heavy = any(codegen.is_heavy(pm) for pm in model.phases)
     capped = res.get("_build", {}).get("heavy_cap", False)
@@ -105,7 +109,7 @@ def test_kernels_use_no_scratch_memory(name, kw, orders):
             assert r["scratch"] == 0, (kern, r)
         elif kern.startswith("pc_bulk"):
             assert r["scratch"] <= codegen.HEAVY_SCRATCH_LIMIT and r["occupancy"] >= 2, (kern, r)
-    if name == "delta_iii":   # the two-wave launch kernel of config 5's uniform mesh fits without spilling at all
+    if name == "delta_iii" and mixed is None:   # the two-wave launch kernel of config 5's uniform mesh fits without spilling at all
         assert res["pc_bulk_all_r_w2"]["scratch"] == 0 and res["pc_bulk_all_r_w2"]["vgprs"] <= 256
 
 

@@ -29,7 +29,9 @@ if [ "$PART" = all ] || [ "$PART" = 2 ]; then
 run delta_iii12k --problem delta_iii --sections 3125 --order 5 --steps 100 --warmup 10 &&
 run delta_iii12k_n4 --problem delta_iii --sections 4167 --order 4 --steps 100 --warmup 10 &&
 run delta_iii50k --problem delta_iii --sections 12500 --order 5 --steps 50 --warmup 10 &&
-run delta_iii_ragged50k --problem delta_iii --sections 2500 --ragged --steps 50 --warmup 10 ;
+run delta_iii_ragged50k --problem delta_iii --sections 2500 --ragged --steps 50 --warmup 10 &&
+run delta_iii_refined50k --problem delta_iii --refined 12500 --steps 50 --warmup 10 &&
+run delta_iii12k_n8 --problem delta_iii --sections 1785 --order 8 --steps 100 --warmup 10 ;
 fi
 if [ "$PART" = 3 ]; then
 run space_station6k --problem space_station --sections 2000 --order 4 --steps 300 --warmup 30 ;
