@@ -95,18 +95,20 @@ inline int phase_max_row_len(const pcp::Phase& P, int n) {
 }
 // staging doubles of the defect-Jacobian block of `rows` rows of n-node sections in a body compiled for that order:
 // the body stages it in row groups (pc_args.h::pc_row_passes), a piece of every section at a time
-inline int order_body_defect_out(const pcp::Phase& P, int rows, int n) {
+inline int order_body_defect_out(const pcp::Phase& P, int rows, int n, bool row_groups = true) {
+  if (!row_groups) return rows * phase_max_row_len(P, n);
   const int nq = (rows + n - 2) / (n - 1);
   return nq * pc_row_group(n, phase_max_row_len(P, n)) * phase_max_row_len(P, n);
 }
 // doubles of the output staging buffer of one phase: the longest CSR run a tile emits in one piece, for tiles of at
 // most `rows` defect rows per state and `nodes` nodes
-inline int phase_lds_out(const pcp::Phase& P, int rows, int nodes) {
+// (row_groups = false: the four-wave per-replica kernels stage a state's block in one piece, pc::bulk NPASS)
+inline int phase_lds_out(const pcp::Phase& P, int rows, int nodes, bool row_groups = true) {
   int nmax = 0;
   for (int k = 0; k < P.K; ++k) nmax = std::max(nmax, (int)P.n_k[k]);
   int out = 0;
   if (P.compiled_order > 0) {
-    out = order_body_defect_out(P, rows, P.compiled_order);
+    out = order_body_defect_out(P, rows, P.compiled_order, row_groups);
   } else {
     for (int a = 0; a < P.n_y; ++a) out = std::max(out, phase_row_len(P, a, nmax) * rows);
   }
@@ -119,13 +121,13 @@ inline int phase_lds_out(const pcp::Phase& P, int rows, int nodes) {
   return out;
 }
 // the same for one actual tile, sections [ka, kb): every row counted with its own section's order
-inline int tile_lds_out(const pcp::Phase& P, int ka, int kb, int order = 0) {
+inline int tile_lds_out(const pcp::Phase& P, int ka, int kb, int order = 0, bool row_groups = true) {
   int rows = 0;
   for (int k = ka; k < kb; ++k) rows += P.n_k[k] - 1;
   const int nodes = rows + 1;
   int out = 0;
   if (order > 0) {   // order-pure tile run by the body of its order: staged in row groups
-    out = order_body_defect_out(P, rows, order);
+    out = order_body_defect_out(P, rows, order, row_groups);
   } else {
     for (int a = 0; a < P.n_y; ++a) {
       int len = 0;
@@ -142,11 +144,11 @@ inline int tile_lds_out(const pcp::Phase& P, int ka, int kb, int order = 0) {
   return out;
 }
 // mixed build: staging doubles of the phase's largest tile, and which kinds of tile body the phase's tiles run
-inline int phase_lds_out_tiles(const pcp::Phase& P, bool* any_pure = nullptr, bool* any_generic = nullptr) {
+inline int phase_lds_out_tiles(const pcp::Phase& P, bool* any_pure = nullptr, bool* any_generic = nullptr, bool row_groups = true) {
   int out = 0;
   for (size_t i = 0; i + 1 < P.tile_k0.size(); ++i) {
     const bool pure = i < P.tile_order.size() && P.tile_order[i] > 0;
-    out = std::max(out, tile_lds_out(P, P.tile_k0[i], P.tile_k0[i + 1], pure ? P.tile_order[i] : 0));
+    out = std::max(out, tile_lds_out(P, P.tile_k0[i], P.tile_k0[i + 1], pure ? P.tile_order[i] : 0, row_groups));
     if (any_pure && pure) *any_pure = true;
     if (any_generic && !pure) *any_generic = true;
   }

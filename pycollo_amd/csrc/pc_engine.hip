@@ -84,6 +84,7 @@ struct PhaseDev {
   DevBuf<unsigned long long> gran;   // resident tail: the per-tile partial sums as granules, [n_tiles][nred][2]
   int32_t erec0 = 0;                 // resident tail: first record of this phase's edge-node Hessian entries
   int uni_n = 0, spt = 0, lds_out = 0;
+  int lds_out4 = 0;                  // staging doubles per replica of a four-wave launch (one pass per state: pc::bulk NPASS)
   int wpt = 1;                       // waves (replicas) per 64-node tile, see pc::bulk
   hipFunction_t fn = nullptr;
   hipFunction_t fn_res = nullptr;    // single-phase problems: bulk kernel with the resident tail as block 0
@@ -306,7 +307,7 @@ void fill_phase_args(pc_handle* h, size_t ip, PcPhaseArgs& a, const double* d_x,
   for (size_t i = 0; i < P.hoff.size(); ++i) a.hoff[i] = P.hoff[i];
   a.uni_n = D.uni_n;
   a.spt = D.spt;
-  a.lds_out = D.lds_out;
+  a.lds_out = wpt == 4 ? D.lds_out4 : D.lds_out;
   a.wpt = wpt;
   a.hslot0 = D.hslot0.p;
   a.hslotN = D.hslotN.p;
@@ -883,17 +884,20 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         throw std::runtime_error("internal error: uniform tiling mismatch");
       D.lds_out = phase_lds_out(P, phase_max_tile_rows(P), std::min(TC, phase_max_tile_rows(P) + 1));   // the largest tile's runs
       bool any_pure = false, any_generic = false;
-      if (!P.spec_orders.empty()) D.lds_out = phase_lds_out_tiles(P, &any_pure, &any_generic);   // every row with its own order
+      D.lds_out4 = phase_lds_out(P, phase_max_tile_rows(P), std::min(TC, phase_max_tile_rows(P) + 1), false);
+      if (!P.spec_orders.empty()) {   // every row with its own order
+        D.lds_out = phase_lds_out_tiles(P, &any_pure, &any_generic);
+        D.lds_out4 = phase_lds_out_tiles(P, nullptr, nullptr, false);
+      }
       // LDS of the phase's workgroups with w staging regions: the larger of the tile bodies the phase's tiles run
       D.lds_for = [&P, &D, TB, qa_n, qw_n, mesh_tables, any_pure, any_generic](int w) {
-        if (P.spec_orders.empty()) return phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, mesh_tables);
+        const int out = (w == 4 ? D.lds_out4 : D.lds_out) * w;
+        if (P.spec_orders.empty()) return phase_lds_bytes(P, TB, qa_n, qw_n, out, mesh_tables);
         int b = 0;
-        if (any_generic) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, true, true));
-        if (any_pure) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, D.lds_out * w, false, true));
+        if (any_generic) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, out, true, true));
+        if (any_pure) b = std::max(b, phase_lds_bytes(P, TB, qa_n, qw_n, out, false, true));
         return b;
       };
-      if (const char* env = std::getenv("PYCOLLO_AMD_LDS_ROWS_EXTRA"))   // experiments: staging sized for that many more rows
-        D.lds_out = phase_lds_out(P, phase_max_tile_rows(P) + std::atoi(env), std::min(TC, phase_max_tile_rows(P) + 1));
       // Few tiles and several states: W waves share a tile and split its output runs, so that the chip's 1024
       // SIMDs each hold a wave (or two) instead of a fraction of them holding one long-running wave.  Beyond that
       // the replicas only add redundant node evaluations (measured on 64-node tiles, W = 1 / 2 / 4: shuttle

@@ -256,8 +256,7 @@ inline unsigned ipm_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std:
 // the scalars of the last reduction, on the host (one copy, one wait)
 void ipm_fetch(pc_ipm* s, int count, double* out) {
   HIP_OK(hipMemcpyAsync(s->h_red.p, s->red.p, count * sizeof(double), hipMemcpyDeviceToHost, s->h->stream));
-  HIP_OK(hipStreamSynchronize(s->h->stream));
-  check_timeout(s->h);
+  wait_stream(s->h);   // (polls before it blocks; reports a resident tail that gave up)
   for (int i = 0; i < count; ++i) out[i] = s->h_red.p[i];
 }
 

@@ -1441,7 +1441,10 @@ __device__ __forceinline__ void bulk(const PcPhaseArgs& KA, bool MULTI = false, 
       for (int a = 0; a < NY; ++a) m = St::D(a) * (UN > 0 ? UN : 0) + St::C(a) > m ? St::D(a) * (UN > 0 ? UN : 0) + St::C(a) : m;
       return m;
     }();
-    constexpr int NPASS = UN > 0 ? pc_row_passes(UN, RSTRIDE_MAX) : 1;
+    // (not in the four-wave per-replica kernels: four waves share a tile only on meshes of a few hundred tiles, where
+    //  every wave has a SIMD to itself whatever the LDS footprint, and the passes only cost -- space station 6 k nodes,
+    //  96 tiles x 4 waves: 17.5 us in one pass, 22.1 us in two)
+    constexpr int NPASS = (UN > 0 && WN != 4) ? pc_row_passes(UN, RSTRIDE_MAX) : 1;
     constexpr int RG = UN > 0 ? (UN - 1 + NPASS - 1) / NPASS : 0;
     auto defect_jacobian_of_state = [&](auto a_) {
       constexpr int a = decltype(a_)::value;

@@ -10,7 +10,10 @@
 // by the tables, two factorisations of the same matrix give the same bits.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -834,9 +837,30 @@ struct pc_kkt {
   Pin<double> h_a, h_b;      // two vectors in, or one in and one out
   KArgs args{};
   bool factored = false;
+  // a refined solve stops once ||rhs - K x||_2 <= resid_tol ||rhs||_2 (IPOPT: residual_ratio_max = 1e-10 on its own ratio).
+  // Config 2, per interior-point iteration: no test 1.40 ms and 3.9 back-substitutions, 1e-12 1.03 ms with the objective
+  // unchanged in all ten printed digits, 1e-11 1.06 ms (objective moves in the 8th digit), 1e-9 0.95 ms
+  // (profiles/r04_ipm_iter_time.txt)
+  double resid_tol = 1e-12;
 };
 
+// Wait for the stream by polling first: a blocking wait costs an interrupt and a wake-up (10-20 us on the MI355X host),
+// and an interior-point iteration makes four or five of them (pivot counts, residual norms)
+static void kwait(hipStream_t st) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) KHIP(e);
+    if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) break;
+  }
+  KHIP(hipStreamSynchronize(st));
+}
+
 // the solve chain on the handle's stream, device vectors in natural order (d_rhs is not modified; d_x may alias it)
+// (A HIP graph of this string of ~25 launches -- and of the factorisation's ~15 -- was built and measured in round 4:
+//  the interior-point iteration got slower, 1.29 -> 1.39 ms at config 2: the launches are not what it waits for, the
+//  level kernels' own latency is; profiles/r04_ipm_iter_time.txt.  Removed.)
 static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
@@ -945,9 +969,10 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     }
     k->mv_coef.upload(d->mv_coef, d->n_mv);
     for (auto* w : {&k->w_rhs, &k->w_sol, &k->w_res, &k->w_trial, &k->w_dx, &k->w_dvec}) w->alloc((size_t)d->nu);
-    k->w_part.alloc(2 * 256);
-    k->w_norm.alloc(2);
-    k->h_norm.alloc(2);
+    k->w_part.alloc(4 * 256);
+    k->w_norm.alloc(4);
+    k->h_norm.alloc(4);
+    if (const char* env = std::getenv("PYCOLLO_AMD_KKT_RESID_TOL")) k->resid_tol = std::atof(env);
     // derived tables
     std::vector<uint8_t> last(d->n_chain, 0);
     for (int64_t p = 0; p < d->n_phase; ++p) last[d->chain_phase_ptr[p + 1] - 1] = 1;
@@ -1211,6 +1236,7 @@ int pc_kkt_plan_entries(const pc_kkt_plan* P, int64_t n, int64_t nv, int64_t nH,
 void pc_kkt_destroy(pc_kkt* k) {
   if (!k) return;
   (void)hipSetDevice(k->device);
+
   if (k->stream) {
     (void)hipStreamSynchronize(k->stream);
     (void)hipStreamSynchronize(k->stream);
@@ -1243,7 +1269,7 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
     hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     KHIP(hipMemcpyAsync(k->h_counts.p, k->counts.p, k->h_counts.n * sizeof(int), hipMemcpyDeviceToHost, st));
-    KHIP(hipStreamSynchronize(st));
+    kwait(st);
     int64_t p = 0, q = 0;
     for (size_t i = 0; i < k->h_counts.n; i += 2) {
       p += k->h_counts.p[i];
@@ -1338,7 +1364,7 @@ static double* solve_refined_device(pc_kkt* k, int use_hess, const double* d_dve
       hipLaunchKernelGGL(kkt_norm_partial, dim3(nred), dim3(256), 0, st, d_r, d_t, k->w_part.p, nu);
       hipLaunchKernelGGL(kkt_norm_final, dim3(1), dim3(64), 0, st, k->w_part.p, nred, k->w_norm.p);
       KHIP(hipMemcpyAsync(k->h_norm.p, k->w_norm.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-      KHIP(hipStreamSynchronize(st));
+      kwait(st);
       sumsq = k->h_norm.p[0];
       bad = k->h_norm.p[1];
     };
@@ -1349,9 +1375,21 @@ static double* solve_refined_device(pc_kkt* k, int use_hess, const double* d_dve
     solve_device(k, d_rhs, sol);
     matvec_device<1>(k, use_hess, d_dvec, sol, d_rhs, res);
     int solves = 1;
-    double nres = 0.0, bad = 0.0;
-    if (max_steps > 0) norms(res, sol, nres, bad);
+    double nres = 0.0, bad = 0.0, nrhs = 0.0;
+    if (max_steps > 0) {   // ||rhs||^2 rides in the same wait as the first residual's norm
+      hipLaunchKernelGGL(kkt_norm_partial, dim3(nred), dim3(256), 0, st, d_rhs, d_rhs, k->w_part.p + 2 * 256, nu);
+      hipLaunchKernelGGL(kkt_norm_final, dim3(1), dim3(64), 0, st, k->w_part.p + 2 * 256, nred, k->w_norm.p + 2);
+      hipLaunchKernelGGL(kkt_norm_partial, dim3(nred), dim3(256), 0, st, res, sol, k->w_part.p, nu);
+      hipLaunchKernelGGL(kkt_norm_final, dim3(1), dim3(64), 0, st, k->w_part.p, nred, k->w_norm.p);
+      KHIP(hipMemcpyAsync(k->h_norm.p, k->w_norm.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+      kwait(st);
+      nres = k->h_norm.p[0];
+      bad = k->h_norm.p[1];
+      nrhs = k->h_norm.p[2];
+    }
+    const double stop2 = k->resid_tol * k->resid_tol * nrhs;   // (NaN or 0 right-hand side: never true, the loop below decides)
     for (int it = 0; it < max_steps; ++it) {
+      if (nres <= stop2) break;                                 // already as accurate as a correction could make it matter
       solve_device(k, res, k->vout.p);
       hipLaunchKernelGGL(kkt_add, dim3(nbk), dim3(256), 0, st, sol, k->vout.p, trial, nu);
       matvec_device<1>(k, use_hess, d_dvec, trial, d_rhs, res_t);

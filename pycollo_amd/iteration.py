@@ -130,11 +130,12 @@ class MeshIteration:
         return ((xb[:, 0] - self.r) / self.V, (xb[:, 1] - self.r) / self.V, W * cb[:, 0], W * cb[:, 1])
 
     # ---- solve -------------------------------------------------------------------------------------
-    def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0, linear_solver: str = "gpu",
+    def solve_with_ipm(self, max_iter: int = 500, tol: float = 1e-8, verbose: int = 0, linear_solver: str = "resident",
                        warm_start: bool = False, host_retry: bool = False):
         """Solve the scaled NLP with the interior-point stand-in for IPOPT (``pycollo_amd.ipm``), driven through
         the cyipopt-protocol object exactly as ``ipopt.problem(...).solve(x0)`` would be (pycollo/nlp.py:84-115).
-        ``linear_solver``: "gpu" -- the KKT systems are assembled from device-resident G~ / H~ and factorised on the
+        ``linear_solver``: "resident" (default) -- as "gpu", and the iteration's vectors stay on the device too
+        (``ipm.ResidentInteriorPointSolver``, csrc/pc_ipm.hpp); "gpu" -- the KKT systems are assembled from device-resident G~ / H~ and factorised on the
         GPU (``pycollo_amd.kkt``; the role of IPOPT's ``linear_solver`` option, pycollo/backend.py:1703-1711);
         "host" -- the callbacks deliver host arrays and SuperLU factorises (what a host-side IPOPT would do).
         ``warm_start``: pycollo's setting of that name (settings.py:228, backend.py:1703-1709).

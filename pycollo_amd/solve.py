@@ -33,7 +33,7 @@ class OcpResult:
 
 def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float = MESH_TOLERANCE, device: int = 0,
               nlp_tol: float = 1e-10, nlp_max_iter: int = 2000, verbose: int = 0, update_scaling: bool = False,
-              scaling_weight: float = 0.8, linear_solver: str = "gpu", warm_start: bool = False,
+              scaling_weight: float = 0.8, linear_solver: str = "resident", warm_start: bool = False,
               host_retry: bool = False) -> OcpResult:
     """Solve ``problem`` (a :class:`pycollo_amd.problem.ProblemSpec`) on its initial mesh, refine, repeat.
     ``nlp_tol`` / ``nlp_max_iter``: the reference's defaults (pycollo/settings.py:60-61: 1e-10, 2000) -- with 1e-8 the tumour
@@ -42,6 +42,8 @@ def solve_ocp(problem, *, max_mesh_iterations: int = 10, mesh_tolerance: float =
     ``warm_start``: pycollo/settings.py:228 (IPOPT's ``warm_start_init_point``, every mesh iteration);
     ``host_retry``: repeat a GPU-factorised NLP solve that did not succeed with the host factorisation (off: a failed
     solve ends the loop and the result says so)."""
+    import os
+    linear_solver = os.environ.get("PYCOLLO_AMD_LINEAR_SOLVER", linear_solver)   # (A/B knob: "gpu" | "resident" | "host")
     prob = copy.deepcopy(problem)
     prev = None
     log = []

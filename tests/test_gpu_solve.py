@@ -111,7 +111,7 @@ def test_time_scaled_transfer_solution(built):
     variable (pycollo/backend.py:1526-1539 keeps both global inside f, p, g), solved end to end on both linear-algebra
     paths: analytic optimum J = 2 sqrt(12), tF = sqrt(12) (problems.time_scaled_transfer)."""
     from pycollo_amd.solve import solve_ocp
-    for ls in ("gpu", "host"):
+    for ls in ("resident", "gpu", "host"):
         res = solve_ocp(problems.time_scaled_transfer(), mesh_tolerance=1e-7, linear_solver=ls)
         np.testing.assert_allclose(res.objective, 2.0 * np.sqrt(12.0), rtol=1e-7)
         assert res.mesh_tolerance_met is True

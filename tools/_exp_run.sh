@@ -1,9 +1,5 @@
-source tools/r4_exp.sh
-: > $out
-for n in 4 6 7 8; do
-  K=$(( 12500 / (n - 1) ))
-  for T in 896 960 1024; do
-  run "PYCOLLO_AMD_TWO_WAVE_TILES=$T" "d3 n$n tiles=$T" --problem delta_iii --sections $K --order $n --steps 200 --warmup 30
-  done
+for tol in 0 1e-12 1e-11 1e-9; do
+echo "== PYCOLLO_AMD_KKT_RESID_TOL=$tol"
+PYCOLLO_AMD_KKT_RESID_TOL=$tol python tools/ipm_resident_time.py hypersensitive 2000 6 resident 2>&1 | grep -v amdgpu.ids | tail -1
+PYCOLLO_AMD_KKT_RESID_TOL=$tol python tools/ipm_resident_time.py cart_pole 5000 4 resident 2>&1 | grep -v amdgpu.ids | tail -1
 done
-cat $out

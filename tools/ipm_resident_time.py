@@ -1,7 +1,7 @@
 """Wall time per interior-point iteration: the host-vector loop over the GPU factorisation ("gpu") against the
 device-resident iteration ("resident"), same NLP, same iterates.
 
-    python tools/ipm_resident_time.py [problem] [K] [order]"""
+    python tools/ipm_resident_time.py [problem] [K] [order] [gpu,resident]"""
 import os
 import sys
 import time
@@ -13,7 +13,8 @@ from pycollo_amd.iteration import MeshIteration  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "hypersensitive"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-for ls in ("gpu", "resident"):
+modes = sys.argv[4].split(",") if len(sys.argv) > 4 else ["gpu", "resident"]
+for ls in modes:
     MeshIteration(problems.REGISTRY[name](K=K, order=order), device=0).solve_with_ipm(max_iter=3, tol=1e-8, linear_solver=ls)   # warm-up
     for rep in range(2):
         it = MeshIteration(problems.REGISTRY[name](K=K, order=order), device=0)
