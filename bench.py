@@ -85,6 +85,57 @@ def host_leg(eng, x_np, lam_np, n_calls: int):
             "by_mode": by_mode}
 
 
+def host_by_config(local_rank, no_cpu):
+    """what a host-resident (serial) solver sees beyond config 2 -- the fused callback from host
+    pointers (pc_eval_all: x~, lambda in host memory, c~, G~, H~ delivered to host memory, synchronous; best data-movement
+    mode, in-place pinned blocks) at BASELINE.json configs[2] and configs[3], with the CPU port on one thread and on the
+    container's CPU quota beside it.  At these sizes the call is the bus: 6.8 MB / 82 MB of results per evaluation."""
+    import numpy as np
+    from pycollo_amd import problems
+    from pycollo_amd.engine import NlpEngine
+    out = []
+    for label, name, K, order in (("config 3: cart-pole, 5000 sections x 4 nodes", "cart_pole", 5000, 4),
+                                  ("config 4: shuttle, 20000 sections x 4 nodes", "shuttle", 20000, 4)):
+        eng = NlpEngine(problems.REGISTRY[name](K=K, order=order), device=local_rank)
+        x = np.random.default_rng(1234).uniform(-0.45, 0.45, eng.num_x)
+        lam = np.random.default_rng(1235).normal(size=eng.num_c)
+        hx, hl, _, _, _ = eng.host_buffers()
+        best = None
+        for mode in (0, 3):      # DMA both ways / the kernels read and write the pinned host blocks
+            eng.set_host_mode(mode)
+            hx[:] = x
+            hl[:] = lam
+            for _ in range(5):
+                eng.evaluate_all_inplace(1.0)
+            n = 200 if name == "cart_pole" else 40
+            ts = np.empty(n)
+            for i in range(n):
+                t0 = time.perf_counter()
+                eng.evaluate_all_inplace(1.0)
+                ts[i] = time.perf_counter() - t0
+            med = float(np.median(ts) * 1e6)
+            if best is None or med < best[0]:
+                best = (med, float(np.percentile(ts, 95) * 1e6), mode)
+        eng.set_host_mode(0)
+        entry = {"workload": label, "nodes": int(eng.layout.phases[0].N), "result_bytes": int(8 * (eng.num_c + eng.nnz_jac + eng.nnz_hess)),
+                 "host_pointer_median_us": round(best[0], 1), "host_pointer_p95_us": round(best[1], 1), "host_mode": best[2],
+                 "host_pointer_evals_per_s": round(1e6 / best[0], 1), "bus_GBs": round(8 * (eng.num_c + eng.nnz_jac + eng.nnz_hess) / best[0] / 1e3, 1)}
+        eng.close()
+        if not no_cpu:
+            try:
+                from oracle import cport
+                cb = cport.time_problem(name, K, order, 6.0)
+                entry["cpu_port_evals_per_s"] = cb["by_threads"]
+                one = cb["by_threads"]["1"]
+                bestc = max(cb["by_threads"].values())
+                entry["host_pointer_vs_1_thread"] = round(entry["host_pointer_evals_per_s"] / one, 1)
+                entry["host_pointer_vs_best_threads"] = round(entry["host_pointer_evals_per_s"] / bestc, 1)
+            except Exception as exc:   # noqa: BLE001 -- the baseline is reported, never required
+                entry["cpu_port_evals_per_s"] = f"unavailable: {exc}"[:200]
+        out.append(entry)
+    return out
+
+
 def sharded_config_lines(world, rank, local_rank, dev, tstream, args):
     """BASELINE.json configs[3] and configs[4] -- the configurations the north_star shards -- on the same N ranks, beside
     the headline line: whole-NLP evaluations per second (strong scaling: the mesh is fixed), the time of the exchange
@@ -165,6 +216,7 @@ def main():
                     help="compile the code object this command needs and exit without touching the GPU (run this, "
                          "unprofiled, before any rocprofv3 pass: no compiler may be spawned under the profiler)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-pointer (pc_eval_all) timing leg")
+    ap.add_argument("--no-host-configs", action="store_true", help="skip the host-pointer lines of configs 3 and 4 (host_by_config)")
     ap.add_argument("--host-calls", type=int, default=2000, help="timed host-pointer calls per variant (>= 1000)")
     ap.add_argument("--no-pin", action="store_true", help="leave the launching thread to the scheduler")
     ap.add_argument("--ragged", action="store_true", help="ph-refined style mesh: random section sizes, orders 4..8")
@@ -471,6 +523,12 @@ def main():
         if host is not None:
             out["host_ms_per_step"] = round(host["median_us"] * 1e-3, 6)
             out["host"] = host
+        default_workload = args.problem == "hypersensitive" and args.sections == 2000 and args.order == 6 and not (args.ragged or args.refined or args.generic)
+        if world == 1 and not args.no_host and not args.no_host_configs and default_workload:
+            if full_mask:
+                from pycollo_amd.hostpin import restore_affinity
+                restore_affinity(full_mask)
+            out["host_by_config"] = host_by_config(local_rank, args.no_cpu)
         if world == 1 and not args.no_cpu:
             if full_mask:
                 from pycollo_amd.hostpin import restore_affinity

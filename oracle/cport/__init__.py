@@ -265,6 +265,8 @@ def build_all():
     from pycollo_amd import problems
     from pycollo_amd.quadrature import QuadratureTables
     cp = CPort(problems.hypersensitive(K=4, order=6), QuadratureTables("lobatto"))
+    for name in ("cart_pole", "shuttle"):      # bench.py's host_by_config (BASELINE.json configs[2], configs[3])
+        CPort(problems.REGISTRY[name](K=4, order=4), QuadratureTables("lobatto"))
     return cp.lib._name
 
 
@@ -307,11 +309,11 @@ def host_cpu_facts() -> dict:
     return facts
 
 
-def _sweep(K: int, order: int, budget_s: float, counts: list) -> dict:
+def _sweep(K: int, order: int, budget_s: float, counts: list, problem: str = "hypersensitive") -> dict:
     """Times cp_eval_all at each thread count of ``counts`` in THIS process (libgomp reads OMP_* once, at start-up)."""
     from pycollo_amd import problems
     from pycollo_amd.quadrature import QuadratureTables
-    cp = CPort(problems.hypersensitive(K=K, order=order), QuadratureTables("lobatto"))
+    cp = CPort(problems.REGISTRY[problem](K=K, order=order), QuadratureTables("lobatto"))
     x = np.random.default_rng(1234).uniform(-0.45, 0.45, cp.num_x)
     lam = np.random.default_rng(1235).normal(size=cp.num_c)
     out = {}
@@ -331,7 +333,7 @@ def _sweep(K: int, order: int, budget_s: float, counts: list) -> dict:
     return out
 
 
-def _sweep_child(K, order, budget_s, counts, policy, ceiling):
+def _sweep_child(K, order, budget_s, counts, policy, ceiling, problem="hypersensitive"):
     """One sweep in a child process with its own OpenMP environment; returns {threads: (rate, n, seconds)}."""
     import json
     import sys
@@ -339,7 +341,7 @@ def _sweep_child(K, order, budget_s, counts, policy, ceiling):
     root = os.path.dirname(os.path.dirname(HERE))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     code = ("import json, sys; from oracle import cport; "
-            f"print('SWEEP' + json.dumps(cport._sweep({K}, {order}, {budget_s!r}, {list(counts)!r})))")
+            f"print('SWEEP' + json.dumps(cport._sweep({K}, {order}, {budget_s!r}, {list(counts)!r}, {problem!r})))")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root)
     for line in res.stdout.splitlines():
         if line.startswith("SWEEP"):
@@ -381,3 +383,15 @@ def time_hypersensitive(K: int, order: int, budget_s: float = 20.0) -> dict:
             "host_cpus": ncpu, "cpu_model": facts["model"], "cgroup_cpu_max": facts["cgroup_cpu_max"],
             "quota_cpus": facts["quota_cpus"],
             "best_value": round(out[best_thr][0], 2), "best_threads": best_thr}
+
+
+def time_problem(problem: str, K: int, order: int, budget_s: float = 6.0) -> dict:
+    """One thread and the container's CPU quota (active waits) on another registered problem -- bench.py's
+    ``host_by_config`` -- in a child process like :func:`time_hypersensitive`; {threads: evals/s}."""
+    facts = host_cpu_facts()
+    ncpu = facts["affinity_cpus"]
+    quota = int(facts["quota_cpus"]) if facts["quota_cpus"] else ncpu
+    counts = sorted({1, max(1, min(quota, ncpu))})
+    out = _sweep_child(K, order, budget_s, counts, "active", max(counts), problem)
+    return {"by_threads": {str(t): round(v[0], 2) for t, v in sorted(out.items())}, "evals": {str(t): v[1] for t, v in out.items()},
+            "kind": "port", "quota_cpus": facts["quota_cpus"]}
