@@ -749,7 +749,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         int64_t tiles = 0;
         for (auto& P : Q.ph) {
           if (!P.spec_orders.empty()) {
-            pcp::phase_set_caps(P, 64, W, qa_n, qw_n, budget);
+            pcp::phase_set_caps(P, W > 1 ? 64 : TB, W, qa_n, qw_n, budget);
             // A launch is one generation of waves and lasts as long as its slowest one: a tile of several orders runs
             // the any-order body, which takes about twice as long per row as an order-specialised one -- such tiles are
             // kept to half the rows so that they finish with the others (measured: with 63-row any-order tiles among
