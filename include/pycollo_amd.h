@@ -69,6 +69,15 @@ typedef struct {
   int32_t n_spec;
   int32_t spec_orders[4];
   int32_t reserved_spec[3];
+  /* tile table given by the caller instead of cut by pc_create (n_fixed_tiles = 0: pc_create cuts): first section of
+   * every tile [n_fixed_tiles + 1] (0 ... K, increasing) and, for a mixed build, the order whose body runs each tile
+   * [n_fixed_tiles] (NULL: the any-order body everywhere).  What a rank-local handle of the section-sharded evaluation
+   * is built with (pycollo_amd/sharding.py, LocalShard): the global tiling's tiles of the rank's range behind a halo tile,
+   * so that every tile computes bit for bit what it computes in the whole mesh. */
+  int32_t n_fixed_tiles;
+  int32_t reserved_tiles;
+  const int32_t* fixed_tile_k0;
+  const int32_t* fixed_tile_order;
 } pc_phase_desc;
 
 typedef struct {
@@ -104,7 +113,8 @@ typedef struct {
                                       resource sidecar); 0 = none.  >= 2: pc_create shares every 64-node tile between
                                       two waves and sizes the tiles so that a CU holds eight of them.  A launch-shape
                                       hint only: results do not depend on it beyond summation order of the integrals */
-  int32_t reserved;
+  int32_t plan_only;               /* 1: stop after the tiles are cut -- no layout, no patterns, no device (pc_phase_tiles /
+                                      pc_phase_tile_orders / pc_get_info's tile fields work; O(sections) memory) */
 } pc_problem_desc;
 
 typedef struct {

@@ -48,6 +48,11 @@ inline void from_desc(const pc_problem_desc& d, Problem& Q) {
     P.spec_orders.assign(s.spec_orders, s.spec_orders + s.n_spec);
     for (int n : P.spec_orders)
       if (n < 2 || n > PC_MAX_ORDER) throw std::runtime_error("specialised section order outside [2, 20]");
+    if (s.n_fixed_tiles > 0) {
+      if (!s.fixed_tile_k0) throw std::runtime_error("fixed tile table missing");
+      P.fixed_tile_k0.assign(s.fixed_tile_k0, s.fixed_tile_k0 + s.n_fixed_tiles + 1);
+      if (s.fixed_tile_order) P.fixed_tile_order.assign(s.fixed_tile_order, s.fixed_tile_order + s.n_fixed_tiles);
+    }
     for (int k = 0; k < s.K; ++k)
       if (s.compiled_order > 0 && s.n_k[k] != s.compiled_order)
         throw std::runtime_error("phase kernel was compiled for a fixed section order that the mesh does not have");

@@ -777,8 +777,22 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
         int64_t max_waves = 2048;   // every wave of the launch resident at once (two per SIMD)
         if (const char* env = std::getenv("PYCOLLO_AMD_TWO_WAVE_MAX_WAVES")) max_waves = std::atoll(env);
         // the smallest tile capacity from the chip-filling one upwards whose cut keeps every wave resident
-        bool fits = false;
-        for (int t = std::min(tc, fill_tc(tc)); t <= tc && !fits; ++t) {
+        bool fits = false, fixed = false;
+        for (auto& P : Q.ph) fixed = fixed || !P.fixed_tile_k0.empty();
+        if (fixed) {   // the caller's tiles (a rank-local handle): two waves per tile when its actual tiles allow it
+          TC = 64;
+          const int64_t tiles = cut(2, kQuarterCu);
+          int need = 0;
+          for (auto& P : Q.ph)
+            if (!P.spec_orders.empty()) {
+              bool ap = false, ag = false;
+              const int out = 2 * phase_lds_out_tiles(P, &ap, &ag);
+              if (ag) need = std::max(need, phase_lds_bytes(P, 64, qa_n, qw_n, out, true, true));
+              if (ap) need = std::max(need, phase_lds_bytes(P, 64, qa_n, qw_n, out, false, true));
+            }
+          fits = need <= kQuarterCu && need_uniform(64) <= kQuarterCu && 2 * tiles <= max_waves;
+        }
+        for (int t = std::min(tc, fill_tc(tc)); !fixed && t <= tc && !fits; ++t) {
           TC = t;
           fits = need_uniform(t) <= kQuarterCu && 2 * cut(2, kQuarterCu) <= max_waves;
         }
@@ -817,6 +831,16 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       if (v >= max_nk && v <= TB) TC = v;
     }
     h->TC = TC;
+    if (d->plan_only) {   // the tiling alone (a rank of the section-sharded evaluation asks for its range, sharding.py)
+      pcp::build_all(Q, TC, true);
+      h->device = -1;
+      h->pd.resize(Q.ph.size());
+      for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
+        h->pd[ip].reset(new PhaseDev());
+        h->pd[ip]->n_tiles = (int)Q.ph[ip].tile_k0.size() - 1;
+      }
+      return;
+    }
     pcp::build_all(Q, TC);
     if (h->mixed) {   // one record per tile: which body runs it and where it sits in the mesh
       for (auto& P : Q.ph)
@@ -878,6 +902,7 @@ int pc_create(const pc_problem_desc* d, pc_handle** out) {
       // uniform section order: index arithmetic replaces the section tables
       bool same = true;
       for (int k = 0; k < P.K; ++k) same = same && P.n_k[k] == P.n_k[0];
+      same = same && P.fixed_tile_k0.empty();   // (a caller's tile table is read from the tables, never computed from the tile index)
       D.uni_n = same ? P.n_k[0] : 0;
       D.spt = same ? (TC - 1) / (P.n_k[0] - 1) : 0;
       if (same && P.tile_k0.size() > 1 && P.tile_k0[1] != std::min(D.spt, P.K))

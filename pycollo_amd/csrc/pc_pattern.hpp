@@ -63,6 +63,7 @@ struct Phase {
   int64_t gq_base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<int32_t> tile_k0;
   std::vector<int32_t> tile_order;   // [n_tiles] mixed build: the order whose body runs the tile, 0 = the any-order body
+  std::vector<int32_t> fixed_tile_k0, fixed_tile_order;   // the caller's tile table (pc_phase_desc::fixed_tile_k0), else empty
   int nred = 0;
 
   bool dep(int r, int c) const { return jmask[(size_t)r * n_v + c] != 0; }
@@ -238,6 +239,27 @@ inline void build_tiles_mixed(Phase& P, int TB) {
 }
 
 inline void build_tiles(Phase& P, int TB) {
+  if (!P.fixed_tile_k0.empty()) {   // the caller's tiles, checked
+    const auto& t = P.fixed_tile_k0;
+    if (t.size() < 2 || t.front() != 0 || t.back() != P.K) fail("fixed tile table must run from section 0 to K");
+    auto has_body = [&](int n) { return std::find(P.spec_orders.begin(), P.spec_orders.end(), n) != P.spec_orders.end(); };
+    for (size_t i = 0; i + 1 < t.size(); ++i) {
+      if (t[i + 1] <= t[i]) fail("fixed tile table must be strictly increasing");
+      int rows = 0;
+      for (int k = t[i]; k < t[i + 1]; ++k) rows += P.n_k[k] - 1;
+      if (rows > TB - 1) fail("a fixed tile holds more nodes than a workgroup has threads");
+      const int o = i < P.fixed_tile_order.size() ? P.fixed_tile_order[i] : 0;
+      if (o != 0) {
+        if (!has_body(o)) fail("a fixed tile names an order the code object has no body for");
+        for (int k = t[i]; k < t[i + 1]; ++k)
+          if (P.n_k[k] != o) fail("a fixed tile of order n holds a section of another order");
+      }
+    }
+    P.tile_k0 = t;
+    P.tile_order.assign(t.size() - 1, 0);
+    for (size_t i = 0; i + 1 < t.size() && i < P.fixed_tile_order.size(); ++i) P.tile_order[i] = P.fixed_tile_order[i];
+    return;
+  }
   if (!P.spec_orders.empty()) {
     build_tiles_mixed(P, TB);
     return;
@@ -608,11 +630,12 @@ inline void build_H(Problem& Q) {
   for (int64_t sl : Q.pt_hslot) Q.pt_hlocal.push_back(local(sl));
 }
 
-inline void build_all(Problem& Q, int TB) {
+inline void build_all(Problem& Q, int TB, bool tiles_only = false) {
   for (auto& P : Q.ph) {
     if (P.sec_s.empty()) finalize_phase_tables(P, Q.n_s);
     build_tiles(P, TB);
   }
+  if (tiles_only) return;
   build_layout(Q);
   build_G(Q);
   build_H(Q);

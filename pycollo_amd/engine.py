@@ -44,7 +44,8 @@ class _PhaseDesc(C.Structure):
                 ("n_hess", C.c_int32), ("hess_row", _i32p), ("hess_col", _i32p),
                 ("bulk_kernel", C.c_char_p), ("compiled_order", C.c_int32), ("n_edge_rec", C.c_int32 * 2),
                 ("eval_ops", C.c_int32), ("n_w", C.c_int32), ("w_kind", _i32p), ("w_idx", _i32p),
-                ("n_spec", C.c_int32), ("spec_orders", C.c_int32 * 4), ("reserved_spec", C.c_int32 * 3)]
+                ("n_spec", C.c_int32), ("spec_orders", C.c_int32 * 4), ("reserved_spec", C.c_int32 * 3),
+                ("n_fixed_tiles", C.c_int32), ("reserved_tiles", C.c_int32), ("fixed_tile_k0", _i32p), ("fixed_tile_order", _i32p)]
 
 
 class _ProblemDesc(C.Structure):
@@ -57,7 +58,7 @@ class _ProblemDesc(C.Structure):
                 ("n_orders", C.c_int32), ("orders", _i32p), ("quad_A", _f64p), ("quad_w", _f64p),
                 ("code_object", C.c_char_p), ("tail_kernel", C.c_char_p),
                 ("device", C.c_int32), ("threads_per_block", C.c_int32), ("two_wave_occupancy", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("plan_only", C.c_int32)]
 
 
 class _Info(C.Structure):
@@ -184,7 +185,13 @@ class NlpEngine:
 
     def __init__(self, problem: ProblemSpec | Model, meshes: list[PhaseMesh] | None = None, *, device: int | None = 0,
                  threads_per_block: int = 0, quad: QuadratureTables | None = None, build: bool = True,
-                 specialise: bool = True, mixed="auto"):
+                 specialise: bool = True, mixed="auto", orders=None, fixed_tiles=None, plan_only: bool = False,
+                 plan_device: int = -1):
+        """``orders`` / ``mixed``: the build to use instead of the one chosen from the meshes (a rank-local handle runs the
+        global handle's build on its part of the mesh).  ``fixed_tiles``: per phase ``(tile_k0, tile_order or None)`` --
+        the caller's tile table (``pc_phase_desc.fixed_tile_k0``).  ``plan_only``: cut the tiles and stop
+        (``phase_tiles`` / ``phase_tile_orders`` / ``info`` work; no patterns, no device memory); ``plan_device``: the
+        device whose LDS limit the plan assumes (-1: the 64 KiB default of a structure-only handle)."""
         self.model = problem if isinstance(problem, Model) else compile_model(problem)
         self.quad = quad or QuadratureTables(self.model.quadrature_method)
         if meshes is None:
@@ -202,13 +209,18 @@ class NlpEngine:
         self.orders = tuple(int(m.n[0]) if np.all(m.n == m.n[0]) else 0 for m in meshes)
         if not specialise:
             self.orders = tuple(0 for _ in meshes)
+        if orders is not None:
+            self.orders = tuple(int(o) for o in orders)
+        self._fixed_tiles = fixed_tiles
+        self._plan_only = bool(plan_only)
+        wants_device = self.device >= 0 or (plan_only and plan_device >= 0)
         # ... and a phase whose sections differ in order gets the mixed build when its orders come in runs (large NLPs
         # only: a code object per set of orders is not worth compiling for a mesh of a few hundred nodes).
         # mixed: "auto" | None | one tuple of orders per phase
         if mixed == "auto":
             big = sum(int(np.sum(m.n - 1)) + 1 for m in meshes) >= MIX_MIN_NODES
             mixed = (tuple(choose_spec_orders(m.n) if o == 0 else () for m, o in zip(meshes, self.orders))
-                     if (specialise and big and self.device >= 0) else None)
+                     if (specialise and big and wants_device) else None)
         self.mixed = (tuple(tuple(int(n) for n in mm) for mm in mixed) if mixed is not None and any(mixed)
                       else tuple(() for _ in meshes))
         if self.device >= 0:
@@ -216,13 +228,23 @@ class NlpEngine:
                            else codegen.code_object_path(self.model, self.orders, self.mixed))
             if not os.path.exists(code_object):
                 raise RuntimeError(f"code object {code_object} is missing")
+        if plan_only and plan_device >= 0:   # the plan of a device handle: its code object's register figures decide the launch shape
+            code_object = codegen.code_object_path(self.model, self.orders, self.mixed)
+            if not os.path.exists(code_object):
+                code_object = codegen.build_code_object(self.model, self.orders, mixed=self.mixed) if build else None
         self.code_object = code_object
         desc = self._make_desc(code_object, threads_per_block)
+        if plan_only:
+            desc.plan_only = 1
+            desc.device = int(plan_device)
+            desc.code_object = None
         if not self._lib.pc_create(C.byref(desc), C.byref(self._h)):
             raise RuntimeError("pc_create failed: " + self._lib.pc_last_error().decode())
         info = _Info()
         self._check(self._lib.pc_get_info(self._h, C.byref(info)))
         self.info = {k: getattr(info, k) for k, _ in _Info._fields_}
+        if plan_only:
+            return
         self.num_x, self.num_c = info.n, info.m
         self.nnz_jac, self.nnz_hess = int(info.nnz_jac), int(info.nnz_hess)
         if (self.num_x, self.num_c) != (self.layout.num_x, self.layout.num_c):
@@ -253,7 +275,16 @@ class NlpEngine:
             d.n_jac, d.jac_row, d.jac_col = len(jr), _ptr(jr, _i32p), _ptr(jc, _i32p)
             d.n_hess, d.hess_row, d.hess_col = len(hr), _ptr(hr, _i32p), _ptr(hc, _i32p)
             d.bulk_kernel = f"pc_bulk_p{pm.index}".encode()
-            d.compiled_order = self.orders[i] if self.device >= 0 else 0
+            d.compiled_order = self.orders[i] if (self.device >= 0 or self._plan_only) else 0
+            if self._fixed_tiles is not None and self._fixed_tiles[i] is not None:
+                tk, to = self._fixed_tiles[i]
+                tk = _i32(tk)
+                keep.append(tk)
+                d.n_fixed_tiles, d.fixed_tile_k0 = len(tk) - 1, _ptr(tk, _i32p)
+                if to is not None:
+                    to = _i32(to)
+                    keep.append(to)
+                    d.fixed_tile_order = _ptr(to, _i32p)
             d.n_spec = len(self.mixed[i])
             for j, n in enumerate(self.mixed[i]):
                 d.spec_orders[j] = n

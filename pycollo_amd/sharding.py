@@ -27,6 +27,81 @@ def _indptr(rows: np.ndarray, n_rows: int) -> np.ndarray:
     return np.cumsum(out)
 
 
+def tile_cuts(sec_s: np.ndarray, tile_k0, world: int) -> list:
+    """Tile index at which every rank's contiguous share of one phase starts (``world + 1`` entries): shares balanced
+    by the nodes they hold (a rank's part of c~, G~, H~ is proportional to its nodes; on a ph-refined mesh tiles hold
+    different numbers of nodes, and a padded exchange is as long as the longest share)."""
+    k0s = np.asarray(tile_k0, dtype=np.int64)
+    n_tiles = len(k0s) - 1
+    tile_nodes = np.diff(sec_s[k0s])
+    cum = np.concatenate([[0], np.cumsum(tile_nodes)])
+    cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n_tiles
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return cuts
+
+
+def _range_segments(lay, pm, pl, mesh, gp, hp, h_cols, oG, oH, part_off, nred, ka, kb, tb, te, owns_last=None):
+    """(start, stop) positions in the combined buffer [c | G | H | partials ...] that the tiles [tb, te) = sections
+    [ka, kb) of one phase produce: the tile kernels' outputs for the nodes they own -- defect rows of every state with
+    their Jacobian blocks, path rows, the z entries of the integral rows, the Hessian rows / strips of the owned nodes
+    -- and the tiles' partial sums.  Shared by the global plan (ShardPlan) and a rank-local handle (LocalShard), whose
+    segment lists therefore correspond one to one."""
+    seg = []
+    N = pl.N
+    jmask, hmask, tz = pm.jac_mask(), pm.hess_mask(), pm.t_strip_mask()
+    wk = pm.w_kind or [0] * pm.n_s
+    wi = pm.w_idx or list(range(pm.n_s))
+
+    def h_slot(row, col):
+        a, b = hp[row], hp[row + 1]
+        j = a + np.searchsorted(h_cols[a:b], col)
+        assert j < b and h_cols[j] == col
+        return int(j)
+
+    n0, n1 = int(mesh.s[ka]), int(mesh.s[kb])
+    if owns_last is None:
+        owns_last = kb == mesh.K
+    n1o = n1 + (1 if owns_last else 0)             # owned nodes [n0, n1o): the phase's last node belongs to its last tile
+    for a in range(pm.n_y):                         # defect rows n0 .. n1-1 of every state
+        r0 = pl.c_off + a * (N - 1)
+        seg.append((r0 + n0, r0 + n1))
+        seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1]))
+    for m in range(pm.n_p):                         # path rows of the owned nodes
+        r0 = pl.c_path_off + m * N
+        seg.append((r0 + n0, r0 + n1o))
+        seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1o]))
+    for m in range(pm.n_q):                         # z entries of the integral rows
+        row = pl.c_int_off + m
+        rank_b = 0
+        for b in range(pm.n_z):
+            if jmask[pm.n_y + pm.n_p + m, b]:
+                base = oG + gp[row] + rank_b * N
+                seg.append((base + n0, base + n1o))
+                rank_b += 1
+    for b in range(pm.n_z):                         # Hessian rows of the owned nodes
+        if hmask[b, :pm.n_z].any():
+            r0 = pl.x_off + b * N
+            seg.append((oH + hp[r0 + n0], oH + hp[r0 + n1o]))
+    for jt in range(pm.n_t):                        # t strips
+        for b in range(pm.n_z):
+            if tz[b]:
+                base = oH + h_slot(pl.t_off + jt, pl.x_off + b * N)
+                seg.append((base + n0, base + n1o))
+    for l in range(pm.n_s):                         # strips of the parameters (s, q; a time's is its t strip)
+        if wk[l] == 2:
+            continue
+        prow = lay.s_off + wi[l] if wk[l] == 0 else pl.q_off + wi[l]
+        for b in range(pm.n_z):
+            if hmask[pm.n_z + l, b]:
+                base = oH + h_slot(prow, pl.x_off + b * N)
+                seg.append((base + n0, base + n1o))
+    if nred:
+        seg.append((part_off + tb * nred, part_off + te * nred))
+    return seg
+
+
 class ShardPlan:
     """Which positions of the combined buffer [c | G | H | partials_p0 | partials_p1 | ...] each rank produces."""
 
@@ -51,74 +126,17 @@ class ShardPlan:
         self.tile_ranges = [[None] * len(model.phases) for _ in range(world)]
         self.segments = [[] for _ in range(world)]   # (start, stop) in the combined buffer
 
-        def h_slot(row, col):
-            a, b = hp[row], hp[row + 1]
-            j = a + np.searchsorted(h_cols[a:b], col)
-            assert j < b and h_cols[j] == col
-            return int(j)
-
         for ip, (pm, pl, mesh) in enumerate(zip(model.phases, lay.phases, engine.meshes)):
             k0s, nred = self.tiles[ip]
             n_tiles = len(k0s) - 1
-            N = pl.N
-            jmask = pm.jac_mask()
-            hmask = pm.hess_mask()
-            tz = pm.t_strip_mask()
-            wk = pm.w_kind or [0] * pm.n_s
-            wi = pm.w_idx or list(range(pm.n_s))
-            # Ranks get contiguous tile ranges balanced by the nodes they hold (a rank's share of c~, G~, H~ is
-            # proportional to its nodes): on a ph-refined mesh tiles hold different numbers of nodes, and the exchange
-            # is padded to the longest share.
-            tile_nodes = np.diff(np.asarray(mesh.s, dtype=np.int64)[np.asarray(k0s, dtype=np.int64)])
-            cum = np.concatenate([[0], np.cumsum(tile_nodes)])
-            cuts = [int(np.searchsorted(cum, cum[-1] * r / world, side="left")) for r in range(world + 1)]
-            cuts[0], cuts[-1] = 0, n_tiles
-            for r in range(1, world + 1):
-                cuts[r] = max(cuts[r], cuts[r - 1])
+            cuts = tile_cuts(np.asarray(mesh.s, dtype=np.int64), k0s, world)
             for r in range(world):
                 tb, te = cuts[r], cuts[r + 1]
                 self.tile_ranges[r][ip] = (tb, te)
                 if te <= tb:
                     continue
-                seg = self.segments[r]
-                ka, kb = int(k0s[tb]), int(k0s[te])
-                n0, n1 = int(mesh.s[ka]), int(mesh.s[kb])
-                n1o = n1 + (1 if kb == mesh.K else 0)          # owned nodes [n0, n1o)
-                for a in range(pm.n_y):                         # defect rows n0 .. n1-1 of every state
-                    r0 = pl.c_off + a * (N - 1)
-                    seg.append((r0 + n0, r0 + n1))
-                    seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1]))
-                for m in range(pm.n_p):                         # path rows of the owned nodes
-                    r0 = pl.c_path_off + m * N
-                    seg.append((r0 + n0, r0 + n1o))
-                    seg.append((oG + gp[r0 + n0], oG + gp[r0 + n1o]))
-                for m in range(pm.n_q):                         # z entries of the integral rows
-                    row = pl.c_int_off + m
-                    rank_b = 0
-                    for b in range(pm.n_z):
-                        if jmask[pm.n_y + pm.n_p + m, b]:
-                            base = oG + gp[row] + rank_b * N
-                            seg.append((base + n0, base + n1o))
-                            rank_b += 1
-                for b in range(pm.n_z):                         # Hessian rows of the owned nodes
-                    if hmask[b, :pm.n_z].any():
-                        r0 = pl.x_off + b * N
-                        seg.append((oH + hp[r0 + n0], oH + hp[r0 + n1o]))
-                for jt in range(pm.n_t):                        # t strips
-                    for b in range(pm.n_z):
-                        if tz[b]:
-                            base = oH + h_slot(pl.t_off + jt, pl.x_off + b * N)
-                            seg.append((base + n0, base + n1o))
-                for l in range(pm.n_s):                         # strips of the parameters (s, q; a time's is its t strip)
-                    if wk[l] == 2:
-                        continue
-                    prow = lay.s_off + wi[l] if wk[l] == 0 else pl.q_off + wi[l]
-                    for b in range(pm.n_z):
-                        if hmask[pm.n_z + l, b]:
-                            base = oH + h_slot(prow, pl.x_off + b * N)
-                            seg.append((base + n0, base + n1o))
-                if nred:
-                    seg.append((self.part_off[ip] + tb * nred, self.part_off[ip] + te * nred))
+                self.segments[r] += _range_segments(lay, pm, pl, mesh, gp, hp, h_cols, oG, oH, self.part_off[ip], nred,
+                                                     int(k0s[tb]), int(k0s[te]), tb, te)
         self.segments = [[(int(a), int(b)) for a, b in s if b > a] for s in self.segments]
         self.index = [np.concatenate([np.arange(a, b, dtype=np.int64) for a, b in s]) if s else np.zeros(0, np.int64)
                       for s in self.segments]
@@ -358,3 +376,342 @@ class ShardedNlp:
             if root is None or self.rank == root:
                 eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
         return self.c, self.G, self.H
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Rank-local handles: a rank holds its section range only (pattern, tables, buffers), the root holds the whole NLP
+# ---------------------------------------------------------------------------------------------------------------------
+def global_tile_plan(model, meshes, device: int = -1, threads_per_block: int = 0, quad=None, mixed="auto", orders=None):
+    """The tiling the unsharded handle would cut -- per phase (tile_k0, tile_order), plus the build (orders, mixed) and the
+    workgroup size -- from a plan-only handle (``pc_problem_desc.plan_only``: O(sections) memory, no patterns)."""
+    from .engine import NlpEngine
+    plan = NlpEngine(model, meshes, device=None, threads_per_block=threads_per_block, quad=quad, plan_only=True,
+                     plan_device=device, mixed=mixed, orders=orders)
+    tiles = [(plan.phase_tiles(ip)[0], plan.phase_tile_orders(ip)) for ip in range(len(model.phases))]
+    out = {"tiles": tiles, "orders": plan.orders, "mixed": plan.mixed, "threads_per_block": plan.info["threads_per_block"]}
+    plan.close()
+    return out
+
+
+class LocalShard:
+    """One rank of the section-sharded evaluation with RANK-LOCAL memory ("mesh-refinement
+    iterations that blow past one GPU's collocation-node count").
+
+    The rank builds an engine for its own part of every phase's mesh only -- the sections of its tile range between two
+    one-section halos (the section before the range: the range's first node closes it, so that node's adjoint weight
+    and quadrature weight need it; the section after it: the range's end node opens it and belongs to the next rank, so
+    the rank's last tile must not be the mesh's last) -- with the global tiling's tiles of that range as a fixed tile
+    table between two halo tiles.  Every owned tile therefore computes bit for bit what it computes in the whole mesh, on a handle whose
+    pattern, tables and buffers are the rank's share.  Inputs are the rank's slices of x~ and lambda (``x_index`` /
+    ``lam_index`` into the global vectors); outputs are the rank's segments of the global combined buffer
+    [c | G | H | partials], packed in the order of the global plan's segment list (``pack``), which the root scatters
+    into place (``LocalRoot``) before it runs the tail kernel of the whole NLP.  The only exchange is the gather to the
+    root.  The reference has no counterpart (single process)."""
+
+    def __init__(self, problem, rank: int, world: int, device: int | None = 0, meshes=None, quad=None, plan=None,
+                 threads_per_block: int = 0):
+        from .engine import NlpEngine
+        from .layout import NlpLayout
+        from .mesh import build_phase_mesh
+        from .model import Model, compile_model
+        from .quadrature import QuadratureTables
+        self.rank, self.world = int(rank), int(world)
+        self.model = model = problem if isinstance(problem, Model) else compile_model(problem)
+        self.quad = quad or QuadratureTables(model.quadrature_method)
+        if meshes is None:
+            meshes = [build_phase_mesh(self.quad, *ph.mesh.resolved()) for ph in problem.phases]
+        self.global_meshes = meshes
+        plan = plan or global_tile_plan(model, meshes, -1 if device is None else int(device), threads_per_block, self.quad)
+        self.plan = plan
+        glay = NlpLayout(model, meshes)           # offsets only: O(phases)
+        self.global_num_x, self.global_num_c = glay.num_x, glay.num_c
+        local_meshes, fixed, mixed, self.ranges, self.halo, self.halo_after, self.first_section = [], [], [], [], [], [], []
+        for ip, (pm, mesh) in enumerate(zip(model.phases, meshes)):
+            k0s, orders = plan["tiles"][ip]
+            cuts = tile_cuts(np.asarray(mesh.s, dtype=np.int64), k0s, world)
+            tb, te = cuts[rank], cuts[rank + 1]
+            empty = te <= tb
+            if empty:                              # nothing of this phase: one section, nothing owned
+                ka, kb, halo, after = 0, 1, 0, 0
+            else:
+                ka, kb = int(k0s[tb]), int(k0s[te])
+                halo = 1 if ka > 0 else 0
+                after = 1 if kb < mesh.K else 0
+            k_first, k_last = ka - halo, kb + after
+            sizes = np.asarray(mesh.sizes, dtype=np.float64)[k_first:k_last]     # fractions of the WHOLE period: h_k = 2 sizes_k
+            nodes = np.asarray(mesh.n, dtype=np.int64)[k_first:k_last]
+            lm = build_phase_mesh(self.quad, sizes, nodes)
+            # the section widths the kernels read are the WHOLE mesh's, bit for bit (build_phase_mesh pins its last node
+            # to tau = +1 and accumulates edges from -1: neither holds for a part of the mesh)
+            lm.h = np.asarray(mesh.h, dtype=np.float64)[k_first:k_last].copy()
+            local_meshes.append(lm)
+            spec = tuple(plan["mixed"][ip]) if plan["mixed"][ip] else ((int(plan["orders"][ip]),) if plan["orders"][ip] else ())
+            mixed.append(spec)
+            if empty:
+                tk, to = np.array([0, 1], dtype=np.int32), np.array([0], dtype=np.int32)
+            else:
+                body = np.asarray(k0s[tb:te + 1], dtype=np.int64) - k_first
+                tk = np.concatenate([[0], body]) if halo else body
+                own = np.asarray(orders[tb:te], dtype=np.int32) if plan["mixed"][ip] else np.full(te - tb, plan["orders"][ip], dtype=np.int32)
+                nh = int(mesh.n[k_first])
+                to = np.concatenate([[nh if nh in spec else 0], own]) if halo else own
+                if after:
+                    na = int(mesh.n[kb])
+                    tk = np.concatenate([tk, [tk[-1] + 1]])
+                    to = np.concatenate([to, [na if na in spec else 0]])
+            fixed.append((tk.astype(np.int32), to.astype(np.int32)))
+            self.ranges.append((tb, te))
+            self.halo.append(halo)
+            self.halo_after.append(after)
+            self.first_section.append(k_first)
+        self.engine = eng = NlpEngine(model, local_meshes, device=device, quad=self.quad, orders=tuple(0 for _ in local_meshes),
+                                      mixed=tuple(mixed), fixed_tiles=fixed, threads_per_block=plan["threads_per_block"])
+        llay = eng.layout
+        # ---- which global x~ / lambda entries the local vectors are (the halo and the shared end node included)
+        xi = np.zeros(eng.num_x, dtype=np.int64)
+        li = np.zeros(eng.num_c, dtype=np.int64)
+        for pm, gl, ll, mesh, k_first in zip(model.phases, glay.phases, llay.phases, meshes, self.first_section):
+            ns = int(mesh.s[k_first])
+            loc = np.arange(ll.N, dtype=np.int64)
+            for b in range(pm.n_z):
+                xi[ll.x_off + b * ll.N + loc] = gl.x_off + b * gl.N + ns + loc
+            for m in range(pm.n_q + pm.n_t):
+                xi[ll.q_off + m] = gl.q_off + m
+            for a in range(pm.n_y):
+                li[ll.c_off + a * (ll.N - 1) + loc[:-1]] = gl.c_off + a * (gl.N - 1) + ns + loc[:-1]
+            for m in range(pm.n_p):
+                li[ll.c_path_off + m * ll.N + loc] = gl.c_path_off + m * gl.N + ns + loc
+            for m in range(pm.n_q):
+                li[ll.c_int_off + m] = gl.c_int_off + m
+        xi[llay.s_off:llay.s_off + llay.n_s] = glay.s_off + np.arange(llay.n_s)
+        li[llay.c_end_off:llay.c_end_off + llay.n_b] = glay.c_end_off + np.arange(llay.n_b)
+        self.x_index, self.lam_index = xi, li
+        # ---- the rank's segments in its own combined buffer [c | G | H | partials ...], in the global plan's order
+        g_rows, _ = eng.evaluate_G_structure()
+        h_rows, h_cols = eng.evaluate_H_structure()
+        gp, hp = _indptr(g_rows, eng.num_c), _indptr(h_rows, eng.num_x)
+        oG, oH = eng.num_c, eng.num_c + eng.nnz_jac
+        self.part_off, off, self.segments = [], oH + eng.nnz_hess, []
+        for ip, (pm, ll, lmesh) in enumerate(zip(model.phases, llay.phases, local_meshes)):
+            k0, nred = eng.phase_tiles(ip)
+            self.part_off.append(off)
+            off += (len(k0) - 1) * nred
+            tb, te = self.ranges[ip]
+            if te <= tb:
+                continue
+            t0, t1 = self.halo[ip], len(k0) - 1 - self.halo_after[ip]      # owned local tiles [t0, t1)
+            self.segments += _range_segments(llay, pm, ll, lmesh, gp, hp, h_cols, oG, oH, self.part_off[ip], nred,
+                                             int(k0[t0]), int(k0[t1]), t0, t1, owns_last=not self.halo_after[ip])
+        self.total = off
+        self.segments = [(int(a), int(b)) for a, b in self.segments if b > a]
+        self.length = sum(b - a for a, b in self.segments)
+        self.buf = None
+        if device is not None:
+            import torch
+            dev = torch.device("cuda", int(device))
+            self.buf = torch.zeros(self.total, dtype=torch.float64, device=dev)
+            self.c, self.G, self.H = self.buf[:oG], self.buf[oG:oH], self.buf[oH:oH + eng.nnz_hess]
+            for ip, off_p in enumerate(self.part_off):
+                k0, nred = eng.phase_tiles(ip)
+                if nred:
+                    eng.set_partials_buffer(ip, self.buf[off_p:off_p + (len(k0) - 1) * nred])
+            runs, o = [], 0
+            chunk = int(eng._lib.pc_run_chunk())
+            for a, b in self.segments:
+                runs.append((a, o, b - a))
+                o += b - a
+            self.pack_tab = torch.from_numpy(_chunk_table(runs, chunk)).to(dev)
+            self.send = torch.zeros(max(self.length, 1), dtype=torch.float64, device=dev)
+            self.x_index_t = torch.from_numpy(xi).to(dev)
+            self.lam_index_t = torch.from_numpy(li).to(dev)
+
+    def device_bytes(self) -> int:
+        """Doubles-and-indices footprint of the rank's handle: inputs, the combined output buffer, the send buffer and
+        the pattern's index arrays (what scales with the rank's share of the mesh)."""
+        e = self.engine
+        return 8 * (e.num_x + e.num_c + self.total + self.length) + 8 * (e.nnz_jac + e.nnz_hess)
+
+    def set_scaling(self, V_ocp, r_ocp, W_ocp, w_J=1.0):
+        self.engine.set_scaling(V_ocp, r_ocp, W_ocp, w_J)
+
+    def evaluate_packed(self, d_x_global, d_lam_global, stream=None):
+        """Tile kernels over the rank's tiles on its slices of the global x~ / lambda (device tensors); returns the send
+        buffer: the rank's segments of the global combined buffer, packed in plan order.  Asynchronous on the current
+        torch stream."""
+        import torch
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        x = d_x_global.index_select(0, self.x_index_t)
+        lam = d_lam_global.index_select(0, self.lam_index_t)
+        self.engine.launch_bulk_only(x, lam, self.c, self.G, self.H, st)
+        if self.pack_tab.shape[0]:
+            if not self.engine._lib.pc_copy_runs(self.buf.data_ptr(), self.send.data_ptr(), self.pack_tab.data_ptr(),
+                                                 self.pack_tab.shape[0], st):
+                raise RuntimeError("pc_copy_runs failed: " + self.engine._lib.pc_last_error().decode())
+        self._keep = (x, lam)
+        return self.send[:self.length]
+
+    def close(self):
+        self.engine.close()
+
+
+class LocalRoot:
+    """The root of the rank-local sharded evaluation: it holds the whole NLP (pattern, full buffers -- the solver lives
+    here), receives every rank's packed segments and finishes the evaluation with the tail kernel."""
+
+    def __init__(self, engine, world: int):
+        self.engine, self.world = engine, int(world)
+        self.plan = ShardPlan(engine, world)
+
+    def unpack_index(self, rank: int) -> np.ndarray:
+        """Positions of rank ``rank``'s packed values in the combined buffer [c | G | H | partials ...]."""
+        return self.plan.index[rank]
+
+
+class LocalShardedNlp:
+    """The rank-local sharded evaluation as processes run it (one per GPU, ``torch.distributed``): every rank holds a
+    :class:`LocalShard` of its section range; the root rank additionally holds the whole NLP (``NlpEngine`` -- the NLP
+    solver lives there) and finishes every evaluation.  Per evaluation: the root scatters every rank's slices of x~ and
+    lambda, the ranks run their tiles and pack, ONE gather brings the packed segments to the root, which scatters them
+    into the whole NLP's buffer (``pc_copy_runs``) and runs the tail kernel.  No rank but the root ever holds more than
+    its share.  Over gloo (CPU tests; several ranks sharing one GPU) the tensors are staged through the host."""
+
+    def __init__(self, problem, device: int | None = 0, root: int = 0, group=None, threads_per_block: int = 0):
+        import torch
+        import torch.distributed as dist
+        from .engine import NlpEngine
+        from .mesh import build_phase_mesh
+        from .model import compile_model
+        from .quadrature import QuadratureTables
+        self.torch, self.dist, self.group, self.root = torch, dist, group, int(root)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        model = compile_model(problem)
+        quad = QuadratureTables(model.quadrature_method)
+        meshes = [build_phase_mesh(quad, *ph.mesh.resolved()) for ph in problem.phases]
+        plan = global_tile_plan(model, meshes, -1 if device is None else int(device), threads_per_block, quad)
+        self.shard = LocalShard(model, self.rank, self.world, device, meshes=meshes, quad=quad, plan=plan)
+        self.is_root = self.rank == self.root
+        self.on_device = device is not None
+        self.dev = torch.device("cuda", int(device)) if self.on_device else torch.device("cpu")
+        self._host_staged = (not self.on_device) or (dist.is_initialized() and dist.get_backend(group) == "gloo")
+        # every rank's packed length and (on the root) its index maps
+        mine = (self.shard.length, self.shard.x_index, self.shard.lam_index)
+        if dist.is_initialized() and self.world > 1:
+            gathered = [None] * self.world if self.is_root else None
+            dist.gather_object(mine, gathered, dst=self._global(self.root), group=group)
+            sizes = [None]
+            if self.is_root:
+                sizes = [([g[0] for g in gathered], max(len(g[1]) for g in gathered), max(len(g[2]) for g in gathered))]
+            dist.broadcast_object_list(sizes, src=self._global(self.root), group=group)
+            self.lengths, self.x_max, self.lam_max = sizes[0]
+        else:
+            gathered, self.lengths = [mine], [self.shard.length]
+            self.x_max, self.lam_max = len(self.shard.x_index), len(self.shard.lam_index)
+        self.maxlen = max(max(self.lengths), 1)
+        self.engine = None
+        if self.is_root:
+            self.engine = eng = NlpEngine(model, meshes, device=device, quad=quad, orders=plan["orders"], mixed=plan["mixed"],
+                                          threads_per_block=plan["threads_per_block"])
+            self.root_plan = rp = ShardPlan(eng, self.world)
+            if [int(l) for l in self.lengths] != [int(l) for l in rp.lengths]:
+                raise RuntimeError("the ranks' packed lengths differ from the root's plan")
+            self.x_idx = [torch.from_numpy(g[1]).to(self.dev) for g in gathered]
+            self.lam_idx = [torch.from_numpy(g[2]).to(self.dev) for g in gathered]
+            self.num_x, self.num_c, self.nnz_jac, self.nnz_hess = eng.num_x, eng.num_c, eng.nnz_jac, eng.nnz_hess
+            self.buf = torch.zeros(rp.total, dtype=torch.float64, device=self.dev)
+            oG, oH = rp.num_c, rp.num_c + rp.nnz_G
+            self.c, self.G, self.H = self.buf[:oG], self.buf[oG:oH], self.buf[oH:oH + rp.nnz_H]
+            self.recv = torch.zeros(self.world * self.maxlen, dtype=torch.float64, device=self.dev)
+            self.unpack_index = [torch.from_numpy(rp.index[r]).to(self.dev) for r in range(self.world)]
+            if self.on_device:
+                for ip, ((k0, nred), off) in enumerate(zip(rp.tiles, rp.part_off)):
+                    if nred:
+                        eng.set_partials_buffer(ip, self.buf[off:off + (len(k0) - 1) * nred])
+                chunk = int(eng._lib.pc_run_chunk())
+                runs = []
+                for r in range(self.world):
+                    o = r * self.maxlen
+                    for a, b in rp.segments[r]:
+                        runs.append((o, a, b - a))
+                        o += b - a
+                self.unpack_tab = torch.from_numpy(_chunk_table(runs, chunk)).to(self.dev)
+        self.send = torch.zeros(self.maxlen, dtype=torch.float64, device=self.dev)
+        self.x_local = torch.zeros(len(self.shard.x_index), dtype=torch.float64, device=self.dev)
+        self.lam_local = torch.zeros(len(self.shard.lam_index), dtype=torch.float64, device=self.dev)
+
+    def _global(self, r):
+        return self.dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def set_scaling(self, V_ocp, r_ocp, W_ocp, w_J=1.0):
+        self.shard.set_scaling(V_ocp, r_ocp, W_ocp, w_J)
+        if self.is_root and self.on_device:
+            self.engine.set_scaling(V_ocp, r_ocp, W_ocp, w_J)
+
+    def distribute(self, d_x=None, d_lam=None):
+        """The root's global x~ / lambda -> every rank's slices (``x_local`` / ``lam_local``)."""
+        dist, torch = self.dist, self.torch
+        if self.world == 1:
+            self.x_local.copy_(d_x.index_select(0, self.x_idx[0]))
+            self.lam_local.copy_(d_lam.index_select(0, self.lam_idx[0]))
+            return
+        # (a scatter moves equal-sized pieces: every rank's slice is padded to the longest)
+        for mine, src, idx, width in ((self.x_local, d_x, "x_idx", self.x_max), (self.lam_local, d_lam, "lam_idx", self.lam_max)):
+            pieces = None
+            if self.is_root:
+                pieces = []
+                for i in getattr(self, idx):
+                    p = torch.zeros(width, dtype=src.dtype, device=src.device)
+                    p[:i.numel()] = src.index_select(0, i)
+                    pieces.append(p.cpu() if self._host_staged else p)
+            out = torch.empty(width, dtype=mine.dtype, device="cpu" if self._host_staged else mine.device)
+            dist.scatter(out, pieces, src=self._global(self.root), group=self.group)
+            mine.copy_(out[:mine.numel()])
+
+    def collect(self, packed):
+        """The ranks' packed segments -> the root's whole buffer (gather + scatter into place)."""
+        dist, torch = self.dist, self.torch
+        n = packed.numel()
+        self.send[:n].copy_(packed)
+        if self.world == 1:
+            self.recv[:self.maxlen].copy_(self.send)
+        elif self._host_staged:
+            pieces = [torch.empty(self.maxlen, dtype=self.send.dtype) for _ in range(self.world)] if self.is_root else None
+            dist.gather(self.send.cpu(), pieces, dst=self._global(self.root), group=self.group)
+            if self.is_root:
+                self.recv.copy_(torch.cat(pieces))
+        else:
+            pieces = [self.recv[q * self.maxlen:(q + 1) * self.maxlen] for q in range(self.world)] if self.is_root else None
+            dist.gather(self.send, pieces, dst=self._global(self.root), group=self.group)
+        if not self.is_root:
+            return
+        if self.on_device:
+            if self.unpack_tab.shape[0]:
+                st = torch.cuda.current_stream().cuda_stream
+                if not self.engine._lib.pc_copy_runs(self.recv.data_ptr(), self.buf.data_ptr(), self.unpack_tab.data_ptr(),
+                                                     self.unpack_tab.shape[0], st):
+                    raise RuntimeError("pc_copy_runs failed: " + self.engine._lib.pc_last_error().decode())
+        else:
+            for r in range(self.world):
+                self.buf.index_copy_(0, self.unpack_index[r], self.recv[r * self.maxlen:r * self.maxlen + self.lengths[r]])
+
+    def evaluate_all_device(self, d_x, obj_factor, d_lam, stream=None):
+        """One evaluation; ``d_x`` / ``d_lam`` are the global vectors on the root (ignored elsewhere).  Returns the
+        root's (c~, G~, H~) views (None on the other ranks).  Runs on the current torch stream."""
+        torch = self.torch
+        self.distribute(d_x, d_lam)
+        st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        sh = self.shard
+        sh.engine.launch_bulk_only(self.x_local, self.lam_local, sh.c, sh.G, sh.H, st)
+        if sh.pack_tab.shape[0]:
+            if not sh.engine._lib.pc_copy_runs(sh.buf.data_ptr(), sh.send.data_ptr(), sh.pack_tab.data_ptr(), sh.pack_tab.shape[0], st):
+                raise RuntimeError("pc_copy_runs failed: " + sh.engine._lib.pc_last_error().decode())
+        self.collect(sh.send[:sh.length])
+        if not self.is_root:
+            return None
+        self.engine.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, st)
+        return self.c, self.G, self.H
+
+    def close(self):
+        self.shard.close()
+        if self.engine is not None:
+            self.engine.close()

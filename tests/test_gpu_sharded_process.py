@@ -95,3 +95,69 @@ def test_rccl_collectives_carry_the_exchange(built):
     res = subprocess.run([sys.executable, "-c", _RCCL_WORLD_OF_ONE], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     assert "RCCL world of one: all modes equal" in res.stdout
+
+
+_LOCAL_TWO_RANKS = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+from pycollo_amd import problems
+from pycollo_amd.engine import NlpEngine
+from pycollo_amd.sharding import LocalShardedNlp
+dev = torch.device("cuda", 0)
+for name, kw in (("shuttle", dict(K=300, order=4)), ("delta_iii", dict(K=40, order=5)), ("time_coupled_transfer", dict(K=60, order=4))):
+    prob = problems.REGISTRY[name](**kw)
+    sh = LocalShardedNlp(prob, device=0, root=0)
+    st = torch.cuda.Stream()
+    x = lam = None
+    if sh.is_root:
+        lo, hi = (0.05, 0.3) if name == "delta_iii" else (-0.45, 0.45)
+        x = torch.from_numpy(np.random.default_rng(1).uniform(lo, hi, sh.num_x)).to(dev)
+        lam = torch.from_numpy(np.random.default_rng(2).normal(size=sh.num_c)).to(dev)
+    for rep in range(2):
+        with torch.cuda.stream(st):
+            out = sh.evaluate_all_device(x, 0.8, lam)
+        torch.cuda.synchronize()
+    whole = None
+    if sh.is_root:
+        ref = NlpEngine(prob, device=0)
+        rc, rG, rH = (torch.empty(n, dtype=torch.float64, device=dev) for n in (ref.num_c, ref.nnz_jac, ref.nnz_hess))
+        with torch.cuda.stream(st):
+            ref.evaluate_all_device(x, 0.8, lam, rc, rG, rH, st.cuda_stream)
+        st.synchronize()
+        same = lambda a, b: bool(torch.equal(torch.nan_to_num(a, nan=1.25e300), torch.nan_to_num(b, nan=1.25e300)))
+        ok = same(rc, out[0]) and same(rG, out[1]) and same(rH, out[2])
+        whole = 8 * (ref.num_x + 2 * ref.num_c + 2 * (ref.nnz_jac + ref.nnz_hess))
+        print(f"LOCAL {name}: root reassembled the unsharded evaluation: {ok}", flush=True)
+        ref.close()
+        if not ok:
+            sys.exit(1)
+    else:
+        assert out is None and sh.engine is None
+    print(f"LOCAL {name}: rank {rank} holds {sh.shard.device_bytes()} B of its own", flush=True)
+    sh.close()
+dist.barrier()
+dist.destroy_process_group()
+print(f"LOCAL rank {rank} done")
+'''
+
+
+def test_rank_local_shards_two_processes(built, tmp_path):
+    """``LocalShardedNlp`` as processes run it (two ranks under torch.distributed.run sharing the one GPU, gloo): the root
+    scatters the ranks' slices of x~ / lambda, every rank evaluates its section range on a handle that holds nothing else,
+    one gather brings the packed segments to the root, whose tail finishes the evaluation -- bit for bit the unsharded one.
+    Only the root holds the whole NLP."""
+    script = tmp_path / "local_two_ranks.py"
+    script.write_text(_LOCAL_TWO_RANKS)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = res.stdout + res.stderr
+    assert res.returncode == 0, out[-3000:]
+    assert out.count("root reassembled the unsharded evaluation: True") == 3, out[-3000:]
+    assert "LOCAL rank 0 done" in out and "LOCAL rank 1 done" in out
