@@ -28,7 +28,7 @@ std::vector<T> read_vec(std::istream& in, long n) {
 }
 
 struct PhaseIn {
-  std::vector<int32_t> n_k, jr, jc, hr, hc, wk, wi;
+  std::vector<int32_t> n_k, jr, jc, hr, hc, wk, wi, fk, fo;
   std::vector<double> h_k;
 };
 
@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
       PhaseIn& a = store[ip];
       s = pc_phase_desc{};
       in >> s.n_y >> s.n_u >> s.n_q >> s.n_p >> s.t0_free >> s.tF_free >> s.K >> s.n_jac >> s.n_hess >> s.n_w >> s.compiled_order;
+      // mixed build: the orders with a tile body; a caller's tile table (pc_phase_desc::fixed_tile_k0 / fixed_tile_order)
+      in >> s.n_spec >> s.spec_orders[0] >> s.spec_orders[1] >> s.spec_orders[2] >> s.spec_orders[3] >> s.n_fixed_tiles;
       if (!in) throw std::runtime_error("bad phase header");
       a.n_k = read_vec<int32_t>(in, s.K);
       a.h_k = read_vec<double>(in, s.K);
@@ -69,6 +71,10 @@ int main(int argc, char** argv) {
       a.hc = read_vec<int32_t>(in, s.n_hess);
       a.wk = read_vec<int32_t>(in, s.n_w);
       a.wi = read_vec<int32_t>(in, s.n_w);
+      a.fk = read_vec<int32_t>(in, s.n_fixed_tiles > 0 ? s.n_fixed_tiles + 1 : 0);
+      a.fo = read_vec<int32_t>(in, s.n_fixed_tiles > 0 ? s.n_fixed_tiles : 0);
+      s.fixed_tile_k0 = s.n_fixed_tiles > 0 ? a.fk.data() : nullptr;
+      s.fixed_tile_order = s.n_fixed_tiles > 0 ? a.fo.data() : nullptr;
       s.n_k = a.n_k.data(); s.h_k = a.h_k.data();
       s.jac_row = a.jr.data(); s.jac_col = a.jc.data();
       s.hess_row = a.hr.data(); s.hess_col = a.hc.data();
@@ -90,6 +96,11 @@ int main(int argc, char** argv) {
     pcp::Problem Q;
     pcp::from_desc(d, Q);
     for (auto& P : Q.ph) pcp::finalize_phase_tables(P, Q.n_s);
+    for (auto& P : Q.ph)   // mixed build: the row caps pc_create sets for one wave per tile (64 KiB of LDS)
+      if (!P.spec_orders.empty()) {
+        pcp::phase_set_caps(P, tile_nodes, 1, qa_total, qw_total, 64 * 1024);
+        P.mix_cap_rows = std::min(P.mix_cap_rows, 32);
+      }
     pcp::build_all(Q, tile_nodes);
 
     std::ofstream out(argv[2]);
@@ -100,6 +111,13 @@ int main(int argc, char** argv) {
     for (size_t ip = 0; ip < Q.ph.size(); ++ip) {
       const auto& P = Q.ph[ip];
       put(out, "tile_k0", P.tile_k0);
+      put(out, "tile_order", P.tile_order);
+      if (!P.spec_orders.empty()) {   // the exact staging size of the tiles as cut, row groups included, in both forms
+        bool ap = false, ag = false;
+        std::vector<int> m = {pcp::phase_lds_out_tiles(P, &ap, &ag), pcp::phase_lds_out_tiles(P, nullptr, nullptr, false), (int)ap, (int)ag};
+        for (int n = 2; n <= PC_MAX_ORDER; ++n) m.push_back(pc_row_passes(n, pcp::phase_max_row_len(P, n)));
+        put(out, "mixed", m);
+      }
       put(out, "goff", P.goff); put(out, "hoff", P.hoff); put(out, "hslot0", P.hslot0); put(out, "hslotN", P.hslotN);
       const int rows = pcp::phase_max_tile_rows(P);
       const int lds_out = pcp::phase_lds_out(P, rows, std::min(tile_nodes, rows + 1));
