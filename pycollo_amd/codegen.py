@@ -532,7 +532,7 @@ def _extra_defines() -> list[str]:
     return [d for d in os.environ.get("PYCOLLO_AMD_DEFINES", "").split() if d]
 
 
-HEAVY_SCRATCH_LIMIT = int(os.environ.get("PYCOLLO_AMD_HEAVY_SCRATCH_LIMIT", "128"))   # bytes per lane a capped heavy kernel may spill (env: experiments)
+HEAVY_SCRATCH_LIMIT = int(os.environ.get("PYCOLLO_AMD_HEAVY_SCRATCH_LIMIT", "384"))   # bytes per lane a capped heavy kernel may spill (env: experiments)
 
 
 def _heavy_cap_enabled() -> bool:
@@ -607,7 +607,7 @@ def code_object_path(model: Model, orders=None, mixed=None) -> str:
         occ += "_nocap"
     if not _heavy_w4_enabled():
         occ += "_nohw4"
-    if HEAVY_SCRATCH_LIMIT != 128:          # (decides whether a heavy model's kernels keep their register cap)
+    if HEAVY_SCRATCH_LIMIT != 384:          # (decides whether a heavy model's kernels keep their register cap)
         occ += f"_sl{HEAVY_SCRATCH_LIMIT}"
     if _extra_defines():
         occ += "_d" + hashlib.sha256(" ".join(_extra_defines()).encode()).hexdigest()[:8]

@@ -1729,7 +1729,16 @@ int pc_read_symbol(pc_handle* h, const char* name, void* dst, size_t bytes) {
     if (!name || !dst) throw std::runtime_error("null symbol name or destination");
     hipDeviceptr_t p = nullptr;
     size_t sz = 0;
-    HIP_OK(hipModuleGetGlobal(&p, &sz, h->module, name));
+    // "symbol@k": the copy in part k of a code object that comes in parts (every part has its own device globals)
+    std::string sym(name);
+    hipModule_t mod = h->module;
+    if (const size_t at = sym.find('@'); at != std::string::npos) {
+      const int k = std::atoi(sym.c_str() + at + 1);
+      sym.resize(at);
+      if (k < 0 || k > (int)h->more_modules.size()) throw std::runtime_error("no such part of the code object");
+      if (k > 0) mod = h->more_modules[k - 1];
+    }
+    HIP_OK(hipModuleGetGlobal(&p, &sz, mod, sym.c_str()));
     if (bytes > sz) throw std::runtime_error("symbol is smaller than the requested read");
     HIP_OK(hipStreamSynchronize(h->stream));
     HIP_OK(hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost));
