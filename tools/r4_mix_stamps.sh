@@ -3,5 +3,3 @@
 mkdir -p gpurun_out
 PYCOLLO_AMD_DEFINES=PC_STAMPS timeout -k 10 400 python tools/stamps.py --problem delta_iii --refined 12500 --reps 5 > gpurun_out/mix_stamps.txt 2>&1
 tail -40 gpurun_out/mix_stamps.txt
-PYCOLLO_AMD_MIX_SPLIT=1 PYCOLLO_AMD_MIX_LPT=1 PYCOLLO_AMD_TWO_WAVE_MAX_WAVES=2400 PYCOLLO_AMD_DEFINES=PC_STAMPS timeout -k 10 400 python tools/stamps.py --problem delta_iii --refined 12500 --reps 5 > gpurun_out/mix_stamps_split.txt 2>&1
-tail -22 gpurun_out/mix_stamps_split.txt
