@@ -369,6 +369,13 @@ int pc_ipm_errors(pc_ipm* s, double* out10);
 int pc_ipm_newton(pc_ipm* s, double mu, double tau, double dw_last, double* out8);
 /* trial point v + alpha dv: out3 = scaled objective, sum |c|, mu x barrier sum there */
 int pc_ipm_trial(pc_ipm* s, double alpha, double mu, double* out3);
+/* Second-order correction after pc_ipm_trial rejected the step of size alpha (IPOPT's A-5.7 .. A-5.9, which the reference's
+ * solver applies inside ipopt.Problem.solve, backend.py:1711): the factorisation of the last pc_ipm_newton solved again for the
+ * constraint values alpha c + c(trial) (first != 0) or alpha c_soc + c(trial) of the previous corrected trial; the corrected step
+ * replaces the Newton step for pc_ipm_trial / pc_ipm_accept.  out8 as pc_ipm_newton's.  pc_ipm_soc_restore puts the Newton step
+ * back when the corrections were rejected. */
+int pc_ipm_soc(pc_ipm* s, double alpha, int first, double mu, double tau, double* out8);
+int pc_ipm_soc_restore(pc_ipm* s, double mu, double tau);
 /* accept the last trial point: v, lambda (+= alpha), z (+= alpha_z, kept near the central path); grad J, jac_g at the new v */
 int pc_ipm_accept(pc_ipm* s, double alpha, double alpha_z, double mu);
 

@@ -19,7 +19,7 @@ struct pc_ipm {
   int64_t n = 0, m = 0, ns = 0, nv = 0, nu = 0, ngj = 0;
   double sf = 1.0;
   DevBuf<double> v, lam, zl, zu, vl, vu, sc, rhs_c, g, c, ct, vt, sol, dzl, dzu, Sigma, gphi, dvec, dvec_true, rhs, jtl, lams, mvx,
-      gradnz, ft, part, red;
+      gradnz, ft, part, red, csoc, sol0;   // csoc / sol0: second-order correction (its constraint values, the Newton step kept aside)
   DevBuf<uint8_t> hasl, hasu, fixed;
   DevBuf<int32_t> slack_of_row;   // [m] slack index of an inequality row, -1 for an equality row
   DevBuf<int64_t> gcol;           // [ngj] x index of every structural non-zero of grad J
@@ -212,6 +212,19 @@ __global__ void __launch_bounds__(256) ipm_trial_point(const double* __restrict_
   }
   ipm_reduce<1>(val, op, part, counter, out);
 }
+// second-order correction: c_soc = alpha c_prev + c(trial) (c_prev: c at the current point the first time, c_soc after), and the
+// constraint part of the right-hand side = -c_soc
+__global__ void ipm_soc_rhs(const double* __restrict__ c, const double* __restrict__ ct, double* __restrict__ csoc, double alpha, int first,
+                            double* __restrict__ rhs_c, int64_t m) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = alpha * (first ? c[i] : csoc[i]) + ct[i];
+    csoc[i] = v;
+    rhs_c[i] = -v;
+  }
+}
+__global__ void ipm_neg(const double* __restrict__ c, double* __restrict__ out, int64_t m) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) out[i] = -c[i];
+}
 // theta = sum |c|, max |c|
 __global__ void __launch_bounds__(256) ipm_theta(const double* __restrict__ c, int64_t m, double* part, unsigned* counter, double* out) {
   double val[2] = {0.0, 0.0};
@@ -310,8 +323,8 @@ int pc_ipm_create(pc_handle* h, pc_kkt* k, const pc_ipm_desc* d, pc_ipm** out) {
     if (gcol.empty()) gcol.push_back(0);
     s->gcol.upload(gcol);
     for (DevBuf<double>* b : {&s->v, &s->zl, &s->zu, &s->g, &s->vt, &s->dzl, &s->dzu, &s->Sigma, &s->gphi}) b->alloc(nv);
-    for (DevBuf<double>* b : {&s->lam, &s->c, &s->ct, &s->lams}) b->alloc(m);
-    for (DevBuf<double>* b : {&s->sol, &s->dvec, &s->dvec_true, &s->rhs, &s->jtl, &s->mvx}) b->alloc(nu);
+    for (DevBuf<double>* b : {&s->lam, &s->c, &s->ct, &s->lams, &s->csoc}) b->alloc(m);
+    for (DevBuf<double>* b : {&s->sol, &s->dvec, &s->dvec_true, &s->rhs, &s->jtl, &s->mvx, &s->sol0}) b->alloc(nu);
     s->gradnz.alloc(gcol.size());
     s->ft.alloc(2);
     s->part.alloc((size_t)IPM_BLOCKS * IPM_NRED);
@@ -463,6 +476,44 @@ int pc_ipm_trial(pc_ipm* s, double alpha, double mu, double* out3) {
     out3[0] = s->sf * r[2];
     out3[1] = r[0];
     out3[2] = mu * r[4];
+  });
+}
+
+// Second-order correction (ipm.py, IPOPT A-5.7 .. A-5.9) after pc_ipm_trial rejected the step of size `alpha`: the same
+// factorisation solved for the constraint values c_soc = alpha c + c(trial) (first != 0), or alpha c_soc + c(trial) of the
+// previous corrected trial; the corrected step replaces the Newton step (kept aside: pc_ipm_soc_restore), the bound
+// multipliers' step and the limits follow it.  out8 as pc_ipm_newton's (0: unused).
+int pc_ipm_soc(pc_ipm* s, double alpha, int first, double mu, double tau, double* out8) {
+  return guarded([&] {
+    if (!s || !out8) throw std::runtime_error("null argument");
+    require_device(s->h);
+    hipStream_t st = s->h->stream;
+    const unsigned gu = ipm_grid(s->nu);
+    if (first) HIP_OK(hipMemcpyAsync(s->sol0.p, s->sol.p, (size_t)s->nu * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(ipm_soc_rhs, dim3(ipm_grid(s->m)), dim3(256), 0, st, s->c.p, s->ct.p, s->csoc.p, alpha, first, s->rhs.p + s->nv, s->m);
+    int32_t ns_ = 0;
+    if (!pc_kkt_solve_refined_device(s->k, 1, s->dvec_true.p, s->rhs.p, 3, s->sol.p, &ns_)) throw std::runtime_error(pc_kkt_last_error());
+    hipLaunchKernelGGL(ipm_step_kernel, dim3(gu), dim3(256), 0, st, s->sol.p, s->v.p, s->vl.p, s->vu.p, s->zl.p, s->zu.p, s->hasl.p,
+                       s->hasu.p, s->fixed.p, s->gphi.p, mu, tau, s->dzl.p, s->dzu.p, s->nv, s->m, s->part.p, s->counter.p, s->red.p);
+    double r[6];
+    ipm_fetch(s, 6, r);
+    out8[0] = 0.0; out8[1] = r[0]; out8[2] = std::min(r[1], r[2]); out8[3] = r[3]; out8[4] = mu * r[4];
+    out8[5] = 0.0; out8[6] = ns_; out8[7] = r[5];
+  });
+}
+
+// the corrections were rejected: the Newton step, its right-hand side and its bound-multiplier steps back in place
+int pc_ipm_soc_restore(pc_ipm* s, double mu, double tau) {
+  return guarded([&] {
+    if (!s) throw std::runtime_error("null argument");
+    require_device(s->h);
+    hipStream_t st = s->h->stream;
+    HIP_OK(hipMemcpyAsync(s->sol.p, s->sol0.p, (size_t)s->nu * sizeof(double), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(ipm_neg, dim3(ipm_grid(s->m)), dim3(256), 0, st, s->c.p, s->rhs.p + s->nv, s->m);
+    hipLaunchKernelGGL(ipm_step_kernel, dim3(ipm_grid(s->nu)), dim3(256), 0, st, s->sol.p, s->v.p, s->vl.p, s->vu.p, s->zl.p, s->zu.p, s->hasl.p,
+                       s->hasu.p, s->fixed.p, s->gphi.p, mu, tau, s->dzl.p, s->dzu.p, s->nv, s->m, s->part.p, s->counter.p, s->red.p);
+    double r[6];
+    ipm_fetch(s, 6, r);
   });
 }
 

@@ -58,8 +58,9 @@ class IpmResult:
 class InteriorPointSolver:
     def __init__(self, problem_obj, n: int, m: int, lb, ub, cl, cu, tol: float = 1e-8, acceptable_tol: float = 1e-6,
                  max_iter: int = 300, mu_init: float = 0.1, verbose: int = 0, warm_start: bool = False,
-                 gradient_scaling: bool = True):
+                 gradient_scaling: bool = True, second_order_correction: bool = True):
         self.p, self.n, self.m = problem_obj, int(n), int(m)
+        self.second_order_correction = bool(second_order_correction)
         # IPOPT's warm_start_init_point (the one thing pycollo's warm_start setting switches, backend.py:1703-1709):
         # the starting point is kept closer to where it was given -- bound push / fraction 1e-3 instead of 1e-2
         # (warm_start_bound_push, warm_start_bound_frac).  No multipliers are handed over: the reference passes none.
@@ -210,6 +211,7 @@ class InteriorPointSolver:
             if good or (dw >= 1e20 and sol is not None and np.all(np.isfinite(sol))):
                 full = np.zeros(self.nv)
                 full[fr] = sol[:nv]
+                self._last_factor = (lu, K)      # (second-order corrections solve with it again: _resolve_kkt)
                 return full, sol[nv:], dw
             # wrong inertia / curvature (or singular): raise the primal regularisation, IPOPT's delta_w schedule
             if dw == 0.0:
@@ -219,6 +221,23 @@ class InteriorPointSolver:
             if dw > 1e20:
                 break
         raise RuntimeError("KKT regularisation failed")
+
+    def _resolve_kkt(self, r1, r2, v=None, lam=None):
+        """Another right-hand side for the matrix ``_solve_kkt`` factorised last (second-order correction); ``v``, ``lam``:
+        the point the matrix belongs to (for a subclass whose matrix lives where trial evaluations overwrite it)."""
+        lu, K = self._last_factor
+        rhs = np.concatenate([r1[self.free], r2])
+        sol = lu.solve(rhs)
+        res = rhs - K @ sol
+        for _ in range(2):
+            trial = sol + lu.solve(res)
+            res_t = rhs - K @ trial
+            if not np.all(np.isfinite(trial)) or np.linalg.norm(res_t) >= 0.5 * np.linalg.norm(res):
+                break
+            sol, res = trial, res_t
+        full = np.zeros(self.nv)
+        full[self.free] = sol[:self.nf]
+        return full, sol[self.nf:]
 
     def _JT(self, J, lam):
         """J^T lambda over v = [x ; s]."""
@@ -362,6 +381,20 @@ class InteriorPointSolver:
             dphi = float(grad_phi @ dv)
             alpha, accepted = a_max, False
             a_min = 1e-12
+
+            def acceptable(alpha_, ft_, th_t_, phi_t_):
+                """The filter's verdict on a trial point reached with step size alpha_ (IPOPT A-5.4 .. A-5.8); a point
+                accepted by the sufficient-decrease test augments the filter (returned as the second value)."""
+                if not (np.isfinite(ft_) and np.isfinite(th_t_) and np.isfinite(phi_t_) and th_t_ <= theta_max):
+                    return False, False
+                if any(th_t_ >= th_f and phi_t_ >= ph_f for th_f, ph_f in filt):
+                    return False, False
+                if dphi < 0 and alpha_ * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min:
+                    return phi_t_ <= phi + eta * alpha_ * dphi, False
+                ok = th_t_ <= (1 - g_th) * theta or phi_t_ <= phi - g_phi * theta
+                return ok, ok
+
+            first = True
             while alpha > a_min:
                 vt = v + alpha * dv
                 with np.errstate(all="ignore"):
@@ -369,18 +402,54 @@ class InteriorPointSolver:
                     ct = self._c(vt)
                     th_t = float(np.sum(np.abs(ct)))
                     phi_t = self._barrier(vt, ft, mu)
-                if np.isfinite(ft) and np.isfinite(th_t) and np.isfinite(phi_t) and th_t <= theta_max:
-                    in_filter = any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt)
-                    if not in_filter:
-                        switching = dphi < 0 and alpha * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min
-                        if switching:
-                            if phi_t <= phi + eta * alpha * dphi:
-                                accepted = True
-                        elif th_t <= (1 - g_th) * theta or phi_t <= phi - g_phi * theta:
-                            accepted = True
-                            filt.append(((1 - g_th) * theta, phi - g_phi * theta))
-                        if accepted:
+                accepted, augment = acceptable(alpha, ft, th_t, phi_t)
+                if self.verbose >= 2 and first:
+                    print(f"      first trial: alpha {alpha:.2e} theta {theta:.3e} -> {th_t:.3e}  phi {phi:.10e} -> {phi_t:.10e}  dphi {dphi:.3e} "
+                          f"switching {dphi < 0 and alpha * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min} theta_min {theta_min:.1e} "
+                          f"in filter {any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt)} accepted {accepted}")
+                if accepted:
+                    if augment:
+                        filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                    break
+                if first and self.second_order_correction and np.isfinite(th_t) and th_t >= theta:
+                    # Second-order correction (IPOPT A-5.7 .. A-5.9): the full step was rejected and did not even reduce
+                    # the violation -- the linearisation of c is what fails.  Up to four corrected steps from the same
+                    # factorisation, each aimed at the violation the previous trial point was left with.
+                    c_soc, th_old, a_soc = alpha * c + ct, theta, alpha
+                    for _ in range(4):
+                        self.counts["second_order_corrections"] = self.counts.get("second_order_corrections", 0) + 1
+                        try:
+                            dv_s, dlam_s = self._resolve_kkt(-(grad_phi + JTlam), -c_soc, v, lam)
+                        except RuntimeError:
                             break
+                        if not (np.all(np.isfinite(dv_s)) and np.all(np.isfinite(dlam_s))):
+                            break
+                        a_soc = self._alpha_max(v, dv_s, tau)
+                        vs = v + a_soc * dv_s
+                        with np.errstate(all="ignore"):
+                            fs = self._f(vs[:n])
+                            cs = self._c(vs)
+                            th_s = float(np.sum(np.abs(cs)))
+                            phi_s = self._barrier(vs, fs, mu)
+                        ok_s, augment = acceptable(alpha, fs, th_s, phi_s)
+                        if self.verbose >= 2:
+                            print(f"      correction: alpha {a_soc:.2e} theta -> {th_s:.3e}  phi -> {phi_s:.10e}  accepted {ok_s}")
+                        if ok_s:
+                            if augment:
+                                filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                            accepted, dv, dlam, alpha, vt, ft, ct = True, dv_s, dlam_s, a_soc, vs, fs, cs
+                            dzl = np.where(self.hasl, mu / dlv - zl - zl / dlv * dv, 0.0)
+                            dzu = np.where(self.hasu, mu / duv - zu + zu / duv * dv, 0.0)
+                            a_z = min(self._alpha_dual(zl[self.hasl], dzl[self.hasl], tau) if self.hasl.any() else 1.0,
+                                      self._alpha_dual(zu[self.hasu], dzu[self.hasu], tau) if self.hasu.any() else 1.0)
+                            self.counts["second_order_steps"] = self.counts.get("second_order_steps", 0) + 1
+                            break
+                        if not np.isfinite(th_s) or th_s > 0.99 * th_old:
+                            break
+                        c_soc, th_old = a_soc * c_soc + cs, th_s
+                    if accepted:
+                        break
+                first = False
                 alpha *= 0.5
             phase["line_search"] += time.perf_counter() - t_ph
             if not accepted and e0 <= self.acceptable_tol:
@@ -557,6 +626,7 @@ class GpuInteriorPointSolver(InteriorPointSolver):
                 with np.errstate(all="ignore"):
                     sol = self._refined_solve(rhs, np.concatenate([Sigma + dw, np.full(m, -dc)]), True)
                 if np.all(np.isfinite(sol)):
+                    self._last_dvec = np.concatenate([Sigma + dw, np.full(m, -dc)])
                     return np.where(self.fixed, 0.0, sol[:nv]), sol[nv:], dw
             if dw >= 1e20:
                 break
@@ -565,6 +635,15 @@ class GpuInteriorPointSolver(InteriorPointSolver):
             else:
                 dw *= 100.0 if dw_last == 0.0 else 8.0
         raise RuntimeError("KKT regularisation failed")
+
+    def _resolve_kkt(self, r1, r2, v=None, lam=None):
+        nv = self.nv
+        # the callbacks evaluate G~ with every new point (pc_engine.hip::ensure_fcG), the trial points included: the
+        # refinement's matrix-vector products need G~ / H~ of the point the factors belong to again
+        self.engine.evaluate_resident(v[:self.n], self.sf, self.sc * lam, want_grad=False)
+        with np.errstate(all="ignore"):
+            sol = self._refined_solve(np.concatenate([np.where(self.fixed, 0.0, r1), r2]), self._last_dvec, True)
+        return np.where(self.fixed, 0.0, sol[:nv]), sol[nv:]
 
     def _ls_multipliers(self, J, gz):
         lam = np.zeros(self.m)
@@ -631,7 +710,7 @@ class ResidentInteriorPointSolver(GpuInteriorPointSolver):
         t_start = time.perf_counter()
         lib = self.engine._lib
         for name in ("pc_ipm_create", "pc_ipm_set_state", "pc_ipm_get_state", "pc_ipm_eval_point", "pc_ipm_errors",
-                     "pc_ipm_newton", "pc_ipm_trial", "pc_ipm_accept"):
+                     "pc_ipm_newton", "pc_ipm_trial", "pc_ipm_accept", "pc_ipm_soc", "pc_ipm_soc_restore"):
             getattr(lib, name).restype = C.c_int
         lib.pc_ipm_destroy.restype = None
         lib.pc_ipm_destroy.argtypes = [C.c_void_p]
@@ -643,6 +722,8 @@ class ResidentInteriorPointSolver(GpuInteriorPointSolver):
         lib.pc_ipm_newton.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p]
         lib.pc_ipm_trial.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         lib.pc_ipm_accept.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        lib.pc_ipm_soc.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        lib.pc_ipm_soc_restore.argtypes = [C.c_void_p, C.c_double, C.c_double]
 
         def check(ok):
             if not ok:
@@ -769,24 +850,61 @@ class ResidentInteriorPointSolver(GpuInteriorPointSolver):
             t_ph = time.perf_counter()
             alpha, accepted = a_max, False
             ft = th_t = phi_t = np.nan
-            while alpha > 1e-12:
+
+            def acceptable(alpha_, ft_, th_t_, phi_t_):
+                # (InteriorPointSolver.solve's test; the second value says the filter is to be augmented)
+                if not (np.isfinite(ft_) and np.isfinite(th_t_) and np.isfinite(phi_t_) and th_t_ <= theta_max):
+                    return False, False
+                if any(th_t_ >= th_f and phi_t_ >= ph_f for th_f, ph_f in filt):
+                    return False, False
+                if dphi < 0 and alpha_ * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min:
+                    return phi_t_ <= phi + eta * alpha_ * dphi, False
+                ok = th_t_ <= (1 - g_th) * theta or phi_t_ <= phi - g_phi * theta
+                return ok, ok
+
+            def trial(a):
                 self.counts["objective"] += 1
                 self.counts["constraints"] += 1
-                check(lib.pc_ipm_trial(handle, alpha, mu, r3.ctypes.data))
-                ft, th_t = float(r3[0]), float(r3[1])
-                phi_t = ft + float(r3[2])
-                if np.isfinite(ft) and np.isfinite(th_t) and np.isfinite(phi_t) and th_t <= theta_max:
-                    in_filter = any(th_t >= th_f and phi_t >= ph_f for th_f, ph_f in filt)
-                    if not in_filter:
-                        switching = dphi < 0 and alpha * (-dphi) ** 2.3 > theta ** 1.1 and theta <= theta_min
-                        if switching:
-                            if phi_t <= phi + eta * alpha * dphi:
-                                accepted = True
-                        elif th_t <= (1 - g_th) * theta or phi_t <= phi - g_phi * theta:
-                            accepted = True
-                            filt.append(((1 - g_th) * theta, phi - g_phi * theta))
-                        if accepted:
+                check(lib.pc_ipm_trial(handle, a, mu, r3.ctypes.data))
+                return float(r3[0]), float(r3[1]), float(r3[0]) + float(r3[2])
+
+            first = True
+            while alpha > 1e-12:
+                ft, th_t, phi_t = trial(alpha)
+                accepted, augment = acceptable(alpha, ft, th_t, phi_t)
+                if self.verbose >= 2 and first:
+                    print(f"      first trial: alpha {alpha:.2e} theta {theta:.3e} -> {th_t:.3e}  phi {phi:.10e} -> {phi_t:.10e}  dphi {dphi:.3e} accepted {accepted}")
+                if accepted:
+                    if augment:
+                        filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                    break
+                if first and self.second_order_correction and np.isfinite(th_t) and th_t >= theta:
+                    # second-order correction on the device (pc_ipm_soc): up to four corrected steps from the same factors
+                    th_old, a_soc, r8s = theta, alpha, np.empty(8)
+                    for p_soc in range(4):
+                        self.counts["second_order_corrections"] = self.counts.get("second_order_corrections", 0) + 1
+                        check(lib.pc_ipm_soc(handle, a_soc, 1 if p_soc == 0 else 0, mu, tau, r8s.ctypes.data))
+                        self.counts["kkt_solves"] = self.counts.get("kkt_solves", 0) + int(r8s[6])
+                        if r8s[7] != 0.0:
                             break
+                        a_soc = float(r8s[1])
+                        fs, th_s, phi_s = trial(a_soc)
+                        ok_s, augment = acceptable(alpha, fs, th_s, phi_s)
+                        if self.verbose >= 2:
+                            print(f"      correction: alpha {a_soc:.2e} theta -> {th_s:.3e}  phi -> {phi_s:.10e}  accepted {ok_s}")
+                        if ok_s:
+                            if augment:
+                                filt.append(((1 - g_th) * theta, phi - g_phi * theta))
+                            accepted, alpha, a_z, ft, th_t, phi_t = True, a_soc, float(r8s[2]), fs, th_s, phi_s
+                            self.counts["second_order_steps"] = self.counts.get("second_order_steps", 0) + 1
+                            break
+                        if not np.isfinite(th_s) or th_s > 0.99 * th_old:
+                            break
+                        th_old = th_s
+                    if accepted:
+                        break
+                    check(lib.pc_ipm_soc_restore(handle, mu, tau))
+                first = False
                 alpha *= 0.5
             phase["line_search"] += time.perf_counter() - t_ph
             if not accepted and e0 <= self.acceptable_tol:

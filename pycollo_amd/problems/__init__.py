@@ -153,10 +153,19 @@ def shuttle(K: int = 10, order: int = 4) -> ProblemSpec:
     return prob
 
 
-def delta_iii(K: int = 10, order: int = 4) -> ProblemSpec:
+def delta_iii(K: int = 10, order: int = 4, *, burnout_mass: bool = False) -> ProblemSpec:
     """Betts ex. 6.15 Delta III ascent, 4 phases, 18 linkage constraints;
     examples/delta_iii_launch_vehicle/delta_iii_launch_vehicle.py:198-459.
-    7 states, 3 controls, 2 path constraints per phase; all phase times fixed."""
+    7 states, 3 controls, 2 path constraints per phase; all phase times fixed.
+
+    As the example stands the NLP is **infeasible**: phase D's mass is pinned to 23 464 kg at 261 s and to the payload's
+    4 164 kg at 961 s, while its state equation burns T / (g_0 I) = 24.03 kg/s for those 700 s -- 16 820 kg, the second
+    stage's propellant, not the 19 300 kg between the two pins (the difference is the stage's 2 480 kg of structure,
+    which Betts' problem drops only because there the burn ends at a *free* final time).  Every mass defect row of phase
+    D keeps the same residual whatever the solver does (2 480 kg; phases A-C are off by about a gram, of either sign: the
+    rounding of the tabulated propellant masses against thrust / specific impulse).  ``burnout_mass=True`` is the minimal repair: the
+    final mass of a phase is what its burn leaves -- bounded by the example's figure (less 1 kg) from below instead of
+    being pinned to it; same functions, same code object."""
     r_x, r_y, r_z, v_x, v_y, v_z, m = sym.symbols("r_x r_y r_z v_x v_y v_z m")
     u_x, u_y, u_z = sym.symbols("u_x u_y u_z")
     D_x, D_y, D_z, T, xi, C_D, S, omega_E = sym.symbols("D_x D_y D_z T xi C_D S omega_E")
@@ -207,11 +216,11 @@ def delta_iii(K: int = 10, order: int = 4) -> ProblemSpec:
         ph.bounds.final_time = tb
         ph.bounds.state_variables = {r_x: [-2 * R_E_val, 2 * R_E_val], r_y: [-2 * R_E_val, 2 * R_E_val],
                                      r_z: [-2 * R_E_val, 2 * R_E_val], v_x: [-10000, 10000],
-                                     v_y: [-10000, 10000], v_z: [-10000, 10000], m: [m_b, m_a]}
+                                     v_y: [-10000, 10000], v_z: [-10000, 10000], m: [m_b - (1.0 if burnout_mass else 0.0), m_a]}
         ph.bounds.control_variables = {u_x: [-1.1, 1.1], u_y: [-1.1, 1.1], u_z: [-1.1, 1.1]}
         ph.bounds.path_constraints = [[0, 0], [0, "inf"]]
         ph.bounds.initial_state_constraints = {m: m_a}
-        ph.bounds.final_state_constraints = {m: m_b}
+        ph.bounds.final_state_constraints = {m: [m_b - 1.0, m_a] if burnout_mass else m_b}
         # guess: at rest on the pad, mass linear, constant steering (delta_iii_launch_vehicle.py:273-281; the
         # example's later phases reuse phase B's time span in their guess, here each phase gets its own)
         vy0 = omega_val * R_E_val * np.cos(psi_L_val)
@@ -624,4 +633,42 @@ def with_refined_mesh(prob: ProblemSpec, nodes_per_phase: int, seeds=None) -> Pr
         ph.mesh.number_mesh_sections = int(nodes.size)
         ph.mesh.mesh_section_sizes = sizes
         ph.mesh.number_mesh_section_nodes = nodes
+    return prob
+
+
+def delta_iii_flown_guess(prob: ProblemSpec, points: int = 60) -> ProblemSpec:
+    """Replace the guess of :func:`delta_iii` by a trajectory that was actually flown: the equations of motion of the
+    example (delta_iii_launch_vehicle.py:198-459) integrated phase after phase from the pad with the thrust along the
+    local vertical, ``points`` samples per phase.  The example's own guess -- the vehicle standing on the pad for all
+    four phases -- has zero air speed under the drag term's square root, i.e. NaN partial derivatives at every node,
+    and violates the dynamics everywhere; this one satisfies dynamics, mass schedule, linkages and path constraints, so
+    an interior-point solve starts feasible."""
+    from scipy.integrate import solve_ivp
+    mu, R_E, om, h_0, rho_0, C_D, S = 3.986012e14, 6378145.0, 7.29211585e-5, 7200.0, 1.225, 0.5, 4 * np.pi
+    T, xi = sym.symbols("T xi")
+
+    def rhs(thrust, mdot):
+        def f(t, y):
+            r, v, m = y[:3], y[3:6], y[6]
+            rn = np.linalg.norm(r)
+            vr = v - np.array([-om * r[1], om * r[0], 0.0])
+            drag = -0.5 * C_D * S * rho_0 * np.exp(-(rn - R_E) / h_0) * np.linalg.norm(vr) * vr
+            return np.concatenate([v, -mu / rn**3 * r + thrust / m * (r / rn) + drag / m, [-mdot]])
+        return f
+
+    y_end = None
+    for ph in prob.phases:
+        ta, tb = float(ph.bounds.initial_time), float(ph.bounds.final_time)
+        m_a = float(ph.guess.state_variables[6][0])
+        y0 = np.array([ph.guess.state_variables[i][0] for i in range(7)], float) if y_end is None else np.append(y_end[:6], m_a)
+        thrust, mdot = float(ph.auxiliary_data[T]), float(ph.auxiliary_data[xi])
+        t = np.linspace(ta, tb, points)
+        sol = solve_ivp(rhs(thrust, mdot), (ta, tb), y0, t_eval=t, rtol=1e-10, atol=1e-6)
+        if not sol.success:
+            raise RuntimeError(f"phase {ph.name}: the guess trajectory could not be integrated: {sol.message}")
+        y = sol.y
+        ph.guess.time = t
+        ph.guess.state_variables = y
+        ph.guess.control_variables = y[:3] / np.linalg.norm(y[:3], axis=0)
+        y_end = y[:, -1]
     return prob

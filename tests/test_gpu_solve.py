@@ -165,3 +165,43 @@ def test_parity_on_the_mesh_the_refinement_loop_ends_on(built, name):
     for got, ref in ((eng.evaluate_G_structure(), ora.G_structure()), (eng.evaluate_H_structure(), ora.H_structure())):
         np.testing.assert_array_equal(got[0], ref[0])
         np.testing.assert_array_equal(got[1], ref[1])
+
+
+def test_delta_iii_solved_end_to_end(built):
+    """BASELINE.json configs[4]'s model (examples/delta_iii_launch_vehicle/delta_iii_launch_vehicle.py; the reference has
+    no integration test for it).  As published the example is infeasible (tests/test_delta_iii_cpu.py); with the final
+    mass of a phase left to its burn and a flown guess the build's own loop -- interior-point iteration on the device,
+    GPU mesh-error estimate, ph refinement -- meets the reference's default mesh tolerance: final altitude 2 681.144 km
+    (the value the host factorisation reaches as well, tools/solve_delta_iii.py --linear-solver host)."""
+    from pycollo_amd.solve import solve_ocp
+    prob = problems.delta_iii_flown_guess(problems.delta_iii(burnout_mass=True))
+    res = solve_ocp(prob, max_mesh_iterations=15)
+    assert res.mesh_tolerance_met is True
+    assert res.gpu_linear_solver_gave_up == []
+    np.testing.assert_allclose(res.objective, -2681144.0, rtol=2e-6)
+    assert all(r["status"] in ("optimal", "acceptable") for r in res.iterations)
+    assert res.iterations[-1]["status"] == "optimal"
+    # the refinement acted where the trajectory bends: the first and the last stage, not the coasting middle
+    K = res.iterations[-1]["K"]
+    assert K[0] > 10 and K[3] > 10
+
+
+def test_delta_iii_as_published_is_infeasible(built):
+    """The same solve on the example as it stands ends where IPOPT's would, at a point of local infeasibility: the mass
+    defect rows of phase D keep, section by section, their share of the 2 480 kg its two pinned masses are apart from its burn."""
+    from pycollo_amd.iteration import MeshIteration
+    prob = problems.delta_iii_flown_guess(problems.delta_iii())
+    it = MeshIteration(prob, device=0)
+    res = it.solve_with_ipm(max_iter=200, tol=1e-10)
+    assert not res.success
+    assert res.inf_pr > 1e-3
+    c = it.engine.evaluate_all(it.x_tilde, 1.0, np.zeros(it.engine.num_c))[0]
+    pl = it.layout.phases[3]
+    rows = c[pl.c_off + 6 * (pl.N - 1):pl.c_off + 7 * (pl.N - 1)]               # mass defect rows of phase D
+    share = rows.reshape(10, 3).sum(axis=1)                                      # per mesh section (10 sections of 4 nodes)
+    assert np.ptp(share) < 1e-5 * np.max(np.abs(share)) and np.min(np.abs(share)) > 1e-3   # every section misses its tenth
+    mask = np.zeros(c.size, bool)
+    for q in it.layout.phases:
+        mask[q.c_off:q.c_path_off] = True                                       # every defect row ...
+    mask[pl.c_off + 6 * (pl.N - 1):pl.c_off + 7 * (pl.N - 1)] = False           # ... but those
+    assert np.max(np.abs(rows)) > 100 * np.max(np.abs(c[mask]))
