@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--linear-solver", default="resident")
     ap.add_argument("--example-guess", action="store_true", help="the example's own guess (on the pad): NaN partials")
     ap.add_argument("--as-published", action="store_true", help="phase D's final mass pinned to the payload: infeasible")
+    ap.add_argument("--refine-to", type=int, default=0, metavar="NODES",
+                    help="after the mesh tolerance is met: tighten it a decade at a time, solving again from the last solution, "
+                         "until the meshes hold this many nodes (BASELINE.json configs[4]: 'refinement to ~50k nodes')")
     ap.add_argument("--verbose", type=int, default=1)
     ap.add_argument("--save", default="")
     args = ap.parse_args()
@@ -43,6 +46,28 @@ def main():
         print(f"  {i + 1}: K {r['K']} N {r['N']} total {sum(r['N'])} J {r['objective']:.10g} {r['status']} "
               f"{r['nlp_iterations']} NLP iterations {r['seconds']:.2f} s, max rel. mesh error {r['max_rel_err']:.3e}")
     it = res.final
+    while args.refine_to and sum(int(pl.N) for pl in it.layout.phases) < args.refine_to and tol > 1e-16:
+        tol *= 0.1
+        import copy
+        nxt = copy.deepcopy(prob)
+        taus, ys, us, _, _, _ = it.solution()
+        for ph, mesh, tau, y, u in zip(nxt.phases, it.meshes, taus, ys, us):
+            ta, tb = float(ph.bounds.initial_time), float(ph.bounds.final_time)
+            ph.guess.time = 0.5 * (ta + tb) + 0.5 * (tb - ta) * np.asarray(tau)
+            ph.guess.state_variables, ph.guess.control_variables = y, u
+            ph.mesh.number_mesh_sections = int(mesh.K)
+            ph.mesh.mesh_section_sizes = np.asarray(mesh.sizes, float)
+            ph.mesh.number_mesh_section_nodes = np.asarray(mesh.n, np.int64)
+        t0 = time.perf_counter()
+        res = solve_ocp(nxt, max_mesh_iterations=args.max_mesh_iterations, mesh_tolerance=tol, nlp_tol=args.nlp_tol,
+                        nlp_max_iter=args.nlp_max_iter, verbose=args.verbose, linear_solver=args.linear_solver, warm_start=True)
+        it = res.final
+        last = res.iterations[-1]
+        print(f"tolerance {tol:.0e}: {'met' if res.mesh_tolerance_met else 'NOT met'} after {res.mesh_iterations} mesh iterations, "
+              f"K {last['K']} N {last['N']} total {sum(last['N'])}, J {res.objective:.10g}, {time.perf_counter() - t0:.1f} s", flush=True)
+        if not all(r["status"] in ("optimal", "acceptable") for r in res.iterations):
+            print("  an NLP solve failed:", [r["status"] for r in res.iterations])
+            break
     orders = [np.unique(np.asarray(m.n), return_counts=True) for m in it.meshes]
     print("  final mesh orders per phase:", [{int(o): int(c) for o, c in zip(*oc)} for oc in orders])
     if args.save:
