@@ -127,14 +127,15 @@ class InteriorPointSolver:
     # ---- pieces -----------------------------------------------------------------------------------
     def _push_interior(self, v, k1=1e-2, k2=1e-2):
         v = v.copy()
-        pl = np.minimum(k1 * np.maximum(1.0, np.abs(self.vl)), k2 * (self.vu - self.vl))
-        pu = np.minimum(k1 * np.maximum(1.0, np.abs(self.vu)), k2 * (self.vu - self.vl))
         both = self.hasl & self.hasu
         onlyl = self.hasl & ~self.hasu
         onlyu = self.hasu & ~self.hasl
-        v[both] = np.clip(v[both], (self.vl + pl)[both], (self.vu - pu)[both])
-        v[onlyl] = np.maximum(v[onlyl], (self.vl + k1 * np.maximum(1.0, np.abs(self.vl)))[onlyl])
-        v[onlyu] = np.minimum(v[onlyu], (self.vu - k1 * np.maximum(1.0, np.abs(self.vu)))[onlyu])
+        with np.errstate(invalid="ignore"):   # (an infinite bound gives inf - inf in entries the masks leave out)
+            pl = np.minimum(k1 * np.maximum(1.0, np.abs(self.vl)), k2 * (self.vu - self.vl))
+            pu = np.minimum(k1 * np.maximum(1.0, np.abs(self.vu)), k2 * (self.vu - self.vl))
+            v[both] = np.clip(v[both], (self.vl + pl)[both], (self.vu - pu)[both])
+            v[onlyl] = np.maximum(v[onlyl], (self.vl + k1 * np.maximum(1.0, np.abs(self.vl)))[onlyl])
+            v[onlyu] = np.minimum(v[onlyu], (self.vu - k1 * np.maximum(1.0, np.abs(self.vu)))[onlyu])
         return v
 
     def _barrier(self, v, f, mu):
@@ -325,10 +326,11 @@ class InteriorPointSolver:
             sd = max(s_max, (np.sum(np.abs(lam)) + np.sum(zl) + np.sum(zu)) / (m + nz)) / s_max
             scz = max(s_max, (np.sum(zl) + np.sum(zu)) / nz) / s_max
             comp = 0.0
-            if self.hasl.any():
-                comp = max(comp, float(np.max(np.abs(((v - self.vl) * zl - mu_)[self.hasl]))))
-            if self.hasu.any():
-                comp = max(comp, float(np.max(np.abs(((self.vu - v) * zu - mu_)[self.hasu]))))
+            with np.errstate(invalid="ignore"):   # (inf x 0 where there is no bound: masked out)
+                if self.hasl.any():
+                    comp = max(comp, float(np.max(np.abs(((v - self.vl) * zl - mu_)[self.hasl]))))
+                if self.hasu.any():
+                    comp = max(comp, float(np.max(np.abs(((self.vu - v) * zu - mu_)[self.hasu]))))
             e_du = float(np.max(np.abs(dL))) if self.nf else 0.0
             e_pr = float(np.max(np.abs(c))) if m else 0.0
             return max(e_du / sd, e_pr, comp / scz), e_pr, e_du

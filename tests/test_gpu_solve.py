@@ -45,16 +45,16 @@ def test_space_shuttle_solution(built):
 
 def test_free_flying_robot_solution(built):
     """tests/integration/test_free_flying_robot.py:186-204.  At the reference's settings (mesh tolerance 1e-5, at most 15
-    mesh iterations) the refinement stops on a ~100-node mesh whose NLP optimum is 7.9113: a bang-bang solution's
-    objective moves by +-7e-4 from one such mesh to the next (7.9109 .. 7.9122 over the last six meshes), so which side
-    of the reference's rtol = 1e-4 the run ends on is decided by the mesh sequence, i.e. by the NLP solver's iterates
-    (IPOPT there, the stand-in here) -- 5e-4 is asserted at those settings.  That the path converges to the published
-    value is asserted where it can be: with the mesh tolerance one decade tighter the run ends at 7.91027, inside the
-    reference's own rtol = 1e-4 of both published values."""
+    mesh iterations) the refinement stops on a 95-node mesh whose NLP optimum is 7.91133, 1.4e-4 above the published values
+    (7.9114 on the 90-node mesh the host factorisation's route ends on): a bang-bang solution's objective moves by a few
+    1e-4 from one such mesh to the next, so which side of the reference's rtol = 1e-4 the run ends on is decided by the mesh
+    sequence, i.e. by the NLP solver's iterates (IPOPT there, the stand-in here) -- 2e-4 is asserted at those settings.  That the path converges to the published value is asserted
+    where it can be: with the mesh tolerance one decade tighter the run ends inside the reference's own rtol = 1e-4 of
+    both published values."""
     from pycollo_amd.solve import solve_ocp
     res = solve_ocp(problems.free_flying_robot(), mesh_tolerance=1e-5, max_mesh_iterations=15)
-    assert np.isclose(res.objective, 7.9101902, rtol=5e-4, atol=0.0)
-    assert np.isclose(res.objective, 7.910154646, rtol=5e-4, atol=0.0)
+    assert np.isclose(res.objective, 7.9101902, rtol=2e-4, atol=0.0)
+    assert np.isclose(res.objective, 7.910154646, rtol=2e-4, atol=0.0)
     assert res.mesh_tolerance_met is True
     assert res.gpu_linear_solver_gave_up == []          # every NLP was solved with the GPU factorisation
     fine = solve_ocp(problems.free_flying_robot(), mesh_tolerance=1e-6, max_mesh_iterations=20)
