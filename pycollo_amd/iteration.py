@@ -147,7 +147,8 @@ class MeshIteration:
         # "resident": the GPU factorisation AND the iteration's vectors on the device (csrc/pc_ipm.hpp)
         cls = {"gpu": GpuInteriorPointSolver, "host": InteriorPointSolver, "resident": ResidentInteriorPointSolver}[linear_solver]
         solver = cls(pobj, pobj.n, pobj.m, self.x_bnd_l, self.x_bnd_u, self.c_bnd_l, self.c_bnd_u,
-                     tol=tol, max_iter=max_iter, verbose=verbose, warm_start=warm_start)
+                     tol=tol, max_iter=max_iter, verbose=verbose, warm_start=warm_start,
+                     second_order_correction=os.environ.get("PYCOLLO_AMD_SOC", "1") != "0")   # (A/B knob: IPOPT's max_soc = 0)
         # The model's SymPy graphs are millions of long-lived objects: a full collection walking them takes ~80 ms and
         # strikes in the middle of whichever linear solve allocates the unlucky array (measured: 8 such stalls in
         # an 18-iteration solve, more than all factorisations together).  Collection is off for the duration.
