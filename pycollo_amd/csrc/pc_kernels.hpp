@@ -337,12 +337,48 @@ typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 #ifndef PC_FLUSH_DEPTH
 #define PC_FLUSH_DEPTH 4
 #endif
+#ifndef PC_FLUSH_BUFFER
+#define PC_FLUSH_BUFFER 1
+#endif
+typedef int pc_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
                                           int TB) {
   // The length is the same in every lane, but on a mesh of mixed orders it is computed from LDS tables, i.e. in a vector
   // register: the compiler then treats the batch loop and the chunk tests below as divergent (exec-mask loops).
   len = __builtin_amdgcn_readfirstlane(len);
   if (len <= 0) return;
+#if PC_FLUSH_BUFFER
+  // The stores go through a buffer descriptor of exactly `len` doubles: the hardware's range check is per dword
+  // (tools/bufstore_probe.hip: every length and both alignments on gfx950), so the partial last store instruction, its odd
+  // last element and the lanes beyond the run's end need no predicate -- no compares, no exec-mask save / restore, no
+  // separate 8-byte tail.  The check covers the vector offset and the immediate, not the scalar offset: everything that
+  // varies is in the vector offset.  (The predicated version below was 35 % of the instructions of a Delta III tile body.)
+  const unsigned long long d64 = (unsigned long long)dst;
+  double* base = (double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d64 >> 32)) << 32) |
+                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)d64));
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, len * 8, 0x00020000);
+  const int pairs = (len + 1) >> 1;
+  const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + tid;
+  int voff = 16 * tid;
+  int b0 = 0;
+  for (; b0 + PC_FLUSH_DEPTH * TB <= pairs; b0 += PC_FLUSH_DEPTH * TB, voff += PC_FLUSH_DEPTH * TB * 16) {
+    pc_d2_a8 a[PC_FLUSH_DEPTH];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[b0 + q * TB];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pc_i4, a[q]), rs, voff + q * TB * 16, 0, 0);
+  }
+  if (b0 < pairs) {   // the last, partial batch: all its LDS reads first (past the run's end they fetch what is never stored)
+    pc_d2_a8 a[PC_FLUSH_DEPTH];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[b0 + q * TB];
+#pragma unroll
+    for (int q = 0; q < PC_FLUSH_DEPTH; ++q)
+      if (b0 + q * TB < pairs)   // (wave-uniform: a scalar branch around a chunk that lies wholly past the end)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pc_i4, a[q]), rs, voff + q * TB * 16, 0, 0);
+  }
+#else
   const int pairs = len >> 1;
   const bool odd = (len & 1) && tid == 0;
   double last = 0.0;
@@ -379,6 +415,7 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
     }
   }
   if (odd) dst[len - 1] = last;
+#endif
 }
 
 // The same copy for a run staged in pieces: `nq` chunks of L doubles lie back to back in LDS and go to dst, dst + GS,
@@ -392,6 +429,42 @@ template <int L, int GS>
 __device__ __forceinline__ void flush_chunks(double* __restrict__ dst, const double* __restrict__ src, int nq, int t, int TN) {
   nq = __builtin_amdgcn_readfirstlane(nq);
   if (nq <= 0) return;
+#if PC_FLUSH_BUFFER
+  if (TN == 64) {
+    // as flush_run: a descriptor of exactly one chunk (its base advances in scalar registers), the last store instruction
+    // of a chunk cut by the range check instead of a lane mask
+    constexpr int NR = (L + 127) / 128;
+    const unsigned long long d64 = (unsigned long long)dst;
+    double* base = (double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d64 >> 32)) << 32) |
+                             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)d64));
+    const double* sp = src + 2 * t;
+    const int voff = 16 * t;
+    pc_d2_a8 a[NR], nx[NR];
+    auto fetch = [&](pc_d2_a8* r, const double* p) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) r[i] = *reinterpret_cast<const pc_d2_a8*>(p + 128 * i);
+    };
+    auto store = [&](const pc_d2_a8* r, double* b) {
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, L * 8, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < NR; ++i) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pc_i4, r[i]), rs, voff + 1024 * i, 0, 0);
+    };
+    // two chunks per trip, the two register sets taking turns (no copies): the next chunk's LDS reads are issued before
+    // this chunk's stores
+    fetch(a, sp);
+    int q = 0;
+    for (; q + 2 <= nq; q += 2) {
+      fetch(nx, sp + L);
+      store(a, base);
+      if (q + 2 < nq) fetch(a, sp + 2 * L);
+      store(nx, base + GS);
+      sp += 2 * L;
+      base += 2 * GS;
+    }
+    if (q < nq) store(a, base);
+    return;
+  }
+#endif
   if (TN == 64) {
     constexpr int FULL = L / 128, REM = L % 128, NR = FULL + (REM > 0 ? 1 : 0);
     const double* sp = src + 2 * t;
