@@ -329,16 +329,13 @@ __device__ __forceinline__ void lds_barrier() {
 // wave instruction), counted from the run's FIRST element.  A run starts wherever the CSR layout puts it (8-byte
 // granularity): the 16-byte stores are simply issued at that address -- global memory takes them unaligned, a wave's
 // 64 stores still cover one contiguous KiB -- and the LDS side is read as two 8-byte halves.  Every batch of
-// PC_FLUSH_DEPTH wave-instructions issues ALL its LDS reads before the first store, and the odd last element rides
-// with the first batch: a run costs one LDS round trip per batch and nothing else.  (Measured and dropped, records in
-// profiles/r03_ab_*.txt: an alignment peel, a software-pipelined batch loop, non-temporal stores, a predicate on every
-// store.)
+// PC_FLUSH_DEPTH wave-instructions issues ALL its LDS reads before the first store: a run costs one LDS round trip per
+// batch and nothing else.  (Measured and dropped, records in profiles/r03_ab_*.txt: an alignment peel, a
+// software-pipelined batch loop, non-temporal stores, a predicate on every store; superseded in round 4,
+// profiles/r04_flush_buffer_ab.txt: lane predicates on the partial chunk and a separate odd last element.)
 typedef double pc_d2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 #ifndef PC_FLUSH_DEPTH
 #define PC_FLUSH_DEPTH 4
-#endif
-#ifndef PC_FLUSH_BUFFER
-#define PC_FLUSH_BUFFER 1
 #endif
 typedef int pc_i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double* __restrict__ src, int len, int tid,
@@ -347,12 +344,11 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
   // register: the compiler then treats the batch loop and the chunk tests below as divergent (exec-mask loops).
   len = __builtin_amdgcn_readfirstlane(len);
   if (len <= 0) return;
-#if PC_FLUSH_BUFFER
   // The stores go through a buffer descriptor of exactly `len` doubles: the hardware's range check is per dword
   // (tools/bufstore_probe.hip: every length and both alignments on gfx950), so the partial last store instruction, its odd
   // last element and the lanes beyond the run's end need no predicate -- no compares, no exec-mask save / restore, no
   // separate 8-byte tail.  The check covers the vector offset and the immediate, not the scalar offset: everything that
-  // varies is in the vector offset.  (The predicated version below was 35 % of the instructions of a Delta III tile body.)
+  // varies is in the vector offset.  (The predicated version was 35 % of the instructions of a Delta III tile body.)
   const unsigned long long d64 = (unsigned long long)dst;
   double* base = (double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(d64 >> 32)) << 32) |
                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)d64));
@@ -378,58 +374,19 @@ __device__ __forceinline__ void flush_run(double* __restrict__ dst, const double
       if (b0 + q * TB < pairs)   // (wave-uniform: a scalar branch around a chunk that lies wholly past the end)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pc_i4, a[q]), rs, voff + q * TB * 16, 0, 0);
   }
-#else
-  const int pairs = len >> 1;
-  const bool odd = (len & 1) && tid == 0;
-  double last = 0.0;
-  if (odd) last = src[len - 1];
-  int b0 = 0;   // first pair of the batch: wave-uniform, so the loop and the choice below are scalar branches
-  // full batches: every lane reads and stores, nothing is predicated (a predicated store is a compare, an exec-mask
-  // save / restore and a branch around one instruction: two thirds of the flush's instructions when every store had one)
-  for (; b0 + PC_FLUSH_DEPTH * TB <= pairs; b0 += PC_FLUSH_DEPTH * TB) {
-    const pc_d2_a8* sp = reinterpret_cast<const pc_d2_a8*>(src) + (b0 + tid);
-    pc_d2_a8* dp = reinterpret_cast<pc_d2_a8*>(dst) + (b0 + tid);
-    pc_d2_a8 a[PC_FLUSH_DEPTH];
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = sp[q * TB];
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) dp[q * TB] = a[q];
-  }
-  if (b0 < pairs) {   // the last, partial batch
-    const int e0 = b0 + tid;
-    pc_d2_a8 a[PC_FLUSH_DEPTH];
-    // (unconditional reads at clamped indices: a read under `if` makes its register a conditional definition, and the
-    //  compiler then waits for LDS before every single read)
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) a[q] = *reinterpret_cast<const pc_d2_a8*>(src + 2 * min(e0 + q * TB, pairs - 1));
-    // chunk q of the batch is full, partial or empty -- a wave-uniform fact (scalar compares and branches); only the
-    // one partial chunk stores under a lane predicate
-#pragma unroll
-    for (int q = 0; q < PC_FLUSH_DEPTH; ++q) {
-      const int c0 = b0 + q * TB;
-      if (c0 + TB <= pairs) {
-        *reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)) = a[q];
-      } else if (c0 < pairs) {
-        if (c0 + tid < pairs) *reinterpret_cast<pc_d2_a8*>(dst + 2 * (c0 + tid)) = a[q];
-      }
-    }
-  }
-  if (odd) dst[len - 1] = last;
-#endif
 }
 
 // The same copy for a run staged in pieces: `nq` chunks of L doubles lie back to back in LDS and go to dst, dst + GS,
 // dst + 2 GS, ... (pc::bulk, "row groups": chunk = the rows of one pass of one section, GS = all rows of a section).
 // One chunk at a time, in a scalar loop: a wave moves a chunk with ceil(L / 128) 16-byte store instructions whose lane
-// offsets never change (the chunk's base advances in scalar registers) and whose last one carries a compile-time lane
-// mask -- two instructions per KiB, like flush_run.  (A first version mapped staging element e to chunk e / L per lane:
+// offsets never change (the chunk's base advances in scalar registers) and whose last one is cut by the descriptor's
+// range check -- two instructions per KiB, like flush_run.  (A first version mapped staging element e to chunk e / L per lane:
 // eight address instructions per store, a third more instructions in the whole tile body -- Delta III order 5, two
 // passes: 23.3 -> 34.2 us.)  The next chunk's LDS reads are issued before this chunk's stores.
 template <int L, int GS>
 __device__ __forceinline__ void flush_chunks(double* __restrict__ dst, const double* __restrict__ src, int nq, int t, int TN) {
   nq = __builtin_amdgcn_readfirstlane(nq);
   if (nq <= 0) return;
-#if PC_FLUSH_BUFFER
   if (TN == 64) {
     // as flush_run: a descriptor of exactly one chunk (its base advances in scalar registers), the last store instruction
     // of a chunk cut by the range check instead of a lane mask
@@ -462,34 +419,6 @@ __device__ __forceinline__ void flush_chunks(double* __restrict__ dst, const dou
       base += 2 * GS;
     }
     if (q < nq) store(a, base);
-    return;
-  }
-#endif
-  if (TN == 64) {
-    constexpr int FULL = L / 128, REM = L % 128, NR = FULL + (REM > 0 ? 1 : 0);
-    const double* sp = src + 2 * t;
-    double* dp = dst + 2 * t;
-    pc_d2_a8 a[NR], nx[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) a[i] = *reinterpret_cast<const pc_d2_a8*>(sp + 128 * i);
-    for (int q = 0; q < nq; ++q) {
-      if (q + 1 < nq) {
-#pragma unroll
-        for (int i = 0; i < NR; ++i) nx[i] = *reinterpret_cast<const pc_d2_a8*>(sp + L + 128 * i);
-      }
-#pragma unroll
-      for (int i = 0; i < FULL; ++i) *reinterpret_cast<pc_d2_a8*>(dp + 128 * i) = a[i];
-      if constexpr (REM > 1) {
-        if (2 * t + 1 < REM) *reinterpret_cast<pc_d2_a8*>(dp + 128 * FULL) = a[FULL];
-      }
-      if constexpr (REM % 2 == 1) {
-        if (2 * t == REM - 1) dp[128 * FULL] = a[FULL].x;
-      }
-      sp += L;
-      dp += GS;
-#pragma unroll
-      for (int i = 0; i < NR; ++i) a[i] = nx[i];
-    }
     return;
   }
   // wider workgroups (tiles of 128 / 256 nodes): the same per chunk, a runtime stride
