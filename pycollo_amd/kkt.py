@@ -80,17 +80,38 @@ class KktTables:
     mv_coef: np.ndarray
 
 
-def _node_maps(engine, group):
-    """Per phase: leaf boundaries (every ``group``-th section boundary), node -> (is boundary, leaf index)."""
+def _node_maps(engine, group, cuts=None):
+    """Per phase: leaf boundaries (every ``group``-th section boundary, restarting at every cut), node -> (is boundary,
+    leaf index), and the chain numbering.  ``cuts[ip]``: interior section-boundary nodes at which the phase's chain is cut
+    (the sharded factorisation, kkt_sharded.py): a cut node's unknowns go to the border, and the node stands in the
+    chain twice with no unknowns -- as the last node of the segment on its left and the first of the one on its right --
+    so every segment is a chain of its own, exactly like a phase.
+
+    Returns per phase (s, N, is_b, sec, is_cut, chain_id, leaf_left, n_chain, seg_ptr): ``chain_id[i]`` the chain node of
+    boundary i (the left copy of a cut), ``leaf_left[j]`` the chain node on the left of leaf j, both counted from the
+    phase's first chain node; ``seg_ptr`` the first chain node of every segment and one past the last."""
     out = []
-    for mesh, g in zip(engine.meshes, group):
+    for ip, (mesh, g) in enumerate(zip(engine.meshes, group)):
         s_all = np.asarray(mesh.s, dtype=np.int64)
-        s = np.unique(np.concatenate([s_all[::g], s_all[-1:]]))
+        cut = np.zeros(0, np.int64) if cuts is None else np.unique(np.asarray(cuts[ip], dtype=np.int64))
+        kc = np.searchsorted(s_all, cut)
+        if len(cut) and (np.any(kc >= len(s_all)) or np.any(s_all[np.minimum(kc, len(s_all) - 1)] != cut)
+                         or cut[0] <= 0 or cut[-1] >= s_all[-1]):
+            raise ValueError(f"phase {ip}: a cut must be an interior section boundary")
+        edges = np.concatenate([[0], kc, [len(s_all) - 1]]).astype(np.int64)
+        s = np.unique(np.concatenate([s_all[a:b:g] for a, b in zip(edges[:-1], edges[1:])] + [s_all[-1:]]))
         N = int(s[-1]) + 1
         is_b = np.zeros(N, bool)
         is_b[s] = True
         sec = np.searchsorted(s, np.arange(N), side="right") - 1      # section whose start <= node
-        out.append((s, N, is_b, sec))
+        is_cut = np.isin(s, cut)
+        upto = np.cumsum(is_cut)
+        before = upto - is_cut
+        chain_id = np.arange(len(s), dtype=np.int64) + before
+        leaf_left = (np.arange(len(s) - 1, dtype=np.int64) + upto[:-1]).astype(np.int64)
+        n_chain = len(s) + int(is_cut.sum())
+        seg_ptr = np.concatenate([[0], chain_id[is_cut] + 1, [n_chain]]).astype(np.int64)
+        out.append((s, N, is_b, sec, is_cut, chain_id, leaf_left, n_chain, seg_ptr))
     return out
 
 
@@ -121,10 +142,13 @@ class _Plan(C.Structure):
                 ("wc", C.POINTER(C.c_int64)), ("last_of_phase", C.POINTER(C.c_uint8))]
 
 
-def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: str = "library") -> KktTables:
+def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: str = "library", cuts=None,
+                 _parts: dict | None = None) -> KktTables:
     """``ineq_rows``: constraint rows with a slack (in order); ``fixed_v`` [n + ns]: primal unknowns held fixed;
     ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise); ``group``: mesh sections per leaf
-    (int or one per phase; default ``default_group``)."""
+    (int or one per phase; default ``default_group``); ``cuts``: per phase the nodes at which the chain is cut
+    (``_node_maps``; ``n_phase`` of the result then counts chain segments).  ``_parts``: filled with the classification
+    and the entry list, for ``kkt_sharded``."""
     lay, model = engine.layout, engine.model
     if group is None:
         group = default_group(engine, ineq_rows)
@@ -136,11 +160,13 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     nv, nu = n + ns, n + ns + m
     fixed = np.zeros(nu, bool)
     fixed[:nv] = np.asarray(fixed_v, bool)
-    maps = _node_maps(engine, group)
-    n_phase = len(lay.phases)
-    chain_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) for mp in maps])]).astype(np.int64)
+    maps = _node_maps(engine, group, cuts)
+    chain_base = np.concatenate([[0], np.cumsum([mp[7] for mp in maps])]).astype(np.int64)   # first chain node of a phase
     leaf_phase_ptr = np.concatenate([[0], np.cumsum([len(mp[0]) - 1 for mp in maps])]).astype(np.int64)
-    n_chain, n_leaf = int(chain_phase_ptr[-1]), int(leaf_phase_ptr[-1])
+    n_chain, n_leaf = int(chain_base[-1]), int(leaf_phase_ptr[-1])
+    # the chain's independent pieces: a phase, or with cuts a segment of one (what the tables call a phase of the chain)
+    chain_phase_ptr = np.concatenate([chain_base[ip] + mp[8][:-1] for ip, mp in enumerate(maps)] + [chain_base[-1:]]).astype(np.int64)
+    n_phase = len(chain_phase_ptr) - 1
 
     cls = np.full(nu, BORDER, np.int8)
     blk = np.zeros(nu, np.int64)
@@ -151,16 +177,17 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     dual[nv:] = True
 
     def place_nodes(u, ip, nodes):
-        s, N, is_b, sec = maps[ip]
+        s, N, is_b, sec, is_cut, chain_id = maps[ip][:6]
         b = is_b[nodes]
-        cls[u] = np.where(b, CHAIN, LEAF)
-        blk[u] = np.where(b, chain_phase_ptr[ip] + sec[nodes], leaf_phase_ptr[ip] + sec[nodes])
+        k = sec[nodes]
+        cls[u] = np.where(b, np.where(is_cut[k], BORDER, CHAIN), LEAF)
+        blk[u] = np.where(b, chain_base[ip] + chain_id[k], leaf_phase_ptr[ip] + k)
         key_node[u] = nodes
 
     row_slack = np.full(m, -1, np.int64)
     row_slack[ineq_rows] = np.arange(ns)
     for ip, (pl, pm) in enumerate(zip(lay.phases, model.phases)):
-        s, N, is_b, sec = maps[ip]
+        N = maps[ip][1]
         nz = pm.n_z
         u = pl.x_off + np.arange(nz * N, dtype=np.int64)
         place_nodes(u, ip, (u - pl.x_off) % N)
@@ -187,6 +214,38 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     cls[promoted] = BORDER
     blk[cls == BORDER] = 0
     key_node[cls == BORDER] = 0
+    leaf_left = np.concatenate([chain_base[ip] + mp[6] for ip, mp in enumerate(maps)]).astype(np.int64) \
+        if n_leaf else np.zeros(0, np.int64)
+    jr, jc = (np.asarray(a, np.int64) for a in engine.evaluate_G_structure())
+    if _parts is not None:
+        _parts.update(cls=cls.copy(), blk=blk.copy(), key_node=key_node.copy(), key_kind=key_kind.copy(), dual=dual.copy(),
+                      fixed=fixed.copy(), n=n, m=m, ns=ns, nv=nv, nu=nu, n_leaf=n_leaf, n_chain=n_chain,
+                      chain_phase_ptr=chain_phase_ptr.copy(), leaf_left=leaf_left.copy(), maps=maps, chain_base=chain_base,
+                      leaf_phase_ptr=leaf_phase_ptr, hr=hr, hc=hc, jr=jr, jc=jc, group=list(group))
+    return _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
+                   chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows)
+
+
+def natural_entries(n, nv, hr, hc, jr, jc, row_scale, ineq_rows):
+    """Lower-triangle entries of K over natural unknowns as (row, column, source kind, source index, coefficient):
+    H~, the row-scaled G~, the -1 of every slack."""
+    ns = len(ineq_rows)
+    eu = np.concatenate([hr, nv + jr, nv + ineq_rows])
+    ev = np.concatenate([hc, jc, n + np.arange(ns, dtype=np.int64)])
+    ekind = np.concatenate([np.full(len(hr), SRC_H), np.full(len(jr), SRC_G), np.full(ns, SRC_ONE)]).astype(np.int32)
+    eidx = np.concatenate([np.arange(len(hr)), np.arange(len(jr)), np.zeros(ns, np.int64)]).astype(np.int64)
+    ecoef = np.concatenate([np.ones(len(hr)), np.asarray(row_scale, float)[jr], -np.ones(ns)])
+    return eu, ev, ekind, eidx, ecoef
+
+
+def _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
+            chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows, entries=None, n_primal=None, n_dual=None):
+    """Block order, value-buffer layout and entry tables of a classified system.  ``entries``: the lower-triangle entries
+    (``natural_entries`` form, fixed unknowns already dropped) when the system is not a whole NLP's (a rank's part of a
+    sharded factorisation: ``positions`` must then be "positions" or "numpy")."""
+    n_phase = len(chain_phase_ptr) - 1
+    n_primal = nv if n_primal is None else n_primal
+    n_dual = m if n_dual is None else n_dual
     # block order
     order = np.lexsort((key_idx, key_kind, key_node, dual, blk, cls))
     perm = order.astype(np.int64)
@@ -205,8 +264,6 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     local[is_chain] = pos[is_chain] - base_chain - chain_ptr[blk[is_chain]]
     local[is_border] = pos[is_border] - base_border
 
-    leaf_left = np.concatenate([chain_phase_ptr[ip] + np.arange(len(maps[ip][0]) - 1) for ip in range(n_phase)]).astype(np.int64) \
-        if n_leaf else np.zeros(0, np.int64)
     nzb = counts_chain.astype(np.int64)
     last_of_phase = np.zeros(n_chain, bool)
     last_of_phase[chain_phase_ptr[1:] - 1] = True
@@ -230,7 +287,6 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     total = o + nb * nb
 
     # ---- matrix entries (natural unknown pairs), lower triangle of K ------------------------------------------
-    jr, jc = (np.asarray(a, np.int64) for a in engine.evaluate_G_structure())
     def make_plan():
         """The elimination plan as the C structure ``pc_kkt_plan`` (the arrays are kept alive by the caller)."""
         from .engine import load_library
@@ -253,6 +309,8 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
         return lib, P, keep
 
     if positions == "library":
+        if entries is not None:
+            raise ValueError("explicit entries need positions='positions' or 'numpy'")
         # the entry tables in one pass of host C++ (pc_kkt_plan_entries): the NumPy statement below builds them from a
         # dozen entry-sized temporaries, sorts twice and gathers nine times -- 150 ms for 15 k nodes, and several times
         # that whenever the allocator has to fault the temporaries in afresh, which inside a solve is every time
@@ -285,7 +343,7 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
         if not lib.pc_kkt_plan_positions(C.byref(P), nu, ar.ctypes.data, ar.ctypes.data, diag_pos.ctypes.data):
             raise RuntimeError(lib.pc_kkt_last_error().decode())
         return KktTables(
-            nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=nv, n_dual=m,
+            nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=n_primal, n_dual=n_dual,
             perm=perm, leaf_ptr=leaf_ptr, chain_ptr=chain_ptr, chain_phase_ptr=chain_phase_ptr, leaf_left=leaf_left,
             leafA_off=np.asarray(leafA_off, np.int64), leafS_off=np.asarray(leafS_off, np.int64),
             chainD_off=np.asarray(chainD_off, np.int64), chainS_off=np.asarray(chainS_off, np.int64),
@@ -295,13 +353,12 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
 
     # ---- the same in NumPy: the statement of the rule (positions = "numpy" / "positions"; the CPU tests hold the library
     #      against it).  "positions" takes only the position rule from the library, as round 3's first version did.
-    eu = np.concatenate([hr, nv + jr, nv + ineq_rows])
-    ev = np.concatenate([hc, jc, n + np.arange(ns, dtype=np.int64)])
-    ekind = np.concatenate([np.full(len(hr), SRC_H), np.full(len(jr), SRC_G), np.full(ns, SRC_ONE)]).astype(np.int32)
-    eidx = np.concatenate([np.arange(len(hr)), np.arange(len(jr)), np.zeros(ns, np.int64)]).astype(np.int64)
-    ecoef = np.concatenate([np.ones(len(hr)), np.asarray(row_scale, float)[jr], -np.ones(ns)])
-    keep = ~(fixed[eu] | fixed[ev])
-    eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
+    if entries is None:
+        eu, ev, ekind, eidx, ecoef = natural_entries(n, nv, hr, hc, jr, jc, row_scale, ineq_rows)
+        keep = ~(fixed[eu] | fixed[ev])
+        eu, ev, ekind, eidx, ecoef = eu[keep], ev[keep], ekind[keep], eidx[keep], ecoef[keep]
+    else:
+        eu, ev, ekind, eidx, ecoef = entries
 
     def dest_library(u, v):
         """The same rule as ``dest_numpy`` below in one pass of host C++ (``pc_kkt_plan_positions``): the vectorised form
@@ -382,7 +439,7 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     mv_ptr = np.concatenate([[0], np.cumsum(np.bincount(ru, minlength=nu))]).astype(np.int64)
 
     return KktTables(
-        nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=nv, n_dual=m,
+        nu=nu, nv=nv, n_leaf=n_leaf, n_chain=n_chain, n_phase=n_phase, nb=nb, n_primal=n_primal, n_dual=n_dual,
         perm=perm, leaf_ptr=leaf_ptr, chain_ptr=chain_ptr, chain_phase_ptr=chain_phase_ptr, leaf_left=leaf_left,
         leafA_off=np.asarray(leafA_off, np.int64), leafS_off=np.asarray(leafS_off, np.int64),
         chainD_off=np.asarray(chainD_off, np.int64), chainS_off=np.asarray(chainS_off, np.int64),
