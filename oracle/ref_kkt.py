@@ -51,8 +51,9 @@ def _source_values(kind, idx, G, H, use_H):
 
 
 class RefKkt:
-    def __init__(self, T: KktTables):
+    def __init__(self, T: KktTables, G=None, H=None):
         self.T = T
+        self.G, self.H = G, H          # the values the partial entry points read (a rank's own, NaN elsewhere)
         self.m_l = np.diff(T.leaf_ptr)
         self.nzb = np.diff(T.chain_ptr)
         last = np.zeros(T.n_chain, bool)
@@ -139,9 +140,43 @@ class RefKkt:
                 M[:, nz:] = X
                 self.chainM[c] = M
                 Bd += carry[nx:, nx:]
+        self.B_unfactored = Bd.copy()
+        self.partial_counts = (int(npos), int(nneg))
+        if getattr(self, "_partial", False):        # (factor_partial: the border is factorised elsewhere)
+            return self.partial_counts
         self.Bd = Bd.copy()
         p, q = _ldl_inplace(self.Bd, nb)
         return int(npos + p), int(nneg + q)
+
+    # ---- a rank's part of a factorisation cut across ranks (pycollo_amd/kkt_sharded.py; pc_kkt_*_partial) -----------
+    def factor_partial(self, dvec, use_H=True):
+        """(border block with every Schur complement added, not factorised; pivots of leaves and chain)."""
+        self._partial = True
+        try:
+            self.factor(self.G, self.H, dvec, use_H)
+        finally:
+            self._partial = False
+        return self.B_unfactored, *self.partial_counts
+
+    def border_load_factor(self, B):
+        B = np.asarray(B, float)
+        self.Bd = np.tril(B) + np.tril(B, -1).T
+        return _ldl_inplace(self.Bd, self.T.nb)
+
+    def forward_partial(self, rhs):
+        self._stop_at_border = True
+        try:
+            return self.solve(rhs)
+        finally:
+            self._stop_at_border = False
+
+    def backward_partial(self, xb):
+        self._xb_given = np.asarray(xb, float)
+        try:
+            x = self.solve(self._rhs_kept)
+        finally:
+            self._xb_given = None
+        return x
 
     def solve(self, rhs):
         T = self.T
@@ -172,7 +207,13 @@ class RefKkt:
                 rc[c + 1] -= g[:nx]
             rb -= g[nx:]
             tc[c] = _solve_ldl(M, nz, rc[c][:, None])[:, 0]
-        xb = _solve_ldl(self.Bd, nb, rb[:, None])[:, 0] if nb else rb
+        if getattr(self, "_stop_at_border", False):
+            self._rhs_kept = np.asarray(rhs, float).copy()
+            return rb
+        if getattr(self, "_xb_given", None) is not None:
+            xb = self._xb_given
+        else:
+            xb = _solve_ldl(self.Bd, nb, rb[:, None])[:, 0] if nb else rb
         xc = [None] * T.n_chain
         for c in range(T.n_chain - 1, -1, -1):
             nz, nx = int(self.nzb[c]), int(self.nzb_next[c])

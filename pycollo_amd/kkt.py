@@ -176,7 +176,11 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
     dual = np.zeros(nu, bool)
     dual[nv:] = True
 
+    u_phase = np.full(nu, -1, np.int64)     # the phase and node an unknown sits on (-1: none)
+    u_node = np.full(nu, -1, np.int64)
+
     def place_nodes(u, ip, nodes):
+        u_phase[u], u_node[u] = ip, nodes
         s, N, is_b, sec, is_cut, chain_id = maps[ip][:6]
         b = is_b[nodes]
         k = sec[nodes]
@@ -221,7 +225,7 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
         _parts.update(cls=cls.copy(), blk=blk.copy(), key_node=key_node.copy(), key_kind=key_kind.copy(), dual=dual.copy(),
                       fixed=fixed.copy(), n=n, m=m, ns=ns, nv=nv, nu=nu, n_leaf=n_leaf, n_chain=n_chain,
                       chain_phase_ptr=chain_phase_ptr.copy(), leaf_left=leaf_left.copy(), maps=maps, chain_base=chain_base,
-                      leaf_phase_ptr=leaf_phase_ptr, hr=hr, hc=hc, jr=jr, jc=jc, group=list(group))
+                      leaf_phase_ptr=leaf_phase_ptr, hr=hr, hc=hc, jr=jr, jc=jc, group=list(group), u_phase=u_phase, u_node=u_node)
     return _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
                    chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows)
 
@@ -416,7 +420,7 @@ def _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, 
         raise RuntimeError(f"KKT entry ({eu[bad]}, {ev[bad]}) couples two blocks the elimination order keeps apart")
     so = np.argsort(d, kind="stable")
     d_sorted = d[so]
-    first = np.concatenate([[True], d_sorted[1:] != d_sorted[:-1]])
+    first = np.concatenate([[True], d_sorted[1:] != d_sorted[:-1]]) if len(d) else np.zeros(0, bool)
     dst = d_sorted[first]
     run_ptr = np.concatenate([np.nonzero(first)[0], [len(d_sorted)]]).astype(np.int64)
     diag_pos = dest(np.arange(nu, dtype=np.int64), np.arange(nu, dtype=np.int64))
@@ -465,14 +469,16 @@ class _Desc(C.Structure):
 class GpuKkt:
     """The factorisation object: ``pc_kkt_*`` bound to one engine's device-resident G~ / H~."""
 
-    def __init__(self, engine, ineq_rows, fixed_v, row_scale, group=None):
+    def __init__(self, engine, ineq_rows, fixed_v, row_scale, group=None, tables=None, d_jac=None, d_hess=None):
+        """``tables``: ready-made tables instead of the whole NLP's (a rank's part of a sharded factorisation,
+        kkt_sharded.py); ``d_jac`` / ``d_hess``: device addresses of the G~ / H~ values to read instead of the engine's."""
         from .engine import load_library
         if engine.device < 0:
             raise RuntimeError("the KKT solver needs a GPU engine; pycollo_amd has no CPU fallback")
         self.engine = engine
         import time
         t0 = time.perf_counter()
-        self.tables = T = build_tables(engine, ineq_rows, fixed_v, row_scale, group)
+        self.tables = T = tables if tables is not None else build_tables(engine, ineq_rows, fixed_v, row_scale, group)
         self.seconds_tables = time.perf_counter() - t0          # host: the elimination plan as index tables
         self._lib = lib = load_library()
         vp = C.c_void_p
@@ -485,6 +491,10 @@ class GpuKkt:
         lib.pc_kkt_matvec.argtypes = [vp, C.c_int, vp, vp, vp]
         lib.pc_kkt_solve_refined.argtypes = [vp, C.c_int, vp, vp, C.c_int, vp, C.POINTER(C.c_int32)]
         lib.pc_device_results.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+        lib.pc_kkt_factor_partial.argtypes = [vp, C.c_int, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.pc_kkt_border_load_factor.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        lib.pc_kkt_forward_partial.argtypes = [vp, vp, vp]
+        lib.pc_kkt_backward_partial.argtypes = [vp, vp, vp]
         d = _Desc()
         self._keep = []
         for k in ("nu", "nv", "n_leaf", "n_chain", "n_phase", "nb", "total_vals", "border_off"):
@@ -505,6 +515,10 @@ class GpuKkt:
         dg, dj, dh = vp(), vp(), vp()
         if not lib.pc_device_results(engine._h, C.byref(dg), C.byref(dj), C.byref(dh)):
             raise RuntimeError(lib.pc_last_error().decode())
+        if d_jac is not None:
+            dj = vp(int(d_jac))
+        if d_hess is not None:
+            dh = vp(int(d_hess))
         self._h = vp()
         if not lib.pc_kkt_create(C.byref(d), dj, dh, int(engine.device), C.byref(self._h)):
             raise RuntimeError("pc_kkt_create failed: " + lib.pc_kkt_last_error().decode())
@@ -545,6 +559,43 @@ class GpuKkt:
         self._check(self._lib.pc_kkt_solve_refined(self._h, int(bool(use_hess)), dvec_true.ctypes.data, rhs.ctypes.data,
                                                    int(max_steps), x.ctypes.data, C.byref(n)))
         return x, n.value
+
+    # ---- a rank's part of a factorisation cut across ranks (kkt_sharded.py) ------------------------------------------
+    def factor_partial(self, dvec, use_hess=True):
+        """Assemble, eliminate the leaves and the chain, and return the border block with every Schur complement added
+        but *not* factorised ([nb, nb], lower triangle valid), plus the (positive, negative) pivots so far."""
+        dvec = np.ascontiguousarray(dvec, dtype=np.float64)
+        nb = self.tables.nb
+        B = np.zeros((nb, nb))
+        p, q = C.c_int32(), C.c_int32()
+        self._check(self._lib.pc_kkt_factor_partial(self._h, int(bool(use_hess)), dvec.ctypes.data, B.ctypes.data,
+                                                    C.byref(p), C.byref(q)))
+        return B, p.value, q.value
+
+    def border_load_factor(self, B):
+        """Take the border block as given (lower triangle read) and factorise it; returns its pivot counts."""
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        if B.shape != (self.tables.nb, self.tables.nb):
+            raise ValueError("border block of the wrong shape")
+        p, q = C.c_int32(), C.c_int32()
+        self._check(self._lib.pc_kkt_border_load_factor(self._h, B.ctypes.data, C.byref(p), C.byref(q)))
+        return p.value, q.value
+
+    def forward_partial(self, rhs):
+        """Forward elimination through leaves and chain; returns the border's right-hand side minus what they owe it."""
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        rb = np.empty(self.tables.nb)
+        self._check(self._lib.pc_kkt_forward_partial(self._h, rhs.ctypes.data, rb.ctypes.data))
+        return rb
+
+    def backward_partial(self, xb):
+        """Back-substitution from the given border solution (block order); returns the whole local solution."""
+        xb = np.ascontiguousarray(xb, dtype=np.float64)
+        if xb.shape != (self.tables.nb,):
+            raise ValueError("border solution of the wrong length")
+        x = np.empty(self.nu)
+        self._check(self._lib.pc_kkt_backward_partial(self._h, xb.ctypes.data, x.ctypes.data))
+        return x
 
     def close(self):
         if getattr(self, "_h", None):
