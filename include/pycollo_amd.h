@@ -337,6 +337,23 @@ int pc_kkt_factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t*
 int pc_kkt_matvec_device(pc_kkt* k, int use_hess, const double* d_dvec, const double* d_x, double* d_y);
 int pc_kkt_solve_refined_device(pc_kkt* k, int use_hess, const double* d_dvec_true, const double* d_rhs, int max_steps,
                                 double* d_x, int32_t* n_solves);
+/* A rank's part of a factorisation cut across ranks (the mesh is sharded by contiguous section
+ * ranges, pycollo/mesh.py:297-335 is the partition those follow; pycollo_amd/kkt_sharded.py builds the tables).  The
+ * reference has no counterpart -- IPOPT hands the whole matrix to one MUMPS process (pycollo/backend.py:1703-1711).  The
+ * handle holds the rank's leaves, chain segments and its local border (the NLP's border + the nodes it shares with its
+ * neighbours); G~ / H~ are read where the rank's own tile kernels wrote them.
+ *   pc_kkt_factor_partial      assemble, eliminate leaves and chain; border_out[nb * nb] (host) = the border block with
+ *                              every Schur complement added, NOT factorised, lower triangle valid -- the term this rank adds
+ *                              to the reduced system; pivot counts of leaves and chain
+ *   pc_kkt_border_load_factor  factorise the border block given in border[nb * nb] (lower triangle read) as it stands:
+ *                              the reduced system, in a handle that has a border only
+ *   pc_kkt_forward_partial     forward elimination of rhs[nu]; border_rhs_out[nb] = the border's right-hand side minus what
+ *                              leaves and chain owe it (block order) -- the term this rank adds to the reduced right-hand side
+ *   pc_kkt_backward_partial    back-substitution from border_x[nb] (block order); x[nu] = the local solution */
+int pc_kkt_factor_partial(pc_kkt* k, int use_hess, const double* dvec, double* border_out, int32_t* n_pos, int32_t* n_neg);
+int pc_kkt_border_load_factor(pc_kkt* k, const double* border, int32_t* n_pos, int32_t* n_neg);
+int pc_kkt_forward_partial(pc_kkt* k, const double* rhs, double* border_rhs_out);
+int pc_kkt_backward_partial(pc_kkt* k, const double* border_x, double* x);
 
 /* ---- a device-resident interior-point iteration --------------------------
  * The reference enters its NLP solver once per solve (pycollo/backend.py:1807-1827: ca.nlpsol "ipopt"; legacy

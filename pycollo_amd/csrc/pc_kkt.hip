@@ -629,11 +629,19 @@ __device__ __forceinline__ void border_accumulate(const KArgs& a, int n_entries,
   }
 }
 
+// MODE 0: add every Schur term and factorise; 1: add the terms only (a rank's part of a factorisation cut across ranks:
+// the block goes to the reduced system, pc_kkt_factor_partial); 2: factorise the block as it stands (the reduced system,
+// pc_kkt_border_load_factor)
+template <int MODE>
 __global__ void kkt_border_factor(KArgs a) {
   extern __shared__ double lds[];
   const int nb = a.nb;
   double* B = a.vals + a.border_off;
   double* part = lds + (2 * nb + 2);               // [blockDim.x] partial sums, behind block_eliminate's scratch
+  if constexpr (MODE == 2) {
+    block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
+    return;
+  }
   auto term = [&](int64_t j, int e) -> double {
     if (j < 0) {                                    // total of entry -1 - j sits in part[e]
       const int ent = (int)(-1 - j);
@@ -658,7 +666,7 @@ __global__ void kkt_border_factor(KArgs a) {
   };
   border_accumulate(a, nb * nb, part, term);
   __syncthreads();
-  block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
+  if constexpr (MODE == 0) block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------
@@ -725,6 +733,8 @@ __global__ void kkt_chain_forward(KArgs a) {
   }
 }
 
+// SOLVE false: stop once the border's right-hand side has lost what leaves and chain owe it (pc_kkt_forward_partial)
+template <bool SOLVE>
 __global__ void kkt_border_solve(KArgs a) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nt = blockDim.x, nb = a.nb;
@@ -747,7 +757,7 @@ __global__ void kkt_border_solve(KArgs a) {
   };
   border_accumulate(a, nb, part, term);
   __syncthreads();
-  block_solve(a.vals + a.border_off, nb, nb, lds);
+  if constexpr (SOLVE) block_solve(a.vals + a.border_off, nb, nb, lds);
   for (int i = tid; i < nb; i += nt) rb[i] = lds[i];
 }
 
@@ -861,7 +871,7 @@ static void kwait(hipStream_t st) {
 // (A HIP graph of this string of ~25 launches -- and of the factorisation's ~15 -- was built and measured in round 4:
 //  the interior-point iteration got slower, 1.29 -> 1.39 ms at config 2: the launches are not what it waits for, the
 //  level kernels' own latency is; profiles/r04_ipm_iter_time.txt.  Removed.)
-static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
+static void forward_device(pc_kkt* k, const double* d_rhs) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
   hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, d_rhs, k->perm.p, k->fixed.p, k->r.p, k->nu);
@@ -871,14 +881,23 @@ static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
       const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
       if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
     }
-  } else hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
-  hipLaunchKernelGGL(kkt_border_solve, dim3(1), dim3(256), k->lds_border, st, k->args);
+  } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+}
+static void backward_device(pc_kkt* k, double* d_x);
+static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
+  forward_device(k, d_rhs);
+  hipLaunchKernelGGL(kkt_border_solve<true>, dim3(1), dim3(256), k->lds_border, k->stream, k->args);
+  backward_device(k, d_x);
+}
+static void backward_device(pc_kkt* k, double* d_x) {
+  hipStream_t st = k->stream;
+  const unsigned nbk = (unsigned)((k->nu + 255) / 256);
   if (k->chain_cr) {
     for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
       const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
       if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
     }
-  } else hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+  } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
   if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
   hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, d_x, k->nu);
   KHIP(hipGetLastError());
@@ -1246,7 +1265,9 @@ void pc_kkt_destroy(pc_kkt* k) {
 }
 
 // assembly + factorisation on the handle's stream with the diagonal in device memory; the pivot signs come back
-static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t* n_pos, int32_t* n_neg) {
+// border_mode: kkt_border_factor's MODE (0: the whole factorisation; 1: leaves and chain only, the border block left
+// unfactorised with every Schur term added)
+static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t* n_pos, int32_t* n_neg, int border_mode = 0) {
   {
     hipStream_t st = k->stream;
     KHIP(hipMemsetAsync(k->vals.p, 0, (size_t)k->total * sizeof(double), st));
@@ -1265,13 +1286,15 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
         const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
         if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
       }
-    } else hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
-    hipLaunchKernelGGL(kkt_border_factor, dim3(1), dim3(256), k->lds_border, st, k->args);
+    } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    if (border_mode == 0) hipLaunchKernelGGL(kkt_border_factor<0>, dim3(1), dim3(256), k->lds_border, st, k->args);
+    else hipLaunchKernelGGL(kkt_border_factor<1>, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     KHIP(hipMemcpyAsync(k->h_counts.p, k->counts.p, k->h_counts.n * sizeof(int), hipMemcpyDeviceToHost, st));
     kwait(st);
     int64_t p = 0, q = 0;
-    for (size_t i = 0; i < k->h_counts.n; i += 2) {
+    const size_t n_counts = border_mode == 0 ? k->h_counts.n : k->h_counts.n - 2;   // (the last pair is the border's)
+    for (size_t i = 0; i < n_counts; i += 2) {
       p += k->h_counts.p[i];
       q += k->h_counts.p[i + 1];
     }
@@ -1288,6 +1311,76 @@ int pc_kkt_factor(pc_kkt* k, int use_hess, const double* dvec, int32_t* n_pos, i
     std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
     KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, k->stream));
     factor_device(k, use_hess, k->dvec.p, n_pos, n_neg);
+  });
+}
+
+// ---- a rank's part of a factorisation cut across ranks (pycollo_amd/kkt_sharded.py) --------------------------------
+// The handle holds a rank's leaves, chain segments and local border.  pc_kkt_factor_partial eliminates leaves and chain
+// and hands out the border block with every Schur complement added ([nb][nb] doubles, lower triangle valid) for the
+// reduction over ranks; pc_kkt_border_load_factor factorises a border block given from outside (the reduced system's
+// handle has nothing else); pc_kkt_forward_partial / pc_kkt_backward_partial are the two halves of pc_kkt_solve around
+// the reduced solve.  Host vectors; the matrices stay on the device.
+int pc_kkt_factor_partial(pc_kkt* k, int use_hess, const double* dvec, double* border_out, int32_t* n_pos, int32_t* n_neg) {
+  return guarded([&] {
+    if (!k || !dvec || !border_out) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    std::memcpy(k->h_a.p, dvec, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->dvec.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, k->stream));
+    factor_device(k, use_hess, k->dvec.p, n_pos, n_neg, 1);
+    if (k->nb) {
+      KHIP(hipMemcpyAsync(border_out, k->vals.p + k->args.border_off, (size_t)k->nb * k->nb * sizeof(double),
+                          hipMemcpyDeviceToHost, k->stream));
+      KHIP(hipStreamSynchronize(k->stream));
+    }
+  });
+}
+
+int pc_kkt_border_load_factor(pc_kkt* k, const double* border, int32_t* n_pos, int32_t* n_neg) {
+  return guarded([&] {
+    if (!k || !border) throw std::runtime_error("null argument");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    if (k->nb)
+      KHIP(hipMemcpyAsync(k->vals.p + k->args.border_off, border, (size_t)k->nb * k->nb * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kkt_border_factor<2>, dim3(1), dim3(256), k->lds_border, st, k->args);
+    KHIP(hipGetLastError());
+    int* cnt = k->counts.p + 2 * ((size_t)k->n_leaf + k->n_chain);
+    KHIP(hipMemcpyAsync(k->h_counts.p, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    if (n_pos) *n_pos = k->h_counts.p[0];
+    if (n_neg) *n_neg = k->h_counts.p[1];
+    k->factored = true;
+  });
+}
+
+int pc_kkt_forward_partial(pc_kkt* k, const double* rhs, double* border_rhs_out) {
+  return guarded([&] {
+    if (!k || !rhs || !border_rhs_out) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_forward_partial before a factorisation");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    std::memcpy(k->h_a.p, rhs, k->nu * sizeof(double));
+    KHIP(hipMemcpyAsync(k->vin.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
+    forward_device(k, k->vin.p);
+    hipLaunchKernelGGL(kkt_border_solve<false>, dim3(1), dim3(256), k->lds_border, st, k->args);
+    KHIP(hipGetLastError());
+    if (k->nb) KHIP(hipMemcpyAsync(border_rhs_out, k->r.p + k->args.base_border, (size_t)k->nb * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+  });
+}
+
+int pc_kkt_backward_partial(pc_kkt* k, const double* border_x, double* x) {
+  return guarded([&] {
+    if (!k || !border_x || !x) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_backward_partial before a factorisation");
+    KHIP(hipSetDevice(k->device));
+    hipStream_t st = k->stream;
+    if (k->nb) KHIP(hipMemcpyAsync(k->r.p + k->args.base_border, border_x, (size_t)k->nb * sizeof(double), hipMemcpyHostToDevice, st));
+    backward_device(k, k->vout.p);
+    KHIP(hipGetLastError());
+    KHIP(hipMemcpyAsync(k->h_b.p, k->vout.p, k->nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    KHIP(hipStreamSynchronize(st));
+    std::memcpy(x, k->h_b.p, k->nu * sizeof(double));
   });
 }
 

@@ -328,6 +328,11 @@ class ShardedNlp:
         cg, hp = plan.split()
         self.exchange_cg = SegmentExchange(cg, self.rank, dev, group)
         self.exchange_h = SegmentExchange(hp, self.rank, dev, group)
+        # the per-tile partial sums alone (a few doubles per tile): all a rank needs of the others when its consumer reads
+        # only its own rows (evaluate_local_device; kkt_sharded.py)
+        p0 = oH + plan.nnz_H
+        self.exchange_partials = SegmentExchange(_SubPlan(self.world, [[(a, b) for a, b in seg if a >= p0] for seg in plan.segments]),
+                                                 self.rank, dev, group)
         self.cstream = torch.cuda.Stream(device=dev)       # the exchange's own stream when it overlaps the H~ tiles
         self._ev = [torch.cuda.Event() for _ in range(3)]
         # kernels, torch pack/unpack ops and the collective must share ONE non-default stream (the C ABI maps a
@@ -375,6 +380,22 @@ class ShardedNlp:
                 self.exchange.run(self.buf, root, unpadded)
             if root is None or self.rank == root:
                 eng.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+        return self.c, self.G, self.H
+
+
+    def evaluate_local_device(self, d_x, obj_factor, d_lam, stream=None):
+        """The evaluation for a consumer that reads only this rank's rows (the KKT factorisation cut across ranks,
+        ``kkt_sharded.ShardedKkt``): the rank's tiles, an all-gather of the **per-tile partial sums only**, the tail on
+        every rank.  c~, G~, H~ then hold this rank's runs and the tail's outputs; what other ranks' tiles write is not
+        exchanged and stays whatever the buffer held.  Same stream rules as ``evaluate_all_device``."""
+        import torch
+        cur = torch.cuda.current_stream()
+        ts = cur if cur.cuda_stream != 0 else self.tstream
+        with torch.cuda.stream(ts):
+            self.engine.launch_bulk_only(d_x, d_lam, self.c, self.G, self.H, ts.cuda_stream)
+            if self.world > 1 or self.always_exchange:
+                self.exchange_partials.run(self.buf)
+            self.engine.launch_tail_only(d_x, obj_factor, d_lam, self.c, self.G, self.H, ts.cuda_stream)
         return self.c, self.G, self.H
 
 
