@@ -240,6 +240,11 @@ int pc_launch_bulk_flags_device(pc_handle* h, const double* d_x, const double* d
                                 double* d_hess, int flags, void* stream);
 int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
                           double* d_jac, double* d_hess, void* stream);
+/* pc_launch_tail_device that also returns the objective f and grad_f[n] (host; either may be NULL) and synchronises
+ * `stream`: the eval_f / eval_grad_f of a rank of a sharded solve (pycollo/nlp.py:47-56), whose own tiles never make a
+ * whole evaluation.  obj_factor scales f's part of hess only, as in pc_eval_h. */
+int pc_launch_tail_objective_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
+                                    double* d_jac, double* d_hess, void* stream, double* f, double* grad);
 int pc_synchronize(pc_handle* h);
 
 /* replaces: the sparse row norms inside IterationScaling._calculate_constraint_scaling

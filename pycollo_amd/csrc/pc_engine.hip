@@ -1282,6 +1282,28 @@ int pc_launch_tail_device(pc_handle* h, const double* d_x, double obj_factor, co
   });
 }
 
+// The tail launch of a sharded evaluation that also delivers the objective and its gradient (host): what a solver's
+// objective / gradient callbacks need from a rank that never runs the whole evaluation (pycollo_amd/ipm_sharded.py).
+// Synchronises `stream`.
+int pc_launch_tail_objective_device(pc_handle* h, const double* d_x, double obj_factor, const double* d_lambda, double* d_g,
+                                    double* d_jac, double* d_hess, void* stream, double* f, double* grad) {
+  return guarded([&] {
+    require_device(h);
+    auto& Q = h->Q;
+    h->fc_valid = h->small_synced = h->G_synced = false;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    launch_all(h, d_x, d_lambda, d_g, d_jac, d_hess, h->d_out.p + h->o_f, h->d_out.p + h->o_gn,
+               PC_FLAG_C | PC_FLAG_G | PC_FLAG_H, st, obj_factor, false, true);
+    HIP_OK(hipMemcpyAsync(h->h_out.p, h->d_out.p, (1 + Q.jgrad_col.size()) * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    if (f) *f = h->h_out.p[h->o_f];
+    if (grad) {
+      std::memset(grad, 0, Q.num_x * sizeof(double));
+      for (size_t e = 0; e < Q.jgrad_col.size(); ++e) grad[Q.point_x[Q.jgrad_col[e]]] = h->h_out.p[h->o_gn + e];
+    }
+  });
+}
+
 int pc_set_tile_range(pc_handle* h, int phase, int tile_begin, int tile_end) {
   return guarded([&] {
     if (!h || phase < 0 || phase >= (int)h->pd.size()) throw std::runtime_error("phase out of range");

@@ -334,6 +334,9 @@ struct KArgs {
   double* crbuf;
   const int64_t *cr_a, *cr_b, *crP_off, *crS_off, *crG_off;
   const int64_t* cr_nodes;       // nodes by level, concatenated
+  // wide borders: the border terms pre-summed by a grid (kkt_border_terms); 0 blocks = the border kernels sum them
+  const double* border_part;
+  int32_t border_part_blocks;
 };
 
 __device__ __forceinline__ int nzb_of(const KArgs& a, int64_t c) { return (int)(a.chain_ptr[c + 1] - a.chain_ptr[c]); }
@@ -629,6 +632,49 @@ __device__ __forceinline__ void border_accumulate(const KArgs& a, int n_entries,
   }
 }
 
+// term j (leaf j < n_leaf, else chain node j - n_leaf) of border matrix entry e = i * nb + k (lower triangle, k <= i)
+__device__ __forceinline__ double border_matrix_term(const KArgs& a, int64_t j, int e) {
+  const int nb = a.nb, i = e / nb, k = e % nb;
+  if (k > i) return 0.0;
+  if (j < a.n_leaf) {
+    const int64_t left = a.leaf_left[j];
+    const int ws = nzb_of(a, left) + nzb_of(a, left + 1) + nb, o = ws - nb;
+    return a.vals[a.leafS_off[j] + (size_t)(o + i) * ws + o + k];
+  }
+  const int64_t c = j - a.n_leaf;
+  if (a.cr) {
+    const int o = (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0), wc = o + nb;
+    return a.crbuf[a.crS_off[c] + (size_t)(o + i) * wc + o + k];
+  }
+  const int nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb;
+  return a.vals[a.chainS_off[c] + (size_t)(nx + i) * wc + nx + k];
+}
+// term j of entry e of the border's right-hand side
+__device__ __forceinline__ double border_rhs_term(const KArgs& a, int64_t j, int e) {
+  if (j < a.n_leaf) {
+    const int64_t left = a.leaf_left[j];
+    return a.leafG[a.leafG_off[j] + nzb_of(a, left) + nzb_of(a, left + 1) + e];
+  }
+  const int64_t c = j - a.n_leaf;
+  if (a.cr) return a.crbuf[a.crG_off[c] + (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0) + e];
+  return a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + e];
+}
+// A wide border (a rank's local border in a factorisation cut across ranks carries its cut nodes: tens of unknowns
+// where the NLP's own has one or two) times thousands of leaves is millions of terms -- too many for the one workgroup
+// of the border kernels (5 ms of a 6 ms factorisation at 6 000 shuttle sections cut in two).  Then the terms are summed
+// first by a grid: workgroup b adds the terms b, b + gridDim.x, ... of every entry into part[b][entry]; the border kernel
+// adds the workgroups' sums in workgroup order (a.border_part / a.border_part_blocks) -- fixed order again.
+template <bool RHS>
+__global__ void __launch_bounds__(256) kkt_border_terms(KArgs a, double* __restrict__ part) {
+  const int n_entries = RHS ? a.nb : a.nb * a.nb;
+  const int64_t n_terms = (int64_t)a.n_leaf + a.n_chain;
+  for (int e = threadIdx.x; e < n_entries; e += blockDim.x) {
+    double acc = 0.0;
+    for (int64_t j = blockIdx.x; j < n_terms; j += gridDim.x) acc += RHS ? border_rhs_term(a, j, e) : border_matrix_term(a, j, e);
+    part[(size_t)blockIdx.x * n_entries + e] = acc;
+  }
+}
+
 // MODE 0: add every Schur term and factorise; 1: add the terms only (a rank's part of a factorisation cut across ranks:
 // the block goes to the reduced system, pc_kkt_factor_partial); 2: factorise the block as it stands (the reduced system,
 // pc_kkt_border_load_factor)
@@ -649,24 +695,28 @@ __global__ void kkt_border_factor(KArgs a) {
       if (k <= i) B[ent] += part[e];
       return 0.0;
     }
-    const int i = e / nb, k = e % nb;
-    if (k > i) return 0.0;
-    if (j < a.n_leaf) {
-      const int64_t left = a.leaf_left[j];
-      const int ws = nzb_of(a, left) + nzb_of(a, left + 1) + nb, o = ws - nb;
-      return a.vals[a.leafS_off[j] + (size_t)(o + i) * ws + o + k];
-    }
-    const int64_t c = j - a.n_leaf;
-    if (a.cr) {
-      const int o = (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0), wc = o + nb;
-      return a.crbuf[a.crS_off[c] + (size_t)(o + i) * wc + o + k];
-    }
-    const int nx = a.chain_last[c] ? 0 : nzb_of(a, c + 1), wc = nx + nb;
-    return a.vals[a.chainS_off[c] + (size_t)(nx + i) * wc + nx + k];
+    return border_matrix_term(a, j, e);
   };
-  border_accumulate(a, nb * nb, part, term);
+  if (a.border_part_blocks) {                       // the terms were summed by kkt_border_terms
+    for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
+      if (e % nb > e / nb) continue;
+      double tot = 0.0;
+      for (int b = 0; b < a.border_part_blocks; ++b) tot += a.border_part[(size_t)b * nb * nb + e];
+      B[e] += tot;
+    }
+  } else
+    border_accumulate(a, nb * nb, part, term);
   __syncthreads();
   if constexpr (MODE == 0) block_eliminate(B, nb, 0, nullptr, a.counts + 2 * (a.n_leaf + a.n_chain), lds);
+}
+
+// second stage of kkt_border_terms: entry e of workgroup 0's slot = the sum over workgroups, in workgroup order
+__global__ void __launch_bounds__(256) kkt_border_terms_sum(double* __restrict__ part, int n_entries, int n_blocks) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  double tot = 0.0;
+  for (int b = 0; b < n_blocks; ++b) tot += part[(size_t)b * n_entries + e];
+  part[e] = tot;
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------
@@ -747,15 +797,16 @@ __global__ void kkt_border_solve(KArgs a) {
       lds[(int)(-1 - j)] -= part[e];
       return 0.0;
     }
-    if (j < a.n_leaf) {
-      const int64_t left = a.leaf_left[j];
-      return a.leafG[a.leafG_off[j] + nzb_of(a, left) + nzb_of(a, left + 1) + e];
-    }
-    const int64_t c = j - a.n_leaf;
-    if (a.cr) return a.crbuf[a.crG_off[c] + (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0) + e];
-    return a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + e];
+    return border_rhs_term(a, j, e);
   };
-  border_accumulate(a, nb, part, term);
+  if (a.border_part_blocks) {
+    for (int e = tid; e < nb; e += nt) {
+      double tot = 0.0;
+      for (int b = 0; b < a.border_part_blocks; ++b) tot += a.border_part[(size_t)b * nb + e];
+      lds[e] -= tot;
+    }
+  } else
+    border_accumulate(a, nb, part, term);
   __syncthreads();
   if constexpr (SOLVE) block_solve(a.vals + a.border_off, nb, nb, lds);
   for (int i = tid; i < nb; i += nt) rb[i] = lds[i];
@@ -830,6 +881,8 @@ struct pc_kkt {
   int lds_cr = 0;
   Dev<double> crbuf;
   Dev<int64_t> cr_a, cr_b, crP_off, crS_off, crG_off, cr_nodes;
+  Dev<double> border_part;   // [border_blocks][nb * nb] partial sums of the border terms (wide borders only)
+  int border_blocks = 0;
   int lds_leaf_full = 0;   // LDS of the leaf factorisation: the largest leaf block that fits, plus its staging vectors
   Dev<double> vals, r, leafG, chainG, dvec, vin, vout, src_coef, mv_coef;
   Dev<int64_t> perm, leaf_ptr, chain_ptr, chain_phase_ptr, leaf_left, leafA_off, leafS_off, chainD_off, chainS_off,
@@ -871,6 +924,15 @@ static void kwait(hipStream_t st) {
 // (A HIP graph of this string of ~25 launches -- and of the factorisation's ~15 -- was built and measured in round 4:
 //  the interior-point iteration got slower, 1.29 -> 1.39 ms at config 2: the launches are not what it waits for, the
 //  level kernels' own latency is; profiles/r04_ipm_iter_time.txt.  Removed.)
+// wide borders: the border terms summed by a grid, then across its workgroups; the border kernels read one slot
+template <bool RHS>
+static void border_terms_device(pc_kkt* k) {
+  if (!k->border_blocks) return;
+  const int n_entries = RHS ? k->nb : k->nb * k->nb;
+  hipLaunchKernelGGL(kkt_border_terms<RHS>, dim3(k->border_blocks), dim3(256), 0, k->stream, k->args, k->border_part.p);
+  hipLaunchKernelGGL(kkt_border_terms_sum, dim3((n_entries + 255) / 256), dim3(256), 0, k->stream, k->border_part.p, n_entries, k->border_blocks);
+}
+
 static void forward_device(pc_kkt* k, const double* d_rhs) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
@@ -886,6 +948,7 @@ static void forward_device(pc_kkt* k, const double* d_rhs) {
 static void backward_device(pc_kkt* k, double* d_x);
 static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
   forward_device(k, d_rhs);
+  border_terms_device<true>(k);
   hipLaunchKernelGGL(kkt_border_solve<true>, dim3(1), dim3(256), k->lds_border, k->stream, k->args);
   backward_device(k, d_x);
 }
@@ -1089,6 +1152,10 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       }
     }
     k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2 + 256));
+    if ((int64_t)d->nb * d->nb * (d->n_leaf + d->n_chain) > ((int64_t)1 << 18)) {   // (config 2's own border: 2 x 2 x 1 001 terms)
+      k->border_blocks = (int)std::min<int64_t>(256, d->n_leaf + d->n_chain);
+      k->border_part.alloc((size_t)k->border_blocks * d->nb * d->nb);
+    }
     if (k->lds_leaf > 60000 || k->lds_chain > 60000 || k->lds_border > 60000)
       throw std::runtime_error("KKT block too large for the solver's LDS staging");
     k->vals.alloc((size_t)d->total_vals);
@@ -1113,6 +1180,8 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
     a.counts = k->counts.p;
     a.r = k->r.p; a.leafG = k->leafG.p; a.chainG = k->chainG.p;
     a.leafG_off = k->leafG_off.p; a.chainG_off = k->chainG_off.p;
+    a.border_part = k->border_part.p;
+    a.border_part_blocks = k->border_blocks ? 1 : 0;   // (the border kernels read the slot kkt_border_terms_sum leaves)
     a.cr = k->chain_cr ? 1 : 0;
     if (k->chain_cr) {
       a.crbuf = k->crbuf.p;
@@ -1287,6 +1356,7 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
         if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
       }
     } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    border_terms_device<false>(k);
     if (border_mode == 0) hipLaunchKernelGGL(kkt_border_factor<0>, dim3(1), dim3(256), k->lds_border, st, k->args);
     else hipLaunchKernelGGL(kkt_border_factor<1>, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
@@ -1362,6 +1432,7 @@ int pc_kkt_forward_partial(pc_kkt* k, const double* rhs, double* border_rhs_out)
     std::memcpy(k->h_a.p, rhs, k->nu * sizeof(double));
     KHIP(hipMemcpyAsync(k->vin.p, k->h_a.p, k->nu * sizeof(double), hipMemcpyHostToDevice, st));
     forward_device(k, k->vin.p);
+    border_terms_device<true>(k);
     hipLaunchKernelGGL(kkt_border_solve<false>, dim3(1), dim3(256), k->lds_border, st, k->args);
     KHIP(hipGetLastError());
     if (k->nb) KHIP(hipMemcpyAsync(border_rhs_out, k->r.p + k->args.base_border, (size_t)k->nb * sizeof(double), hipMemcpyDeviceToHost, st));

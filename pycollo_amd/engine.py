@@ -549,6 +549,20 @@ class NlpEngine:
         self._check(self._lib.pc_launch_tail_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c),
                                                     addr(d_G), addr(d_H), stream))
 
+
+    def launch_tail_objective(self, d_x, obj_factor, d_lam, d_c, d_G, d_H, stream=None, want_grad=True):
+        """``launch_tail_only`` that also returns (J, grad J or None) and synchronises the stream
+        (``pc_launch_tail_objective_device``): the objective callbacks of a rank of a sharded solve."""
+        def addr(t):
+            return t.data_ptr() if hasattr(t, "data_ptr") else int(t)
+        self._cached_x = None
+        f = C.c_double()
+        grad = np.empty(self.num_x) if want_grad else None
+        self._lib.pc_launch_tail_objective_device.argtypes = [C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p]
+        self._check(self._lib.pc_launch_tail_objective_device(self._h, addr(d_x), float(obj_factor), addr(d_lam), addr(d_c), addr(d_G),
+                                                              addr(d_H), stream, C.addressof(f), None if grad is None else grad.ctypes.data))
+        return f.value, grad
+
     def set_tile_range(self, phase: int, begin: int, end: int):
         self._check(self._lib.pc_set_tile_range(self._h, phase, begin, end))
 

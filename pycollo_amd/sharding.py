@@ -302,13 +302,15 @@ class SegmentExchange:
 class ShardedNlp:
     """One rank of a section-sharded NLP evaluation (GPU).  Every rank holds the complete outputs."""
 
-    def __init__(self, problem, device: int = 0, threads_per_block: int = 0, group=None):
+    def __init__(self, problem, device: int = 0, threads_per_block: int = 0, group=None, engine=None):
+        """``engine``: an existing GPU engine to shard instead of building one from ``problem`` (a mesh iteration's, with
+        its scaling set: ``ipm_sharded.solve_sharded``); it is restricted to this rank's tiles from here on."""
         import torch
         import torch.distributed as dist
         from .engine import NlpEngine
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.engine = eng = NlpEngine(problem, device=device, threads_per_block=threads_per_block)
+        self.engine = eng = engine if engine is not None else NlpEngine(problem, device=device, threads_per_block=threads_per_block)
         self.plan = plan = ShardPlan(eng, self.world)
         dev = torch.device("cuda", device)
         self.buf = torch.zeros(plan.total, dtype=torch.float64, device=dev)
