@@ -16,6 +16,14 @@ from test_gpu_sharded_process import _free_port
 pytestmark = pytest.mark.gpu
 
 
+def _keep(lines: str, name: str):
+    """The ranks' report lines, kept beside the other run outputs when the scratch directory exists (gpurun_out/)."""
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, name), "w") as f:
+            f.write(lines + "\n")
+
+
 @pytest.mark.parametrize("name,kw", [("hypersensitive", dict(K=200, order=6)), ("cart_pole", dict(K=100, order=4)),
                                      ("sliding_mass", dict(num_phases=2, K=10, order=4))])
 def test_a_world_of_one_takes_the_single_process_path(built, monkeypatch, name, kw):
@@ -80,4 +88,5 @@ def test_two_processes_solve_one_nlp(built, tmp_path):
     lines = "\n".join(ln for ln in out.splitlines() if "SHARDED IPM" in ln)
     assert res.returncode == 0, traces + lines + out[-1500:]
     assert out.count("ok: True") == 6, lines
+    _keep(lines, "sharded_ipm_two_ranks.txt")
     assert "SHARDED IPM rank 0 done" in out and "SHARDED IPM rank 1 done" in out

@@ -164,4 +164,6 @@ def test_two_processes_factorise_one_kkt_system(built, tmp_path):
     traces = "".join(p.read_text() for p in tmp_path.glob("trace.*"))
     assert res.returncode == 0, traces + out[-1500:]
     assert out.count("ok: True") == 6, out[-3000:]
+    from test_gpu_ipm_sharded import _keep
+    _keep("\n".join(ln for ln in out.splitlines() if "SHARDED KKT" in ln), "sharded_kkt_two_ranks.txt")
     assert "SHARDED KKT rank 0 done" in out and "SHARDED KKT rank 1 done" in out
