@@ -72,6 +72,7 @@ for name, kw in cases:
             x1 = np.zeros(plan.nu)
             for r, sk in sks.items():
                 R = plan.ranks[r]
+                sk.handles[r].forward_partial(plan.local_vector(r, rhs))      # (the timing loops above overwrote its state)
                 xl = sk.handles[r].backward_partial(xb[R.border_red])
                 x1[R.univ[R.own]] = xl[R.own]
                 sk.close()
