@@ -196,8 +196,69 @@ def sharded_config_lines(world, rank, local_rank, dev, tstream, args):
                       "rank_tile_kernels_us": round(t_bulk, 2),
                       "rank_hbm_fraction": round(sh.local_algorithmic_bytes / (t_bulk * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                       "rank_algorithmic_bytes": int(sh.local_algorithmic_bytes)})
+        if name == "shuttle":
+            try:
+                lines[-1]["sharded_kkt"] = sharded_kkt_line(sh, x, lam, dev, tstream, rank, world)
+            except Exception as exc:   # noqa: BLE001 -- reported, never required (the ranks are symmetric)
+                lines[-1]["sharded_kkt"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         sh.engine.close()
     return lines
+
+
+def sharded_kkt_line(sh, x, lam, dev, tstream, rank, world):
+    """The consumer that needs only a rank's own rows, on the same ranks: the evaluation with only the
+    per-tile partial sums exchanged, and one interior-point KKT system factorised and solved with the chain cut across the
+    ranks (pycollo_amd/kkt_sharded.py) -- wall time of the slowest rank, reductions included."""
+    import time
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from pycollo_amd.kkt_sharded import ShardedKkt, ShardedKktPlan
+    eng = sh.engine
+    n, m = eng.num_x, eng.num_c
+    lay = eng.layout
+    ineq = []
+    for pl, pm in zip(lay.phases, eng.model.phases):
+        ineq += list(range(pl.c_path_off, pl.c_path_off + pm.n_p * pl.N))
+    ineq = np.array(sorted(ineq + list(range(lay.c_end_off, m, 2))), dtype=np.int64)
+    ns = len(ineq)
+    rng = np.random.default_rng(7)
+    fixed = np.zeros(n + ns, bool)
+    sc = np.ones(m)
+    dvec = np.concatenate([rng.uniform(0.5, 2.0, n + ns) + 50.0, -1e-8 * np.ones(m)])
+    rhs = rng.normal(size=n + ns + m)
+
+    def slowest(fn, reps):
+        fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def local_eval():
+        with torch.cuda.stream(tstream):
+            sh.evaluate_local_device(x, 1.0, lam, tstream)
+    t_eval = slowest(local_eval, 20)
+    t0 = time.perf_counter()
+    plan = ShardedKktPlan(eng, ineq, fixed, sc, sh.plan, only=[rank])
+    t_plan = time.perf_counter() - t0
+    sk = ShardedKkt(eng, plan, [rank], d_jac=sh.G.data_ptr(), d_hess=sh.H.data_ptr(), distributed=True)
+    inertia = sk.factor(dvec)
+    t_factor = slowest(lambda: sk.factor(dvec), 5)
+    t_solve = slowest(lambda: sk.solve(rhs), 5)
+    f = plan.footprint(rank)
+    out = {"nodes_unknowns": int(plan.nu), "local_eval_us_partial_sums_only": round(t_eval * 1e6, 1),
+           "factor_ms": round(t_factor * 1e3, 3), "solve_ms": round(t_solve * 1e3, 3),
+           "inertia": list(inertia), "inertia_expected": [int(n + ns), int(m)],
+           "reduced_border_unknowns": int(plan.nb_red), "rank0_local_border": f["nb_local"],
+           "rank0_matrix_MB": round(8e-6 * f["local_vals"], 1), "plan_build_s": round(t_plan, 2),
+           "note": "host vectors in and out of every call; reductions: nb_red^2 doubles per factorisation, nb_red + nu per solve"}
+    sk.close()
+    return out
 
 
 def main():

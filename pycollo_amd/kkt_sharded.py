@@ -65,7 +65,9 @@ def shard_cuts(engine, shard_plan):
 class ShardedKktPlan:
     """Local tables of every rank and the reduced system, from one classification of the whole NLP's unknowns."""
 
-    def __init__(self, engine, ineq_rows, fixed_v, row_scale, shard_plan, group=None, positions="positions"):
+    def __init__(self, engine, ineq_rows, fixed_v, row_scale, shard_plan, group=None, positions="positions", only=None):
+        """``only``: the ranks whose local tables are built (default all; a process needs its own -- ``ranks[r]`` is None
+        for the others; the checks that every entry is assembled exactly once still cover every rank)."""
         self.world = W = shard_plan.world
         ineq_rows = np.asarray(ineq_rows, dtype=np.int64)
         self.cuts, self.seg_rank = shard_cuts(engine, shard_plan)
@@ -127,6 +129,9 @@ class ShardedKktPlan:
             if np.any((so >= 0) & (so != r)):
                 raise RuntimeError(f"rank {r}: a KKT entry of its blocks is written by another rank's tiles")
             taken += sel
+            if only is not None and r not in only:
+                self.ranks.append(None)
+                continue
             self.ranks.append(self._local(r, P, Tg, member[r], urank, owner, red_pos, chain_rank, leaf_rank,
                                           (eu[sel], ev[sel], ekind[sel], eidx[sel], ecoef[sel]), positions))
         if not np.all(taken == 1):

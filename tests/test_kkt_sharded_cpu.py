@@ -74,4 +74,10 @@ def test_a_rank_holds_its_share_and_a_border_that_does_not_grow_with_the_world(b
             cover[R.univ[R.own]] += 1
         assert np.all(cover == 1)
     assert nb_local[8] == nb_local[4] == whole.nb + 6
+    # a process builds its own rank's tables only: the same tables
+    import dataclasses
+    one = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, ShardPlan(eng, 8), only=[3])
+    assert [R is not None for R in one.ranks] == [r == 3 for r in range(8)]
+    for f in dataclasses.fields(one.ranks[3].tables):
+        assert np.array_equal(getattr(one.ranks[3].tables, f.name), getattr(plan.ranks[3].tables, f.name)), f.name
     eng.close()
