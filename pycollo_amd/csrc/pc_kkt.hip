@@ -436,6 +436,7 @@ __global__ void kkt_chain_factor(KArgs a) {
 // accumulated in place: a node *pulls* what earlier levels owe it -- the leaves' Schur blocks, and for every level
 // below its own the Schur blocks of the two nodes eliminated next to it -- in a fixed order, so the factorisation is
 // bit-reproducible and needs one launch per level and no atomics.
+constexpr int CR_MAX_PULL = 64;   // two per level below a node's own: chains of up to 2^32 nodes
 struct CrNode {
   int nz, na, nb_, w;          // own unknowns, separators' (0 if none), border; w = na + nbr + nb
   int nbr;
@@ -479,6 +480,33 @@ __global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first, int 
   double* M = lds + (2 * nz + w);                 // [nz][ld] panel; block_eliminate's scratch in front
   double* S = M + (size_t)nz * ld;                // [w][w]
   const bool first_in_phase = p == 0, last_in_phase = p == n - 1;
+  // What the levels below owe this node, as a table built once per node: lane 2 (l - 1) + side looks up the node
+  // eliminated next to c at level l (side 0: c is its right separator, 1: its left) -- where its Schur block starts, the
+  // row and column offsets of c's part in it.  The element loop below then issues one load per entry and level; with
+  // these look-ups inside it (four dependent index loads per entry, level and side) the level kernels of a 9-unknown
+  // node took 35 us each at config 3, 13 levels per factorisation.
+  __shared__ int64_t pl_off[CR_MAX_PULL];
+  __shared__ int pl_row[CR_MAX_PULL], pl_ew[CR_MAX_PULL], pl_cD[CR_MAX_PULL], pl_cF[CR_MAX_PULL];
+  const int npull = 2 * (level - 1);
+  if (tid < npull) {
+    const int64_t h = (int64_t)1 << (tid >> 1);
+    int64_t off = -1;
+    int row = 0, ew = 0, cD = 0, cF = 0;
+    if ((tid & 1) == 0) {
+      if (p >= h) {                               // c is the right separator of e = c - h: [a | c | B]
+        const int64_t e2 = c - h;
+        const int ea = nzb_of(k, k.cr_a[e2]);
+        off = k.crS_off[e2]; row = ea; ew = ea + nz + nb; cD = ea; cF = ea + nz;
+      }
+    } else if (p + h <= n - 1) {                  // c is the left separator of e = c + h: [c | b | B]
+      const int64_t e2 = c + h;
+      const int64_t eb = k.cr_b[e2];
+      const int ebn = eb >= 0 ? nzb_of(k, eb) : 0;
+      off = k.crS_off[e2]; row = 0; ew = nz + ebn + nb; cD = 0; cF = nz + ebn;
+    }
+    pl_off[tid] = off; pl_row[tid] = row; pl_ew[tid] = ew; pl_cD[tid] = cD; pl_cF[tid] = cF;
+  }
+  wave_lds_sync();
   // ---- level-0 values: own entries (assembled as a lower triangle + couplings) and the two leaves' Schur blocks
   const int nx0 = last_in_phase ? 0 : nzb_of(k, c + 1), ld0 = nz + nx0 + nb;
   const double* Mg = k.vals + k.chainD_off[c];
@@ -512,19 +540,9 @@ __global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first, int 
     if (col < nz || col >= nz + na + nr) {
       const bool isF = col >= nz;
       const int kk = isF ? col - nz - na - nr : col;
-      for (int l = 1; l < level; ++l) {
-        const int64_t h = (int64_t)1 << (l - 1);
-        if (p >= h) {                             // c is the right separator of e = c - h
-          const int64_t e2 = c - h;
-          const int ea = nzb_of(k, k.cr_a[e2]), ew = ea + nz + nb;
-          v += k.crbuf[k.crS_off[e2] + (size_t)(ea + i) * ew + (isF ? ea + nz + kk : ea + kk)];
-        }
-        if (p + h <= n - 1) {                     // c is the left separator of e = c + h
-          const int64_t e2 = c + h;
-          const int64_t eb = k.cr_b[e2];
-          const int ebn = eb >= 0 ? nzb_of(k, eb) : 0, ew = nz + ebn + nb;
-          v += k.crbuf[k.crS_off[e2] + (size_t)i * ew + (isF ? nz + ebn + kk : kk)];
-        }
+      for (int q = 0; q < npull; ++q) {           // (level by level, right separator's term before the left's)
+        const int64_t o = pl_off[q];
+        if (o >= 0) v += k.crbuf[o + (size_t)(pl_row[q] + i) * pl_ew[q] + (isF ? pl_cF[q] : pl_cD[q]) + kk];
       }
     } else if (level > 1) {                       // couplings created by the node eliminated in between, one level down
       const int64_t h2 = (int64_t)1 << (level - 2);
@@ -565,14 +583,25 @@ __global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first, int
   double* M = lds + nz;
   const double* Pg = k.crbuf + k.crP_off[c];
   for (int e = tid; e < nz * ld; e += 64) M[e] = Pg[e];
+  // (where the levels below left what they owe this node's right-hand side: looked up once, as in kkt_cr_factor)
+  __shared__ int64_t pg_off[CR_MAX_PULL];
+  const int npull = 2 * (level - 1);
+  if (tid < npull) {
+    const int64_t h = (int64_t)1 << (tid >> 1);
+    int64_t off = -1;
+    if ((tid & 1) == 0) {
+      if (p >= h) off = k.crG_off[c - h] + nzb_of(k, k.cr_a[c - h]);                       // as the right separator
+    } else if (p + h <= n - 1) off = k.crG_off[c + h];                                      // as the left separator
+    pg_off[tid] = off;
+  }
+  wave_lds_sync();
   if (tid < nz) {
     double v = k.r[k.base_chain + k.chain_ptr[c] + tid];
     if (p > 0) v -= k.leafG[k.leafG_off[k.leaf_of_left[c - 1]] + nzb_of(k, c - 1) + tid];   // left leaf, R part
     if (p < n - 1) v -= k.leafG[k.leafG_off[k.leaf_of_left[c]] + tid];                      // right leaf, L part
-    for (int l = 1; l < level; ++l) {
-      const int64_t h = (int64_t)1 << (l - 1);
-      if (p >= h) v -= k.crbuf[k.crG_off[c - h] + nzb_of(k, k.cr_a[c - h]) + tid];         // as the right separator
-      if (p + h <= n - 1) v -= k.crbuf[k.crG_off[c + h] + tid];                              // as the left separator
+    for (int q = 0; q < npull; ++q) {
+      const int64_t o = pg_off[q];
+      if (o >= 0) v -= k.crbuf[o + tid];
     }
     rr[tid] = v;
   }
@@ -711,12 +740,14 @@ __global__ void kkt_border_factor(KArgs a) {
 }
 
 // second stage of kkt_border_terms: entry e of workgroup 0's slot = the sum over workgroups, in workgroup order
-__global__ void __launch_bounds__(256) kkt_border_terms_sum(double* __restrict__ part, int n_entries, int n_blocks) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_entries) return;
-  double tot = 0.0;
-  for (int b = 0; b < n_blocks; ++b) tot += part[(size_t)b * n_entries + e];
-  part[e] = tot;
+// (one wave per entry: lane i adds the workgroups i, i + 64, ..., then a fixed tree over the lanes -- a thread per entry
+//  walking all 256 sums in a row took 60 us)
+__global__ void __launch_bounds__(64) kkt_border_terms_sum(double* __restrict__ part, int n_entries, int n_blocks) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  double acc = 0.0;
+  for (int b = lane; b < n_blocks; b += 64) acc += part[(size_t)b * n_entries + e];
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) part[e] = acc;   // (slot 0 of entry e: read above by this wave's lane 0 only)
 }
 
 // ---- solve ----------------------------------------------------------------------------------------------------
@@ -930,7 +961,7 @@ static void border_terms_device(pc_kkt* k) {
   if (!k->border_blocks) return;
   const int n_entries = RHS ? k->nb : k->nb * k->nb;
   hipLaunchKernelGGL(kkt_border_terms<RHS>, dim3(k->border_blocks), dim3(256), 0, k->stream, k->args, k->border_part.p);
-  hipLaunchKernelGGL(kkt_border_terms_sum, dim3((n_entries + 255) / 256), dim3(256), 0, k->stream, k->border_part.p, n_entries, k->border_blocks);
+  hipLaunchKernelGGL(kkt_border_terms_sum, dim3(n_entries), dim3(64), 0, k->stream, k->border_part.p, n_entries, k->border_blocks);
 }
 
 static void forward_device(pc_kkt* k, const double* d_rhs) {
@@ -1152,7 +1183,9 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       }
     }
     k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2 + 256));
-    if ((int64_t)d->nb * d->nb * (d->n_leaf + d->n_chain) > ((int64_t)1 << 18)) {   // (config 2's own border: 2 x 2 x 1 001 terms)
+    // (also the NLP's own narrow border once there are thousands of terms: the one workgroup's walk took 93 us per
+    //  factorisation and 40 us per back-substitution at config 3, 2 x 2 entries x 5 001 terms; config 2's 1 001 terms stay)
+    if (d->nb > 0 && ((int64_t)d->nb * d->nb * (d->n_leaf + d->n_chain) > ((int64_t)1 << 18) || d->n_leaf + d->n_chain >= 2048)) {
       k->border_blocks = (int)std::min<int64_t>(256, d->n_leaf + d->n_chain);
       k->border_part.alloc((size_t)k->border_blocks * d->nb * d->nb);
     }
