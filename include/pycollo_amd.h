@@ -295,6 +295,9 @@ typedef struct {
   const int64_t* mv_ptr;              /* the whole symmetric matrix as CSR over the unknowns (products) */
   const int32_t *mv_col, *mv_kind, *mv_idx;
   const double* mv_coef;
+  const uint8_t* chain_export;        /* [n_chain] or NULL: 1 = the chain node is not eliminated and its assembled panel is
+                                         handed out (pc_kkt_export_*): the nodes a rank shares with its neighbours in a
+                                         factorisation cut across ranks; first / last node of a chain segment only */
 } pc_kkt_desc;
 /* Host-only helper of the table build (no device): value-buffer position of K[u[e], v[e]] for n pairs of natural
  * unknowns under the elimination plan (class 0 leaf / 1 chain / 2 border, block and local index per unknown; block

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "../../include/pycollo_amd.h"
@@ -334,6 +335,12 @@ struct KArgs {
   double* crbuf;
   const int64_t *cr_a, *cr_b, *crP_off, *crS_off, *crG_off;
   const int64_t* cr_nodes;       // nodes by level, concatenated
+  const int64_t *cr_mid_a, *cr_mid_b;   // the node whose Schur block holds a node's coupling to its separator a / b (-1: the
+                                        // assembled entries: they are neighbours in the chain)
+  const int64_t* pull_ptr;       // per chain node: the eliminated nodes it is a separator of, level by level --
+  const int32_t* pull_e;         //   node << 1 | 1 if it is that node's LEFT separator
+  const uint8_t* chain_first;    // [n_chain] first node of its segment
+  const uint8_t* chain_export;   // [n_chain] or null: not eliminated, its assembled panel is handed out
   // wide borders: the border terms pre-summed by a grid (kkt_border_terms); 0 blocks = the border kernels sum them
   const double* border_part;
   int32_t border_part_blocks;
@@ -453,60 +460,41 @@ __device__ __forceinline__ CrNode cr_node(const KArgs& k, int64_t c) {
   n.w = n.na + n.nbr + k.nb;
   return n;
 }
-// position of c in its phase, the phase's length, and the level c is eliminated at (position 0: one past the last)
-__device__ __forceinline__ void cr_where(const KArgs& k, int64_t c, int ph, int64_t& p, int64_t& n, int& level) {
-  const int64_t c0 = k.chain_phase_ptr[ph], c1 = k.chain_phase_ptr[ph + 1];
-  p = c - c0;
-  n = c1 - c0;
-  if (p > 0) level = __builtin_ctzll((unsigned long long)p) + 1;
-  else {
-    level = 1;
-    while (((int64_t)1 << (level - 1)) <= n - 1) ++level;   // 1 + number of levels
-  }
-}
-
-// launch: one workgroup (one wave) per node of the level; `first` = offset of the level in cr_nodes; ph_of via search
-__global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first, int n_phase) {
+// launch: one workgroup (one wave) per node of the level; `first` = offset of the level in cr_nodes
+__global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first) {
   extern __shared__ double lds[];
   const int tid = threadIdx.x, nb = k.nb;
   const int64_t c = k.cr_nodes[first + blockIdx.x];
-  int ph = 0;
-  while (ph + 1 < n_phase && k.chain_phase_ptr[ph + 1] <= c) ++ph;
-  int64_t p, n;
-  int level;
-  cr_where(k, c, ph, p, n, level);
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, na = me.na, nr = me.nbr, w = me.w, ld = nz + w;
   double* M = lds + (2 * nz + w);                 // [nz][ld] panel; block_eliminate's scratch in front
   double* S = M + (size_t)nz * ld;                // [w][w]
-  const bool first_in_phase = p == 0, last_in_phase = p == n - 1;
-  // What the levels below owe this node, as a table built once per node: lane 2 (l - 1) + side looks up the node
-  // eliminated next to c at level l (side 0: c is its right separator, 1: its left) -- where its Schur block starts, the
-  // row and column offsets of c's part in it.  The element loop below then issues one load per entry and level; with
-  // these look-ups inside it (four dependent index loads per entry, level and side) the level kernels of a 9-unknown
-  // node took 35 us each at config 3, 13 levels per factorisation.
+  const bool first_in_phase = k.chain_first[c] != 0, last_in_phase = k.chain_last[c] != 0;
+  // What the levels below owe this node, as a table built once per node: lane q looks up the q-th eliminated node c is a
+  // separator of (host list, level by level) -- where its Schur block starts, the row and column offsets of c's part in
+  // it.  The element loop below then issues one load per entry and pulled node; with these look-ups inside it (four
+  // dependent index loads per entry, level and side) the level kernels of a 9-unknown node took 35 us each at config 3.
   __shared__ int64_t pl_off[CR_MAX_PULL];
   __shared__ int pl_row[CR_MAX_PULL], pl_ew[CR_MAX_PULL], pl_cD[CR_MAX_PULL], pl_cF[CR_MAX_PULL];
-  const int npull = 2 * (level - 1);
+  const int64_t q0 = k.pull_ptr[c];
+  const int npull = (int)(k.pull_ptr[c + 1] - q0);
   if (tid < npull) {
-    const int64_t h = (int64_t)1 << (tid >> 1);
-    int64_t off = -1;
-    int row = 0, ew = 0, cD = 0, cF = 0;
-    if ((tid & 1) == 0) {
-      if (p >= h) {                               // c is the right separator of e = c - h: [a | c | B]
-        const int64_t e2 = c - h;
-        const int ea = nzb_of(k, k.cr_a[e2]);
-        off = k.crS_off[e2]; row = ea; ew = ea + nz + nb; cD = ea; cF = ea + nz;
-      }
-    } else if (p + h <= n - 1) {                  // c is the left separator of e = c + h: [c | b | B]
-      const int64_t e2 = c + h;
+    const int32_t code = k.pull_e[q0 + tid];
+    const int64_t e2 = code >> 1;
+    int row, ew, cD, cF;
+    if (code & 1) {                               // c is the left separator of e2: [c | b | B]
       const int64_t eb = k.cr_b[e2];
       const int ebn = eb >= 0 ? nzb_of(k, eb) : 0;
-      off = k.crS_off[e2]; row = 0; ew = nz + ebn + nb; cD = 0; cF = nz + ebn;
+      row = 0; ew = nz + ebn + nb; cD = 0; cF = nz + ebn;
+    } else {                                      // c is the right separator of e2: [a | c | B]
+      const int64_t ea_ = k.cr_a[e2];
+      const int ea = ea_ >= 0 ? nzb_of(k, ea_) : 0;
+      row = ea; ew = ea + nz + nb; cD = ea; cF = ea + nz;
     }
-    pl_off[tid] = off; pl_row[tid] = row; pl_ew[tid] = ew; pl_cD[tid] = cD; pl_cF[tid] = cF;
+    pl_off[tid] = k.crS_off[e2]; pl_row[tid] = row; pl_ew[tid] = ew; pl_cD[tid] = cD; pl_cF[tid] = cF;
   }
   wave_lds_sync();
+  const int64_t mida = k.cr_mid_a[c], midb = k.cr_mid_b[c];
   // ---- level-0 values: own entries (assembled as a lower triangle + couplings) and the two leaves' Schur blocks
   const int nx0 = last_in_phase ? 0 : nzb_of(k, c + 1), ld0 = nz + nx0 + nb;
   const double* Mg = k.vals + k.chainD_off[c];
@@ -516,95 +504,90 @@ __global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first, int 
   for (int e = tid; e < nz * ld; e += 64) {
     const int i = e / ld, col = e - i * ld;
     double v = 0.0;
-    if (col < nz) {                               // D
-      const int kk = col;
-      v = kk > i ? Mg[(size_t)kk * ld0 + i] : Mg[(size_t)i * ld0 + kk];
-      if (SL) v += SL[(size_t)(nl + i) * wsl + nl + kk];
-      if (SR) v += SR[(size_t)i * ld0 + kk];
-    } else if (col >= nz + na + nr) {             // F
-      const int kk = col - nz - na - nr;
-      v = Mg[(size_t)i * ld0 + nz + nx0 + kk];
-      if (SL) v += SL[(size_t)(nl + i) * wsl + nl + nz + kk];
-      if (SR) v += SR[(size_t)i * ld0 + nz + nx0 + kk];
-    } else if (level == 1) {                      // couplings to the original neighbours
-      if (col < nz + na) {                        // K(c, a), a = c - 1: transposed E of a, and the left leaf's R-L block
-        const int kk = col - nz;
-        const int lda = na + nz + nb;             // a's own panel: [na | nz | nb]
-        v = k.vals[k.chainD_off[me.a] + (size_t)kk * lda + na + i] + SL[(size_t)(nl + i) * wsl + kk];
-      } else {                                    // K(c, b), b = c + 1
-        const int kk = col - nz - na;
-        v = Mg[(size_t)i * ld0 + nz + kk] + SR[(size_t)i * ld0 + nz + kk];
-      }
-    }
-    // ---- what the levels below owe this node: D and F from both eliminated neighbours of every level
-    if (col < nz || col >= nz + na + nr) {
+    if (col < nz || col >= nz + na + nr) {        // D and F: own entries, the leaves, and what the levels below owe
       const bool isF = col >= nz;
       const int kk = isF ? col - nz - na - nr : col;
-      for (int q = 0; q < npull; ++q) {           // (level by level, right separator's term before the left's)
-        const int64_t o = pl_off[q];
-        if (o >= 0) v += k.crbuf[o + (size_t)(pl_row[q] + i) * pl_ew[q] + (isF ? pl_cF[q] : pl_cD[q]) + kk];
+      if (!isF) {
+        v = kk > i ? Mg[(size_t)kk * ld0 + i] : Mg[(size_t)i * ld0 + kk];
+        if (SL) v += SL[(size_t)(nl + i) * wsl + nl + kk];
+        if (SR) v += SR[(size_t)i * ld0 + kk];
+      } else {
+        v = Mg[(size_t)i * ld0 + nz + nx0 + kk];
+        if (SL) v += SL[(size_t)(nl + i) * wsl + nl + nz + kk];
+        if (SR) v += SR[(size_t)i * ld0 + nz + nx0 + kk];
       }
-    } else if (level > 1) {                       // couplings created by the node eliminated in between, one level down
-      const int64_t h2 = (int64_t)1 << (level - 2);
-      if (col < nz + na) {                        // e = c - h/2: [a | c | B], K(c, a) = S.ba
-        const int kk = col - nz;
-        const int64_t e2 = c - h2;
+      for (int q = 0; q < npull; ++q)             // (level by level, right separator's term before the left's)
+        v += k.crbuf[pl_off[q] + (size_t)(pl_row[q] + i) * pl_ew[q] + (isF ? pl_cF[q] : pl_cD[q]) + kk];
+    } else if (col < nz + na) {                   // K(c, a)
+      const int kk = col - nz;
+      if (mida < 0) {                             // a = c - 1: transposed E of a, and the left leaf's R-L block
+        const int lda = na + nz + nb;             // a's own panel: [na | nz | nb]
+        v = k.vals[k.chainD_off[me.a] + (size_t)kk * lda + na + i] + SL[(size_t)(nl + i) * wsl + kk];
+      } else {                                    // created by the node eliminated between a and c: [a | c | B], S.ba
         const int ew = na + nz + nb;
-        v = k.crbuf[k.crS_off[e2] + (size_t)(na + i) * ew + kk];
-      } else {                                    // e = c + h/2: [c | b | B], K(c, b) = S.ab
-        const int kk = col - nz - na;
-        const int64_t e2 = c + h2;
+        v = k.crbuf[k.crS_off[mida] + (size_t)(na + i) * ew + kk];
+      }
+    } else {                                      // K(c, b)
+      const int kk = col - nz - na;
+      if (midb < 0) {                             // b = c + 1: own E block and the right leaf's L-R block
+        v = Mg[(size_t)i * ld0 + nz + kk] + SR[(size_t)i * ld0 + nz + kk];
+      } else {                                    // created by the node eliminated between c and b: [c | b | B], S.ab
         const int ew = nz + nr + nb;
-        v = k.crbuf[k.crS_off[e2] + (size_t)i * ew + nz + kk];
+        v = k.crbuf[k.crS_off[midb] + (size_t)i * ew + nz + kk];
       }
     }
     M[e] = v;
   }
   wave_lds_sync();
-  block_eliminate<true>(M, nz, w, S, k.counts + 2 * (k.n_leaf + c), lds);
   double* Pg = k.crbuf + k.crP_off[c];
+  if (k.chain_export && k.chain_export[c]) {      // not eliminated: the assembled panel is this rank's term of the reduced system
+    for (int e = tid; e < nz * ld; e += 64) Pg[e] = M[e];
+    if (tid < 2) k.counts[2 * (k.n_leaf + c) + tid] = 0;
+    return;
+  }
+  block_eliminate<true>(M, nz, w, S, k.counts + 2 * (k.n_leaf + c), lds);
   double* Sg = k.crbuf + k.crS_off[c];
   for (int e = tid; e < nz * ld; e += 64) Pg[e] = M[e];
   for (int e = tid; e < w * w; e += 64) Sg[e] = S[e];
 }
 
-__global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first, int n_phase) {
+__global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first) {
   extern __shared__ double lds[];
-  const int tid = threadIdx.x, nb = k.nb;
+  const int tid = threadIdx.x;
   const int64_t c = k.cr_nodes[first + blockIdx.x];
-  int ph = 0;
-  while (ph + 1 < n_phase && k.chain_phase_ptr[ph + 1] <= c) ++ph;
-  int64_t p, n;
-  int level;
-  cr_where(k, c, ph, p, n, level);
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, w = me.w, ld = nz + w;
+  const bool first_in_phase = k.chain_first[c] != 0, last_in_phase = k.chain_last[c] != 0;
+  const bool exported = k.chain_export && k.chain_export[c];
   double* rr = lds;
   double* M = lds + nz;
   const double* Pg = k.crbuf + k.crP_off[c];
-  for (int e = tid; e < nz * ld; e += 64) M[e] = Pg[e];
+  if (!exported)
+    for (int e = tid; e < nz * ld; e += 64) M[e] = Pg[e];
   // (where the levels below left what they owe this node's right-hand side: looked up once, as in kkt_cr_factor)
   __shared__ int64_t pg_off[CR_MAX_PULL];
-  const int npull = 2 * (level - 1);
+  const int64_t q0 = k.pull_ptr[c];
+  const int npull = (int)(k.pull_ptr[c + 1] - q0);
   if (tid < npull) {
-    const int64_t h = (int64_t)1 << (tid >> 1);
-    int64_t off = -1;
-    if ((tid & 1) == 0) {
-      if (p >= h) off = k.crG_off[c - h] + nzb_of(k, k.cr_a[c - h]);                       // as the right separator
-    } else if (p + h <= n - 1) off = k.crG_off[c + h];                                      // as the left separator
+    const int32_t code = k.pull_e[q0 + tid];
+    const int64_t e2 = code >> 1;
+    int64_t off = k.crG_off[e2];
+    if (!(code & 1)) {                            // as the right separator: behind e2's left separator's part
+      const int64_t ea_ = k.cr_a[e2];
+      off += ea_ >= 0 ? nzb_of(k, ea_) : 0;
+    }
     pg_off[tid] = off;
   }
   wave_lds_sync();
   if (tid < nz) {
     double v = k.r[k.base_chain + k.chain_ptr[c] + tid];
-    if (p > 0) v -= k.leafG[k.leafG_off[k.leaf_of_left[c - 1]] + nzb_of(k, c - 1) + tid];   // left leaf, R part
-    if (p < n - 1) v -= k.leafG[k.leafG_off[k.leaf_of_left[c]] + tid];                      // right leaf, L part
-    for (int q = 0; q < npull; ++q) {
-      const int64_t o = pg_off[q];
-      if (o >= 0) v -= k.crbuf[o + tid];
-    }
+    if (!first_in_phase) v -= k.leafG[k.leafG_off[k.leaf_of_left[c - 1]] + nzb_of(k, c - 1) + tid];   // left leaf, R part
+    if (!last_in_phase) v -= k.leafG[k.leafG_off[k.leaf_of_left[c]] + tid];                            // right leaf, L part
+    for (int q = 0; q < npull; ++q) v -= k.crbuf[pg_off[q] + tid];
     rr[tid] = v;
+    if (exported) k.r[k.base_chain + k.chain_ptr[c] + tid] = v;   // the rank's term of the reduced right-hand side
   }
+  if (exported) return;
   wave_lds_sync();
   if (tid < w) {
     double g = 0.0;
@@ -618,6 +601,7 @@ __global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first, int
 __global__ void __launch_bounds__(64) kkt_cr_backward(KArgs k, int64_t first) {
   const int tid = threadIdx.x, nb = k.nb;
   const int64_t c = k.cr_nodes[first + blockIdx.x];
+  if (k.chain_export && k.chain_export[c]) return;   // (its solution comes from the reduced system)
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, na = me.na, nr = me.nbr, ld = nz + me.w;
   const double* Pg = k.crbuf + k.crP_off[c];
@@ -672,6 +656,7 @@ __device__ __forceinline__ double border_matrix_term(const KArgs& a, int64_t j, 
   }
   const int64_t c = j - a.n_leaf;
   if (a.cr) {
+    if (a.chain_export && a.chain_export[c]) return 0.0;   // (not eliminated: no Schur block)
     const int o = (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0), wc = o + nb;
     return a.crbuf[a.crS_off[c] + (size_t)(o + i) * wc + o + k];
   }
@@ -685,6 +670,7 @@ __device__ __forceinline__ double border_rhs_term(const KArgs& a, int64_t j, int
     return a.leafG[a.leafG_off[j] + nzb_of(a, left) + nzb_of(a, left + 1) + e];
   }
   const int64_t c = j - a.n_leaf;
+  if (a.cr && a.chain_export && a.chain_export[c]) return 0.0;
   if (a.cr) return a.crbuf[a.crG_off[c] + (a.cr_a[c] >= 0 ? nzb_of(a, a.cr_a[c]) : 0) + (a.cr_b[c] >= 0 ? nzb_of(a, a.cr_b[c]) : 0) + e];
   return a.chainG[a.chainG_off[c] + (a.chain_last[c] ? 0 : nzb_of(a, c + 1)) + e];
 }
@@ -911,7 +897,12 @@ struct pc_kkt {
   std::vector<int64_t> cr_lvl_ptr;   // nodes of level l: cr_nodes[cr_lvl_ptr[l-1] .. cr_lvl_ptr[l])
   int lds_cr = 0;
   Dev<double> crbuf;
-  Dev<int64_t> cr_a, cr_b, crP_off, crS_off, crG_off, cr_nodes;
+  Dev<int64_t> cr_a, cr_b, crP_off, crS_off, crG_off, cr_nodes, cr_mid_a, cr_mid_b, pull_ptr;
+  Dev<int32_t> pull_e;
+  Dev<uint8_t> chain_first, chain_export;
+  bool any_export = false;
+  std::vector<int64_t> export_nodes;    // chain nodes that are not eliminated (a rank's shared nodes), ascending
+  std::vector<int64_t> h_crP_off, h_chain_ptr, h_cr_b;      // host copies for the export calls
   Dev<double> border_part;   // [border_blocks][nb * nb] partial sums of the border terms (wide borders only)
   int border_blocks = 0;
   int lds_leaf_full = 0;   // LDS of the leaf factorisation: the largest leaf block that fits, plus its staging vectors
@@ -972,7 +963,7 @@ static void forward_device(pc_kkt* k, const double* d_rhs) {
   if (k->chain_cr) {
     for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
       const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
+      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
     }
   } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
 }
@@ -1136,24 +1127,81 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       k->args.chain_lds = full <= 64000 ? 1 : 0;
       k->lds_chain_factor = (int)(k->args.chain_lds ? full : k->lds_chain);
     }
-    {   // cyclic reduction of the chain: levels, separators, buffer offsets
+    {   // cyclic reduction of the chain: levels, separators, what every node pulls from the levels below, buffer offsets
+      // A segment (a phase's chain, or with cuts a part of one) of n nodes, positions 0 .. n-1: at level l the positions
+      // (2k+1) 2^(l-1) are eliminated against their neighbours at distance 2^(l-1); position 0 goes last.  A node marked in
+      // desc.chain_export is NOT eliminated (a rank's part of a factorisation cut across ranks: the node it shares with its
+      // neighbour rank, kkt_sharded.py) -- only the two ends of a segment can be: an exported last node is the right
+      // separator of every node whose own would lie beyond it ("anchor"), an exported first node keeps position 0's place
+      // in the order.  Their assembled panels [D | K(first, last) | F] are what the rank adds to the reduced system.
       const int64_t nc = d->n_chain;
-      std::vector<int64_t> ca(nc, -1), cb(nc, -1), oP(nc), oS(nc), oG(nc);
+      std::vector<int64_t> ca(nc, -1), cb(nc, -1), mida(nc, -1), midb(nc, -1), oP(nc), oS(nc), oG(nc);
       std::vector<int> lvl(nc, 1);
+      std::vector<uint8_t> firstv(nc, 0), exported(nc, 0);
+      bool any_export = false;
+      if (d->chain_export)
+        for (int64_t c = 0; c < nc; ++c) any_export |= (exported[c] = d->chain_export[c] != 0) != 0;
+      struct Owe { int64_t sep; int32_t code; };
+      std::vector<Owe> owes;                     // (node that pulls, eliminated node << 1 | pulls as the LEFT separator)
+      owes.reserve((size_t)2 * nc);
       int lmax = 1;
       for (int64_t ph = 0; ph < d->n_phase; ++ph) {
         const int64_t c0 = d->chain_phase_ptr[ph], n = d->chain_phase_ptr[ph + 1] - c0;
+        if (n <= 0) continue;
+        firstv[c0] = 1;
+        for (int64_t p = 1; p + 1 < n; ++p)
+          if (exported[c0 + p]) throw std::runtime_error("only the first and the last node of a chain segment can be exported");
+        const bool expN = n >= 2 && exported[c0 + n - 1];
+        const int64_t anchor = expN ? c0 + n - 1 : -1, n1 = expN ? n - 1 : n;
         int levels = 0;
-        while (((int64_t)1 << levels) <= n - 1) ++levels;      // number of odd-even levels
-        for (int64_t p = 0; p < n; ++p) {
-          if (p == 0) { lvl[c0] = levels + 1; continue; }
+        while (((int64_t)1 << levels) <= n1 - 1) ++levels;      // number of odd-even levels
+        for (int64_t p = 0; p < n1; ++p) {
+          if (p == 0) { lvl[c0] = levels + 1; cb[c0] = anchor; continue; }
           const int l = __builtin_ctzll((unsigned long long)p) + 1;
           const int64_t h = (int64_t)1 << (l - 1);
           lvl[c0 + p] = l;
           ca[c0 + p] = c0 + p - h;
-          if (p + h <= n - 1) cb[c0 + p] = c0 + p + h;
+          cb[c0 + p] = p + h <= n1 - 1 ? c0 + p + h : anchor;
         }
-        lmax = std::max(lmax, levels + 1);
+        if (expN) lvl[anchor] = levels + 2;                     // after position 0, which may still be eliminated against it
+        lmax = std::max(lmax, levels + (expN ? 2 : 1));
+        // in level order: where a node's couplings to its separators come from (the node eliminated between them last,
+        // -1 = they are neighbours in the chain: the assembled entries), and what an eliminated node owes its separators
+        std::vector<std::vector<int64_t>> by_level((size_t)levels + 3);
+        for (int64_t p = 0; p < n; ++p) by_level[(size_t)lvl[c0 + p]].push_back(c0 + p);
+        std::map<std::pair<int64_t, int64_t>, int64_t> link;
+        for (size_t L = 1; L < by_level.size(); ++L)
+          for (int64_t c : by_level[L]) {
+            if (ca[c] >= 0) {
+              auto it = link.find({ca[c], c});
+              mida[c] = it != link.end() ? it->second : -1;
+              if (mida[c] < 0 && ca[c] != c - 1) throw std::runtime_error("cyclic reduction: a separator without a coupling (internal)");
+            }
+            if (cb[c] >= 0) {
+              auto it = link.find({c, cb[c]});
+              midb[c] = it != link.end() ? it->second : -1;
+              if (midb[c] < 0 && cb[c] != c + 1) throw std::runtime_error("cyclic reduction: a separator without a coupling (internal)");
+            }
+            if (exported[c]) continue;
+            if (cb[c] >= 0) owes.push_back({cb[c], (int32_t)(c << 1)});          // (the right separator's term first, as the
+            if (ca[c] >= 0) owes.push_back({ca[c], (int32_t)((c << 1) | 1)});   //  levels were summed before these tables)
+            if (ca[c] >= 0 && cb[c] >= 0) link[{ca[c], cb[c]}] = c;
+          }
+      }
+      if (nc >= ((int64_t)1 << 30)) throw std::runtime_error("chain too long for the pull tables");
+      // CSR by pulling node, stable in the order collected (level by level; inside a level by position: for a separator c
+      // the node c - h comes before c + h)
+      std::vector<int64_t> pull_ptr((size_t)nc + 1, 0);
+      for (const Owe& o : owes) ++pull_ptr[(size_t)o.sep + 1];
+      int64_t max_pull = 0;
+      for (int64_t c = 0; c < nc; ++c) {
+        max_pull = std::max(max_pull, pull_ptr[(size_t)c + 1]);
+        pull_ptr[(size_t)c + 1] += pull_ptr[(size_t)c];
+      }
+      std::vector<int32_t> pull_e(owes.size() ? owes.size() : 1, 0);
+      {
+        std::vector<int64_t> fill(pull_ptr.begin(), pull_ptr.end() - 1);
+        for (const Owe& o : owes) pull_e[(size_t)fill[(size_t)o.sep]++] = o.code;
       }
       int64_t off = 0, ldsmax = 0;
       auto nzof = [&](int64_t c) { return d->chain_ptr[c + 1] - d->chain_ptr[c]; };
@@ -1165,8 +1213,10 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
         ldsmax = std::max(ldsmax, 8 * (2 * nz + w + nz * (nz + w) + w * w + 2));
         if (nz > 64 || w > 64) ldsmax = 1 << 30;
       }
-      k->chain_cr = ldsmax <= 64000;
+      k->chain_cr = ldsmax <= 64000 && max_pull <= CR_MAX_PULL;
       if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CR")) k->chain_cr = k->chain_cr && std::atoi(env) != 0;
+      if (any_export && !k->chain_cr) throw std::runtime_error("exported chain nodes need the cyclic-reduction kernels (blocks too large for their LDS)");
+      k->any_export = any_export;
       if (k->chain_cr) {
         std::vector<int64_t> nodes;
         k->cr_lvl_ptr.assign(1, 0);
@@ -1178,7 +1228,18 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
         k->lds_cr = (int)ldsmax;
         k->crbuf.alloc((size_t)std::max<int64_t>(1, off));
         k->cr_a.upload(ca.data(), ca.size()); k->cr_b.upload(cb.data(), cb.size());
+        k->cr_mid_a.upload(mida.data(), mida.size()); k->cr_mid_b.upload(midb.data(), midb.size());
+        k->pull_ptr.upload(pull_ptr.data(), pull_ptr.size()); k->pull_e.upload(pull_e.data(), pull_e.size());
+        k->chain_first.upload(firstv.data(), firstv.size());
+        if (any_export) {
+          k->chain_export.upload(exported.data(), exported.size());
+          for (int64_t c = 0; c < nc; ++c)
+            if (exported[c]) k->export_nodes.push_back(c);
+        }
         k->crP_off.upload(oP.data(), oP.size()); k->crS_off.upload(oS.data(), oS.size()); k->crG_off.upload(oG.data(), oG.size());
+        k->h_crP_off = oP;
+        k->h_cr_b = cb;
+        k->h_chain_ptr.assign(d->chain_ptr, d->chain_ptr + nc + 1);
         k->cr_nodes.upload(nodes.data(), nodes.size());
       }
     }
@@ -1221,6 +1282,10 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       a.cr_a = k->cr_a.p; a.cr_b = k->cr_b.p;
       a.crP_off = k->crP_off.p; a.crS_off = k->crS_off.p; a.crG_off = k->crG_off.p;
       a.cr_nodes = k->cr_nodes.p;
+      a.cr_mid_a = k->cr_mid_a.p; a.cr_mid_b = k->cr_mid_b.p;
+      a.pull_ptr = k->pull_ptr.p; a.pull_e = k->pull_e.p;
+      a.chain_first = k->chain_first.p;
+      a.chain_export = k->any_export ? k->chain_export.p : nullptr;
     }
   });
   if (!ok) {
@@ -1386,7 +1451,7 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
     if (k->chain_cr) {
       for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
         const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first, k->n_phase);
+        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
       }
     } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     border_terms_device<false>(k);

@@ -463,7 +463,7 @@ class _Desc(C.Structure):
                 + [("src_kind", C.POINTER(C.c_int32)), ("src_idx", C.POINTER(C.c_int32)), ("src_coef", C.POINTER(C.c_double)),
                    ("diag_pos", C.POINTER(C.c_int64)), ("fixed", C.POINTER(C.c_uint8)), ("mv_ptr", C.POINTER(C.c_int64)),
                    ("mv_col", C.POINTER(C.c_int32)), ("mv_kind", C.POINTER(C.c_int32)), ("mv_idx", C.POINTER(C.c_int32)),
-                   ("mv_coef", C.POINTER(C.c_double))])
+                   ("mv_coef", C.POINTER(C.c_double)), ("chain_export", C.POINTER(C.c_uint8))])
 
 
 class GpuKkt:
