@@ -362,6 +362,14 @@ int pc_kkt_factor_partial(pc_kkt* k, int use_hess, const double* dvec, double* b
 int pc_kkt_border_load_factor(pc_kkt* k, const double* border, int32_t* n_pos, int32_t* n_neg);
 int pc_kkt_forward_partial(pc_kkt* k, const double* rhs, double* border_rhs_out);
 int pc_kkt_backward_partial(pc_kkt* k, const double* border_x, double* x);
+/* Exported chain nodes (pc_kkt_desc::chain_export: the nodes a rank shares with its neighbours stay chain nodes of both
+ * and are eliminated by neither): after pc_kkt_factor_partial their assembled panels, concatenated in ascending node
+ * order, each [nz][nz + nr + nb] row-major = [D | K(node, its segment's exported last node) | F] (nr = 0 for a last node
+ * or when the segment's last node is not exported); after pc_kkt_forward_partial their right-hand sides minus what the
+ * eliminated blocks owe them; before pc_kkt_backward_partial their solution from the reduced system.  Host arrays. */
+int pc_kkt_export_panels(pc_kkt* k, double* out);
+int pc_kkt_export_rhs(pc_kkt* k, double* out);
+int pc_kkt_import_solution(pc_kkt* k, const double* in);
 
 /* ---- a device-resident interior-point iteration --------------------------
  * The reference enters its NLP solver once per solve (pycollo/backend.py:1807-1827: ca.nlpsol "ipopt"; legacy

@@ -1553,6 +1553,50 @@ int pc_kkt_backward_partial(pc_kkt* k, const double* border_x, double* x) {
   });
 }
 
+// Exported chain nodes (pc_kkt_desc::chain_export): after pc_kkt_factor_partial their assembled panels, one after the
+// other in ascending node order, each [nz][nz + nr + nb] row-major = [D | K(node, exported last node of its segment) | F]
+// (nr = 0 for a last node or when the segment's last node is not exported); after pc_kkt_forward_partial their right-hand
+// sides minus what the eliminated blocks owe them; before pc_kkt_backward_partial their solution from the reduced system.
+static void export_copy(pc_kkt* k, double* host, int what) {   // 0: panels out, 1: right-hand sides out, 2: solution in
+  KHIP(hipSetDevice(k->device));
+  hipStream_t st = k->stream;
+  size_t o = 0;
+  for (int64_t c : k->export_nodes) {
+    const int64_t nz = k->h_chain_ptr[c + 1] - k->h_chain_ptr[c];
+    const int64_t b = k->h_cr_b[c], nr = b >= 0 ? k->h_chain_ptr[b + 1] - k->h_chain_ptr[b] : 0;
+    if (what == 0) {
+      const size_t cnt = (size_t)(nz * (nz + nr + k->nb));
+      if (cnt) KHIP(hipMemcpyAsync(host + o, k->crbuf.p + k->h_crP_off[c], cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+      o += cnt;
+    } else {
+      double* dev = k->r.p + k->args.base_chain + k->h_chain_ptr[c];
+      if (nz) KHIP(hipMemcpyAsync(what == 1 ? host + o : dev, what == 1 ? dev : host + o, (size_t)nz * sizeof(double),
+                                  what == 1 ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, st));
+      o += (size_t)nz;
+    }
+  }
+  KHIP(hipStreamSynchronize(st));
+}
+int pc_kkt_export_panels(pc_kkt* k, double* out) {
+  return guarded([&] {
+    if (!k || !out) throw std::runtime_error("null argument");
+    if (!k->factored) throw std::runtime_error("pc_kkt_export_panels before a factorisation");
+    export_copy(k, out, 0);
+  });
+}
+int pc_kkt_export_rhs(pc_kkt* k, double* out) {
+  return guarded([&] {
+    if (!k || !out) throw std::runtime_error("null argument");
+    export_copy(k, out, 1);
+  });
+}
+int pc_kkt_import_solution(pc_kkt* k, const double* in) {
+  return guarded([&] {
+    if (!k || !in) throw std::runtime_error("null argument");
+    export_copy(k, const_cast<double*>(in), 2);
+  });
+}
+
 // ---- the same with every vector in device memory (the device-resident interior-point iteration, pc_ipm.hip) ----
 int pc_kkt_set_stream(pc_kkt* k, void* stream) {
   return guarded([&] {

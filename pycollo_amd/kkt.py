@@ -78,6 +78,7 @@ class KktTables:
     mv_kind: np.ndarray
     mv_idx: np.ndarray
     mv_coef: np.ndarray
+    chain_export: np.ndarray | None = None   # [n_chain] uint8: chain nodes that are not eliminated (kkt_sharded.py), or None
 
 
 def _node_maps(engine, group, cuts=None):
@@ -243,7 +244,8 @@ def natural_entries(n, nv, hr, hc, jr, jc, row_scale, ineq_rows):
 
 
 def _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
-            chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows, entries=None, n_primal=None, n_dual=None):
+            chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows, entries=None, n_primal=None, n_dual=None,
+            chain_export=None):
     """Block order, value-buffer layout and entry tables of a classified system.  ``entries``: the lower-triangle entries
     (``natural_entries`` form, fixed unknowns already dropped) when the system is not a whole NLP's (a rank's part of a
     sharded factorisation: ``positions`` must then be "positions" or "numpy")."""
@@ -353,7 +355,7 @@ def _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, 
             chainD_off=np.asarray(chainD_off, np.int64), chainS_off=np.asarray(chainS_off, np.int64),
             border_off=int(border_off), total_vals=int(total),
             dst=dst, run_ptr=run_ptr, src_kind=src_kind, src_idx=src_idx, src_coef=src_coef, diag_pos=diag_pos,
-            fixed=fixed.astype(np.uint8), mv_ptr=mv_ptr, mv_col=mv_col, mv_kind=mv_kind, mv_idx=mv_idx, mv_coef=mv_coef)
+            fixed=fixed.astype(np.uint8), mv_ptr=mv_ptr, mv_col=mv_col, mv_kind=mv_kind, mv_idx=mv_idx, mv_coef=mv_coef, chain_export=chain_export)
 
     # ---- the same in NumPy: the statement of the rule (positions = "numpy" / "positions"; the CPU tests hold the library
     #      against it).  "positions" takes only the position rule from the library, as round 3's first version did.
@@ -451,7 +453,22 @@ def _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, 
         dst=dst.astype(np.int64), run_ptr=run_ptr, src_kind=ekind[so].astype(np.int32), src_idx=eidx[so].astype(np.int32),
         src_coef=ecoef[so].astype(np.float64), diag_pos=diag_pos.astype(np.int64), fixed=fixed.astype(np.uint8),
         mv_ptr=mv_ptr, mv_col=rv[o2].astype(np.int32), mv_kind=rk[o2].astype(np.int32), mv_idx=ri[o2].astype(np.int32),
-        mv_coef=rc[o2].astype(np.float64))
+        mv_coef=rc[o2].astype(np.float64), chain_export=chain_export)
+
+
+def export_shapes(T: KktTables):
+    """(chain node, its unknowns, unknowns of the exported last node of its segment it is coupled to) for every exported
+    chain node, ascending: the layout of ``pc_kkt_export_panels``."""
+    if T.chain_export is None:
+        return []
+    nzb = np.diff(T.chain_ptr)
+    out = []
+    for c in np.nonzero(T.chain_export)[0]:
+        seg = int(np.searchsorted(T.chain_phase_ptr, c, side="right") - 1)
+        last = int(T.chain_phase_ptr[seg + 1] - 1)
+        nr = int(nzb[last]) if (c == T.chain_phase_ptr[seg] and last != c and T.chain_export[last]) else 0
+        out.append((int(c), int(nzb[c]), nr))
+    return out
 
 
 class _Desc(C.Structure):
@@ -495,6 +512,9 @@ class GpuKkt:
         lib.pc_kkt_border_load_factor.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         lib.pc_kkt_forward_partial.argtypes = [vp, vp, vp]
         lib.pc_kkt_backward_partial.argtypes = [vp, vp, vp]
+        lib.pc_kkt_export_panels.argtypes = [vp, vp]
+        lib.pc_kkt_export_rhs.argtypes = [vp, vp]
+        lib.pc_kkt_import_solution.argtypes = [vp, vp]
         d = _Desc()
         self._keep = []
         for k in ("nu", "nv", "n_leaf", "n_chain", "n_phase", "nb", "total_vals", "border_off"):
@@ -512,6 +532,11 @@ class GpuKkt:
             self._keep.append(arr)
             ctype = {np.int64: C.c_int64, np.int32: C.c_int32, np.float64: C.c_double, np.uint8: C.c_uint8}[typ]
             setattr(d, k, arr.ctypes.data_as(C.POINTER(ctype)))
+        if T.chain_export is not None and np.any(T.chain_export):
+            ce = np.ascontiguousarray(T.chain_export, dtype=np.uint8)
+            self._keep.append(ce)
+            d.chain_export = ce.ctypes.data_as(C.POINTER(C.c_uint8))
+        self._export_shapes = export_shapes(T)
         dg, dj, dh = vp(), vp(), vp()
         if not lib.pc_device_results(engine._h, C.byref(dg), C.byref(dj), C.byref(dh)):
             raise RuntimeError(lib.pc_last_error().decode())
@@ -596,6 +621,32 @@ class GpuKkt:
         x = np.empty(self.nu)
         self._check(self._lib.pc_kkt_backward_partial(self._h, xb.ctypes.data, x.ctypes.data))
         return x
+
+    def export_panels(self):
+        """After ``factor_partial``: the assembled panels [D | K(node, exported last node) | F] of the exported chain nodes,
+        in ascending node order (``export_shapes``)."""
+        out = np.zeros(sum(nz * (nz + nr + self.tables.nb) for _, nz, nr in self._export_shapes) or 1)
+        self._check(self._lib.pc_kkt_export_panels(self._h, out.ctypes.data))
+        panels, o = [], 0
+        for _, nz, nr in self._export_shapes:
+            n = nz * (nz + nr + self.tables.nb)
+            panels.append(out[o:o + n].reshape(nz, nz + nr + self.tables.nb))
+            o += n
+        return panels
+
+    def export_rhs(self):
+        """After ``forward_partial``: the exported nodes' right-hand sides minus what the eliminated blocks owe them."""
+        out = np.zeros(sum(nz for _, nz, _ in self._export_shapes) or 1)
+        self._check(self._lib.pc_kkt_export_rhs(self._h, out.ctypes.data))
+        return out[:sum(nz for _, nz, _ in self._export_shapes)]
+
+    def import_solution(self, x):
+        """Before ``backward_partial``: the exported nodes' solution (concatenated in node order)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape != (sum(nz for _, nz, _ in self._export_shapes),):
+            raise ValueError("exported solution of the wrong length")
+        if x.size:
+            self._check(self._lib.pc_kkt_import_solution(self._h, x.ctypes.data))
 
     def close(self):
         if getattr(self, "_h", None):

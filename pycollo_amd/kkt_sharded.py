@@ -41,6 +41,8 @@ class RankTables:
     univ: np.ndarray         # [nu_local] natural index (whole NLP's KKT numbering) of every local unknown, ascending
     own: np.ndarray          # [nu_local] bool: this rank supplies the unknown's diagonal / right-hand side, reports its solution
     border_red: np.ndarray   # [nb_local] position in the reduced system of every local border unknown (block order)
+    export_red: list = None         # per exported chain node (ascending): reduced positions of its unknowns (block order)
+    export_anchor_red: list = None  # ... and of the exported last node of its segment it is coupled to (empty: none)
 
 
 def shard_cuts(engine, shard_plan):
@@ -65,9 +67,19 @@ def shard_cuts(engine, shard_plan):
 class ShardedKktPlan:
     """Local tables of every rank and the reduced system, from one classification of the whole NLP's unknowns."""
 
-    def __init__(self, engine, ineq_rows, fixed_v, row_scale, shard_plan, group=None, positions="positions", only=None):
+    def __init__(self, engine, ineq_rows, fixed_v, row_scale, shard_plan, group=None, positions="positions", only=None,
+                 ends="chain"):
         """``only``: the ranks whose local tables are built (default all; a process needs its own -- ``ranks[r]`` is None
-        for the others; the checks that every entry is assembled exactly once still cover every rank)."""
+        for the others; the checks that every entry is assembled exactly once still cover every rank).
+
+        ``ends``: where a rank keeps the nodes it shares with its neighbours.  "chain" (default): as the first / last node
+        of its chain segment, *not eliminated* (``KktTables.chain_export``): the cyclic reduction runs between them and
+        their assembled panels are the rank's term of the reduced system -- the rank's border is the NLP's own.
+        "border": in the rank's local border (every block of the rank then carries their columns: the first version,
+        kept because it runs on the unchanged elimination kernels and in the NumPy oracle)."""
+        if ends not in ("chain", "border"):
+            raise ValueError("ends must be 'chain' or 'border'")
+        self.ends = ends
         self.world = W = shard_plan.world
         ineq_rows = np.asarray(ineq_rows, dtype=np.int64)
         self.cuts, self.seg_rank = shard_cuts(engine, shard_plan)
@@ -94,13 +106,19 @@ class ShardedKktPlan:
         member = np.zeros((W, nu), bool)
         is_border = cls == BORDER
         member[:, is_border] = True
+        remap = [[] for _ in range(W)]      # per rank: (unknowns of a cut node, chain node that stands for it in the rank's segment)
         for ip, (c, sr) in enumerate(zip(self.cuts, self.seg_rank)):
+            mp = P["maps"][ip]
+            cut_boundaries = np.nonzero(mp[4])[0]
             for j, node in enumerate(c):
                 u = np.nonzero(is_border & (P["u_phase"] == ip) & (P["u_node"] == node))[0]
                 owner[u] = sr[j + 1]
                 member[:, u] = False
                 member[sr[j], u] = True
                 member[sr[j + 1], u] = True
+                g_end = int(P["chain_base"][ip] + mp[5][cut_boundaries[j]])   # last node of the segment on its left ...
+                remap[sr[j]].append((u, g_end))
+                remap[sr[j + 1]].append((u, g_end + 1))                        # ... first node of the one on its right
         for r in range(W):
             member[r, urank == r] = True
         # ---- entries and the rank whose kernels write each entry's source ----------------------------------------------
@@ -133,7 +151,8 @@ class ShardedKktPlan:
                 self.ranks.append(None)
                 continue
             self.ranks.append(self._local(r, P, Tg, member[r], urank, owner, red_pos, chain_rank, leaf_rank,
-                                          (eu[sel], ev[sel], ekind[sel], eidx[sel], ecoef[sel]), positions))
+                                          (eu[sel], ev[sel], ekind[sel], eidx[sel], ecoef[sel]), positions,
+                                          remap[r] if ends == "chain" else []))
         if not np.all(taken == 1):
             raise RuntimeError("a KKT entry is assembled by no rank or by two")
         # ---- the reduced system: all border unknowns, dense, its entries arrive as the ranks' Schur complements --------
@@ -145,8 +164,12 @@ class ShardedKktPlan:
                                    np.zeros(1, np.int64), np.zeros(0, np.int64), None, None, None, None, None, None,
                                    entries=e0, n_primal=int(np.sum(Bg < nv)), n_dual=int(np.sum(Bg >= nv)))
 
-    def _local(self, r, P, Tg, member, urank, owner, red_pos, chain_rank, leaf_rank, entries, positions) -> RankTables:
+    def _local(self, r, P, Tg, member, urank, owner, red_pos, chain_rank, leaf_rank, entries, positions, remap) -> RankTables:
         cls, blk = P["cls"], P["blk"]
+        if remap:                                   # the rank's shared nodes: chain nodes of its own segments
+            cls, blk = cls.copy(), blk.copy()
+            for u, gid in remap:
+                cls[u], blk[u] = CHAIN, gid
         univ = np.nonzero(member)[0].astype(np.int64)
         g2l = np.full(len(member), -1, np.int64)
         g2l[univ] = np.arange(len(univ))
@@ -165,28 +188,55 @@ class ShardedKktPlan:
         b_l[c_l == LEAF] = leaf_l[blk[univ][c_l == LEAF]]
         b_l[c_l == CHAIN] = chain_l[blk[univ][c_l == CHAIN]]
         assert np.all(b_l >= 0) and np.all(leaf_left >= 0)
-        own = (urank[univ] == r) | ((c_l == BORDER) & (owner[univ] == r))
+        shared = P["cls"][univ] == BORDER           # (by the whole plan's classes: the NLP's border and the cut nodes)
+        own = (urank[univ] == r) | (shared & (owner[univ] == r))
+        chain_export = None
+        if remap:
+            chain_export = np.zeros(len(my_chain), np.uint8)
+            chain_export[chain_l[[gid for _, gid in remap]]] = 1
         eu, ev, ekind, eidx, ecoef = entries
         nul = len(univ)
         T = kkt._finish(positions, 0, 0, nul, 0, 0, c_l.astype(np.int8), b_l, P["key_node"][univ], P["key_kind"][univ],
                         np.arange(nul, dtype=np.int64), P["dual"][univ], P["fixed"][univ] & own, len(my_leaf), len(my_chain),
                         seg_ptr, leaf_left, None, None, None, None, None, None,
                         entries=(g2l[eu], g2l[ev], ekind, eidx, ecoef),
-                        n_primal=int(np.sum(own & ~P["dual"][univ])), n_dual=int(np.sum(own & P["dual"][univ])))
-        base_border = int(T.leaf_ptr[-1]) + int(T.chain_ptr[-1])
+                        n_primal=int(np.sum(own & ~P["dual"][univ])), n_dual=int(np.sum(own & P["dual"][univ])),
+                        chain_export=chain_export)
+        base_chain = int(T.leaf_ptr[-1])
+        base_border = base_chain + int(T.chain_ptr[-1])
         border_red = red_pos[univ[T.perm[base_border:]]]
         assert np.all(border_red >= 0) and np.all(np.diff(border_red) > 0)   # a sub-sequence of the reduced order
-        return RankTables(T, univ, own, border_red)
+
+        def node_red(c):
+            return red_pos[univ[T.perm[base_chain + int(T.chain_ptr[c]):base_chain + int(T.chain_ptr[c + 1])]]]
+        export_red, export_anchor_red = [], []
+        for c, nz, nr in kkt.export_shapes(T):
+            seg = int(np.searchsorted(T.chain_phase_ptr, c, side="right") - 1)
+            export_red.append(node_red(c))
+            export_anchor_red.append(node_red(int(T.chain_phase_ptr[seg + 1] - 1)) if nr else np.zeros(0, np.int64))
+            assert np.all(export_red[-1] >= 0) and len(export_red[-1]) == nz and len(export_anchor_red[-1]) == nr
+        return RankTables(T, univ, own, border_red, export_red, export_anchor_red)
 
     # ---- what a rank contributes and takes, as index operations on whole-NLP vectors (shared by every driver) --------
     def local_vector(self, r, v):
         R = self.ranks[r]
         return np.where(R.own, np.asarray(v, float)[R.univ], 0.0)
 
-    def add_border(self, r, B_local, B_red):
-        """Add a rank's Schur complement on its local border (lower triangle valid) into the reduced matrix."""
-        ix = self.ranks[r].border_red
-        B_red[np.ix_(ix, ix)] += np.tril(np.asarray(B_local).reshape(len(ix), len(ix)))
+    def add_border(self, r, B_local, B_red, panels=None):
+        """Add a rank's terms into the reduced matrix (kept whole, both triangles): its Schur complement on its local
+        border (lower triangle valid) and the assembled panels [D | K | F] of its exported chain nodes."""
+        R = self.ranks[r]
+        ix = R.border_red
+        Bl = np.tril(np.asarray(B_local).reshape(len(ix), len(ix)))
+        B_red[np.ix_(ix, ix)] += Bl + np.tril(Bl, -1).T
+        for P_, ru, ra in zip(panels or [], R.export_red or [], R.export_anchor_red or []):
+            nz, nr = len(ru), len(ra)
+            B_red[np.ix_(ru, ru)] += P_[:, :nz]
+            if nr:
+                B_red[np.ix_(ru, ra)] += P_[:, nz:nz + nr]
+                B_red[np.ix_(ra, ru)] += P_[:, nz:nz + nr].T
+            B_red[np.ix_(ru, ix)] += P_[:, nz + nr:]
+            B_red[np.ix_(ix, ru)] += P_[:, nz + nr:].T
 
     def footprint(self, r) -> dict:
         """Doubles of matrix storage a rank's factorisation holds, against the unsharded plan's."""
@@ -201,7 +251,7 @@ def factor_ranks(plan: ShardedKktPlan, handles, reduced, dvec, use_hess=True, re
     cnt = np.zeros(2, np.int64)
     for r, h in handles.items():
         Bl, p, q = h.factor_partial(plan.local_vector(r, dvec), use_hess)
-        plan.add_border(r, Bl, B)
+        plan.add_border(r, Bl, B, h.export_panels() if plan.ranks[r].export_red else None)
         cnt += (p, q)
     if reduce is not None:
         B = reduce(B)
@@ -215,13 +265,18 @@ def solve_ranks(plan: ShardedKktPlan, handles, reduced, rhs, reduce=None):
     over processes by ``reduce`` into the whole vector."""
     rb = np.zeros(plan.nb_red)
     for r, h in handles.items():
-        rb[plan.ranks[r].border_red] += h.forward_partial(plan.local_vector(r, rhs))
+        R = plan.ranks[r]
+        rb[R.border_red] += h.forward_partial(plan.local_vector(r, rhs))
+        if R.export_red:
+            np.add.at(rb, np.concatenate(R.export_red), h.export_rhs())
     if reduce is not None:
         rb = reduce(rb)
     xb = reduced.solve(rb)
     x = np.zeros(plan.nu)
     for r, h in handles.items():
         R = plan.ranks[r]
+        if R.export_red:
+            h.import_solution(xb[np.concatenate(R.export_red)])
         xl = h.backward_partial(xb[R.border_red])
         x[R.univ[R.own]] = xl[R.own]
     if reduce is not None:

@@ -24,8 +24,10 @@ CASES = [("hypersensitive", dict(K=2000, order=6), 8), ("hypersensitive", dict(K
          ("sliding_mass", dict(num_phases=3, K=8, order=4), 2)]       # (the last: one tile per phase, i.e. one rank has it all)
 
 
+@pytest.mark.parametrize("ends", ["chain", "border"])
 @pytest.mark.parametrize("name,kw,world", CASES)
-def test_ranks_one_after_the_other_match_the_single_rank_factorisation(built, name, kw, world):
+def test_ranks_one_after_the_other_match_the_single_rank_factorisation(built, name, kw, world, ends):
+    """``ends``: the shared nodes as the un-eliminated ends of a rank's chain segments (default) or in its border."""
     import torch
     from pycollo_amd import kkt_sharded
     from pycollo_amd.kkt import GpuKkt
@@ -34,7 +36,7 @@ def test_ranks_one_after_the_other_match_the_single_rank_factorisation(built, na
     c, G, H = eng.evaluate_all(x, 1.0, lam)
     eng.evaluate_resident(x, 1.0, lam)
     sp = ShardPlan(eng, world)
-    plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, sp)
+    plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, sp, ends=ends)
     dev = torch.device("cuda", 0)
     vals = [[torch.from_numpy(a).to(dev) for a in rank_values(plan, sp, r, G, H)] for r in range(world)]
     busy = [r for r in range(world) if any(te > tb for tb, te in sp.tile_ranges[r])]
@@ -69,7 +71,11 @@ def test_ranks_one_after_the_other_match_the_single_rank_factorisation(built, na
     np.testing.assert_array_equal(sk.solve(rhs), sk.solve(rhs))
     # a rank's matrix storage: its share of the blocks, each widened by the rank's two cut nodes per phase, which ride in
     # its local border (1.2x the share for the 3-unknown nodes of the hypersensitive problem, 2.7x for the shuttle's 14)
-    assert max(plan.footprint(r)["local_vals"] for r in range(world)) <= 3.0 * k0.tables.total_vals / len(busy) + 65536
+    #  -- as chain ends they widen nothing: the rank's border is the NLP's own
+    bound = 3.0 if ends == "border" else 1.3
+    assert max(plan.footprint(r)["local_vals"] for r in range(world)) <= bound * k0.tables.total_vals / len(busy) + 65536
+    if ends == "chain":
+        assert all(plan.ranks[r].tables.nb == k0.tables.nb for r in range(world))
     for h in (sk, k0, kw_):
         h.close()
     eng.close()
