@@ -24,6 +24,7 @@ cases = [("hypersensitive", dict(K=2000, order=6)), ("cart_pole", dict(K=5000, o
 only = os.environ.get("KKT_PROBLEM")
 only_k = os.environ.get("KKT_K")
 worlds = [int(w) for w in os.environ.get("KKT_WORLDS", "2,4,8").split(",")]
+ends = os.environ.get("KKT_ENDS", "chain")
 for name, kw in cases:
     if (only and name != only) or (only_k and int(only_k) != kw["K"]) or (not only_k and kw["K"] >= 100000):
         continue
@@ -35,11 +36,11 @@ for name, kw in cases:
     x0 = k0.solve(rhs)
     inertia0 = k0.factor(dvec)
     mb0, nb0 = 8e-6 * k0.tables.total_vals, k0.tables.nb
-    print(f"{name} {kw}: nu {k0.nu}  single rank: factor {f0:.3f} ms  solve {s0:.3f} ms  matrix {mb0:.1f} MB  border {nb0}", flush=True)
+    print(f"{name} {kw} [shared nodes: {ends}]: nu {k0.nu}  single rank: factor {f0:.3f} ms  solve {s0:.3f} ms  matrix {mb0:.1f} MB  border {nb0}", flush=True)
     k0.close()
     for world in worlds:
         t0 = time.perf_counter()
-        plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, ShardPlan(eng, world))
+        plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, ShardPlan(eng, world), ends=ends)
         t_plan = time.perf_counter() - t0
         big = kw["K"] >= 100000
         fr, fw, bw = [], [], []
@@ -50,13 +51,18 @@ for name, kw in cases:
         for r in range(world):                       # one rank's handle at a time (a rank's matrix is what a GPU would hold)
             sk = kkt_sharded.ShardedKkt(eng, plan, [r])
             h = sk.handles[r]
+            R = plan.ranks[r]
+            exp = bool(R.export_red)
             Bl, p, q = h.factor_partial(plan.local_vector(r, dvec))
-            plan.add_border(r, Bl, B); cnt += (p, q)
-            rb[plan.ranks[r].border_red] += h.forward_partial(plan.local_vector(r, rhs))
+            plan.add_border(r, Bl, B, h.export_panels() if exp else None); cnt += (p, q)
+            rb[R.border_red] += h.forward_partial(plan.local_vector(r, rhs))
+            if exp:
+                np.add.at(rb, np.concatenate(R.export_red), h.export_rhs())
             if not big or r in (0, 1, world - 1):
-                fr.append(med(lambda: h.factor_partial(plan.local_vector(r, dvec)), 7))
-                fw.append(med(lambda: h.forward_partial(plan.local_vector(r, rhs)), 7))
-                bw.append(med(lambda: h.backward_partial(np.zeros(plan.ranks[r].tables.nb)), 7))
+                nexp = sum(len(a) for a in R.export_red) if exp else 0
+                fr.append(med(lambda: (h.factor_partial(plan.local_vector(r, dvec)), exp and h.export_panels()), 7))
+                fw.append(med(lambda: (h.forward_partial(plan.local_vector(r, rhs)), exp and h.export_rhs()), 7))
+                bw.append(med(lambda: (exp and h.import_solution(np.zeros(nexp)), h.backward_partial(np.zeros(R.tables.nb))), 7))
             if big:
                 sk.close()
             else:
@@ -73,6 +79,8 @@ for name, kw in cases:
             for r, sk in sks.items():
                 R = plan.ranks[r]
                 sk.handles[r].forward_partial(plan.local_vector(r, rhs))      # (the timing loops above overwrote its state)
+                if R.export_red:
+                    sk.handles[r].import_solution(xb[np.concatenate(R.export_red)])
                 xl = sk.handles[r].backward_partial(xb[R.border_red])
                 x1[R.univ[R.own]] = xl[R.own]
                 sk.close()
