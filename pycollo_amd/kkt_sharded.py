@@ -9,12 +9,16 @@ chain of every phase is **cut where the evaluation is cut**:
               kernels wrote (plus the handful the tail kernel writes, which every rank has after the exchange of the
               per-tile partial sums -- a few doubles per tile, never the rows);
   cut nodes   the node two ranks share (first node of a rank's range) -- its variables, path slacks / multipliers and the
-              defect multipliers of the rows that end on it -- join the *border* (``kkt._node_maps(cuts=...)``); a rank's
-              local border = the NLP's own border (integrals, times, parameters, endpoint rows) + its two cut nodes per
-              phase, so the width of its blocks does not grow with the number of ranks;
-  reduced     every rank's Schur complement on its local border is added into the system of all border unknowns
-  system      (one all-reduce of nb_red^2 doubles -- (8 ranks x 4 phases x ~20)^2 at the largest configuration here), which
-              every rank then factorises redundantly: a dense block of a few hundred unknowns.
+              defect multipliers of the rows that end on it -- is a chain node of BOTH ranks' segments (the last of the
+              one, the first of the other) and is eliminated by NEITHER (``KktTables.chain_export``): the cyclic reduction
+              of a segment runs between its two ends (an exported last node is the right separator of every node whose own
+              would lie beyond it), and the ends' assembled panels [D | K(first, last) | F] are what the rank adds to the
+              reduced system.  A rank's border is therefore the NLP's own (integrals, times, parameters, endpoint rows) and
+              its blocks are exactly as wide as the unsharded plan's.  (``ends="border"``: the first version -- the shared
+              nodes in the rank's local border, dense in every block; kept for the unchanged kernels and the NumPy oracle.)
+  reduced     every rank's terms -- its Schur complement on the border and its exported panels -- are added into the system
+  system      of all border and shared unknowns (one all-reduce of nb_red^2 doubles -- (8 ranks x 4 phases x ~20)^2 at the
+              largest configuration here), which every rank then factorises redundantly: a dense block of a few hundred.
 
 A solve is the same in three steps: local forward elimination, one all-reduce of the reduced right-hand side (nb_red
 doubles), the reduced solve, local back-substitution.  The pivot signs of all local blocks and of the reduced system add up
