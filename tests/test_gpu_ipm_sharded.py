@@ -56,7 +56,9 @@ rank = dist.get_rank()
 from pycollo_amd import problems
 from pycollo_amd.ipm_sharded import solve_sharded
 from pycollo_amd.iteration import MeshIteration
-for name, kw in (("hypersensitive", dict(K=400, order=6)), ("cart_pole", dict(K=300, order=4)), ("sliding_mass", dict(num_phases=3, K=120, order=5))):
+CASES = {2: (("hypersensitive", dict(K=400, order=6)), ("cart_pole", dict(K=300, order=4)), ("sliding_mass", dict(num_phases=3, K=120, order=5))),
+         4: (("hypersensitive", dict(K=800, order=6)), ("sliding_mass", dict(num_phases=2, K=400, order=4)))}[dist.get_world_size()]
+for name, kw in CASES:
     prob = problems.REGISTRY[name](**kw)
     b, sh = solve_sharded(MeshIteration(prob, device=0), max_iter=1500, tol=1e-8, poison=True)
     cuts = [len(c) for c in b.evaluations.get("cuts", [])]
@@ -67,7 +69,7 @@ for name, kw in (("hypersensitive", dict(K=400, order=6)), ("cart_pole", dict(K=
     busy = sum(1 for r in range(sh.world) if any(te > tb for tb, te in sh.plan.tile_ranges[r]))
     print(f"SHARDED IPM {name} rank {rank}: {busy} ranks with tiles, iterations {b.iterations} (single process {a.iterations}), "
           f"objective difference {df:.1e}, x difference {dx:.1e}, {b.evaluations['sharded']['evaluations']} sharded evaluations, ok: {ok}", flush=True)
-    if not ok or busy < 2:
+    if not ok or busy < dist.get_world_size():
         sys.exit(1)
 dist.barrier()
 dist.destroy_process_group()
@@ -75,18 +77,20 @@ print(f"SHARDED IPM rank {rank} done")
 '''
 
 
-def test_two_processes_solve_one_nlp(built, tmp_path):
+@pytest.mark.parametrize("nproc,n_cases", [(2, 3), (4, 2)])
+def test_several_processes_solve_one_nlp(built, tmp_path, nproc, n_cases):
+    """``nproc`` = 4: the middle ranks keep BOTH ends of their chain segments un-eliminated (a first node and an anchor)."""
     script = tmp_path / "ipm_two_ranks.py"
     script.write_text(_TWO_RANKS)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYCOLLO_AMD_KKT_RESID_TOL="0",
                PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), IPM_LOG=str(tmp_path / "trace"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(script)]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100)
     out = res.stdout + res.stderr
     traces = "".join(p.read_text() for p in tmp_path.glob("trace.*"))
     lines = "\n".join(ln for ln in out.splitlines() if "SHARDED IPM" in ln)
     assert res.returncode == 0, traces + lines + out[-1500:]
-    assert out.count("ok: True") == 6, lines
-    _keep(lines, "sharded_ipm_two_ranks.txt")
-    assert "SHARDED IPM rank 0 done" in out and "SHARDED IPM rank 1 done" in out
+    assert out.count("ok: True") == nproc * n_cases, lines
+    _keep(lines, f"sharded_ipm_{nproc}_ranks.txt")
+    assert all(f"SHARDED IPM rank {r} done" in out for r in range(nproc))
