@@ -311,6 +311,14 @@ typedef struct {
   const uint8_t* last_of_phase;
 } pc_kkt_plan;
 int pc_kkt_plan_positions(const pc_kkt_plan* plan, int64_t n, const int64_t* u, const int64_t* v, int64_t* out);
+/* Host-only: the tables of the chain's cyclic reduction as pc_kkt_create builds them (csrc/pc_kkt_cr.hpp) -- per chain node
+ * its separators (-1: none), the node whose Schur block holds its coupling to each (-1: neighbours in the chain), its level,
+ * and in CSR form the eliminated nodes it is a separator of (node << 1 | 1 if it is that node's left separator; pull_e holds
+ * pull_cap entries, 2 n_chain suffice).  chain_export as in pc_kkt_desc (may be NULL).  For the CPU tests, which hold the
+ * tables against a symbolic elimination of the chain graph. */
+int pc_kkt_cr_plan(int64_t n_chain, int64_t n_phase, const int64_t* chain_phase_ptr, const int64_t* chain_ptr, int64_t nb,
+                   const uint8_t* chain_export, int64_t* cr_a, int64_t* cr_b, int64_t* mid_a, int64_t* mid_b, int32_t* level,
+                   int64_t* pull_ptr, int32_t* pull_e, int64_t pull_cap);
 /* Host-only: the entry tables of pc_kkt_desc (dst, run_ptr, src_*, mv_*) from the CSR structures of H~ (hr, hc; lower
  * triangle), G~ (jr, jc; rows scaled by row_scale[m]), the slack columns of the ns inequality rows ineq_rows and the fixed
  * flags [nu], under the plan.  n = number of NLP variables, nv = n + ns.  counts[3] receives (n_src, n_dst, n_mv).

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/pycollo_amd.h"
+#include "pc_kkt_cr.hpp"
 
 namespace {
 
@@ -443,7 +444,6 @@ __global__ void kkt_chain_factor(KArgs a) {
 // accumulated in place: a node *pulls* what earlier levels owe it -- the leaves' Schur blocks, and for every level
 // below its own the Schur blocks of the two nodes eliminated next to it -- in a fixed order, so the factorisation is
 // bit-reproducible and needs one launch per level and no atomics.
-constexpr int CR_MAX_PULL = 64;   // two per level below a node's own: chains of up to 2^32 nodes
 struct CrNode {
   int nz, na, nb_, w;          // own unknowns, separators' (0 if none), border; w = na + nbr + nb
   int nbr;
@@ -1127,120 +1127,37 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       k->args.chain_lds = full <= 64000 ? 1 : 0;
       k->lds_chain_factor = (int)(k->args.chain_lds ? full : k->lds_chain);
     }
-    {   // cyclic reduction of the chain: levels, separators, what every node pulls from the levels below, buffer offsets
-      // A segment (a phase's chain, or with cuts a part of one) of n nodes, positions 0 .. n-1: at level l the positions
-      // (2k+1) 2^(l-1) are eliminated against their neighbours at distance 2^(l-1); position 0 goes last.  A node marked in
-      // desc.chain_export is NOT eliminated (a rank's part of a factorisation cut across ranks: the node it shares with its
-      // neighbour rank, kkt_sharded.py) -- only the two ends of a segment can be: an exported last node is the right
-      // separator of every node whose own would lie beyond it ("anchor"), an exported first node keeps position 0's place
-      // in the order.  Their assembled panels [D | K(first, last) | F] are what the rank adds to the reduced system.
+    {   // cyclic reduction of the chain: levels, separators, what every node pulls from the levels below (pc_kkt_cr.hpp)
       const int64_t nc = d->n_chain;
-      std::vector<int64_t> ca(nc, -1), cb(nc, -1), mida(nc, -1), midb(nc, -1), oP(nc), oS(nc), oG(nc);
-      std::vector<int> lvl(nc, 1);
-      std::vector<uint8_t> firstv(nc, 0), exported(nc, 0);
-      bool any_export = false;
-      if (d->chain_export)
-        for (int64_t c = 0; c < nc; ++c) any_export |= (exported[c] = d->chain_export[c] != 0) != 0;
-      struct Owe { int64_t sep; int32_t code; };
-      std::vector<Owe> owes;                     // (node that pulls, eliminated node << 1 | pulls as the LEFT separator)
-      owes.reserve((size_t)2 * nc);
-      int lmax = 1;
-      for (int64_t ph = 0; ph < d->n_phase; ++ph) {
-        const int64_t c0 = d->chain_phase_ptr[ph], n = d->chain_phase_ptr[ph + 1] - c0;
-        if (n <= 0) continue;
-        firstv[c0] = 1;
-        for (int64_t p = 1; p + 1 < n; ++p)
-          if (exported[c0 + p]) throw std::runtime_error("only the first and the last node of a chain segment can be exported");
-        const bool expN = n >= 2 && exported[c0 + n - 1];
-        const int64_t anchor = expN ? c0 + n - 1 : -1, n1 = expN ? n - 1 : n;
-        int levels = 0;
-        while (((int64_t)1 << levels) <= n1 - 1) ++levels;      // number of odd-even levels
-        for (int64_t p = 0; p < n1; ++p) {
-          if (p == 0) { lvl[c0] = levels + 1; cb[c0] = anchor; continue; }
-          const int l = __builtin_ctzll((unsigned long long)p) + 1;
-          const int64_t h = (int64_t)1 << (l - 1);
-          lvl[c0 + p] = l;
-          ca[c0 + p] = c0 + p - h;
-          cb[c0 + p] = p + h <= n1 - 1 ? c0 + p + h : anchor;
-        }
-        if (expN) lvl[anchor] = levels + 2;                     // after position 0, which may still be eliminated against it
-        lmax = std::max(lmax, levels + (expN ? 2 : 1));
-        // in level order: where a node's couplings to its separators come from (the node eliminated between them last,
-        // -1 = they are neighbours in the chain: the assembled entries), and what an eliminated node owes its separators
-        std::vector<std::vector<int64_t>> by_level((size_t)levels + 3);
-        for (int64_t p = 0; p < n; ++p) by_level[(size_t)lvl[c0 + p]].push_back(c0 + p);
-        std::map<std::pair<int64_t, int64_t>, int64_t> link;
-        for (size_t L = 1; L < by_level.size(); ++L)
-          for (int64_t c : by_level[L]) {
-            if (ca[c] >= 0) {
-              auto it = link.find({ca[c], c});
-              mida[c] = it != link.end() ? it->second : -1;
-              if (mida[c] < 0 && ca[c] != c - 1) throw std::runtime_error("cyclic reduction: a separator without a coupling (internal)");
-            }
-            if (cb[c] >= 0) {
-              auto it = link.find({c, cb[c]});
-              midb[c] = it != link.end() ? it->second : -1;
-              if (midb[c] < 0 && cb[c] != c + 1) throw std::runtime_error("cyclic reduction: a separator without a coupling (internal)");
-            }
-            if (exported[c]) continue;
-            if (cb[c] >= 0) owes.push_back({cb[c], (int32_t)(c << 1)});          // (the right separator's term first, as the
-            if (ca[c] >= 0) owes.push_back({ca[c], (int32_t)((c << 1) | 1)});   //  levels were summed before these tables)
-            if (ca[c] >= 0 && cb[c] >= 0) link[{ca[c], cb[c]}] = c;
-          }
-      }
-      if (nc >= ((int64_t)1 << 30)) throw std::runtime_error("chain too long for the pull tables");
-      // CSR by pulling node, stable in the order collected (level by level; inside a level by position: for a separator c
-      // the node c - h comes before c + h)
-      std::vector<int64_t> pull_ptr((size_t)nc + 1, 0);
-      for (const Owe& o : owes) ++pull_ptr[(size_t)o.sep + 1];
-      int64_t max_pull = 0;
-      for (int64_t c = 0; c < nc; ++c) {
-        max_pull = std::max(max_pull, pull_ptr[(size_t)c + 1]);
-        pull_ptr[(size_t)c + 1] += pull_ptr[(size_t)c];
-      }
-      std::vector<int32_t> pull_e(owes.size() ? owes.size() : 1, 0);
-      {
-        std::vector<int64_t> fill(pull_ptr.begin(), pull_ptr.end() - 1);
-        for (const Owe& o : owes) pull_e[(size_t)fill[(size_t)o.sep]++] = o.code;
-      }
-      int64_t off = 0, ldsmax = 0;
-      auto nzof = [&](int64_t c) { return d->chain_ptr[c + 1] - d->chain_ptr[c]; };
-      for (int64_t c = 0; c < nc; ++c) {
-        const int64_t nz = nzof(c), w = (ca[c] >= 0 ? nzof(ca[c]) : 0) + (cb[c] >= 0 ? nzof(cb[c]) : 0) + d->nb;
-        oP[c] = off; off += nz * (nz + w);
-        oS[c] = off; off += w * w;
-        oG[c] = off; off += w;
-        ldsmax = std::max(ldsmax, 8 * (2 * nz + w + nz * (nz + w) + w * w + 2));
-        if (nz > 64 || w > 64) ldsmax = 1 << 30;
-      }
-      k->chain_cr = ldsmax <= 64000 && max_pull <= CR_MAX_PULL;
+      CrPlan P;
+      cr_build(nc, d->n_phase, d->chain_phase_ptr, d->chain_ptr, d->nb, d->chain_export, P);
+      k->chain_cr = P.ldsmax <= 64000 && P.max_pull <= CR_MAX_PULL;
       if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CR")) k->chain_cr = k->chain_cr && std::atoi(env) != 0;
-      if (any_export && !k->chain_cr) throw std::runtime_error("exported chain nodes need the cyclic-reduction kernels (blocks too large for their LDS)");
-      k->any_export = any_export;
+      if (P.any_export && !k->chain_cr) throw std::runtime_error("exported chain nodes need the cyclic-reduction kernels (blocks too large for their LDS)");
+      k->any_export = P.any_export;
       if (k->chain_cr) {
         std::vector<int64_t> nodes;
         k->cr_lvl_ptr.assign(1, 0);
-        for (int l = 1; l <= lmax; ++l) {
+        for (int l = 1; l <= P.lmax; ++l) {
           for (int64_t c = 0; c < nc; ++c)
-            if (lvl[c] == l) nodes.push_back(c);
+            if (P.lvl[c] == l) nodes.push_back(c);
           k->cr_lvl_ptr.push_back((int64_t)nodes.size());
         }
-        k->lds_cr = (int)ldsmax;
-        k->crbuf.alloc((size_t)std::max<int64_t>(1, off));
-        k->cr_a.upload(ca.data(), ca.size()); k->cr_b.upload(cb.data(), cb.size());
-        k->cr_mid_a.upload(mida.data(), mida.size()); k->cr_mid_b.upload(midb.data(), midb.size());
-        k->pull_ptr.upload(pull_ptr.data(), pull_ptr.size()); k->pull_e.upload(pull_e.data(), pull_e.size());
-        k->chain_first.upload(firstv.data(), firstv.size());
-        if (any_export) {
-          k->chain_export.upload(exported.data(), exported.size());
+        k->lds_cr = (int)P.ldsmax;
+        k->crbuf.alloc((size_t)std::max<int64_t>(1, P.buf_len));
+        k->cr_a.upload(P.ca.data(), P.ca.size()); k->cr_b.upload(P.cb.data(), P.cb.size());
+        k->cr_mid_a.upload(P.mida.data(), P.mida.size()); k->cr_mid_b.upload(P.midb.data(), P.midb.size());
+        k->pull_ptr.upload(P.pull_ptr.data(), P.pull_ptr.size()); k->pull_e.upload(P.pull_e.data(), P.pull_e.size());
+        k->chain_first.upload(P.first.data(), P.first.size());
+        if (P.any_export) {
+          k->chain_export.upload(P.exported.data(), P.exported.size());
           for (int64_t c = 0; c < nc; ++c)
-            if (exported[c]) k->export_nodes.push_back(c);
+            if (P.exported[c]) k->export_nodes.push_back(c);
         }
-        k->crP_off.upload(oP.data(), oP.size()); k->crS_off.upload(oS.data(), oS.size()); k->crG_off.upload(oG.data(), oG.size());
-        k->h_crP_off = oP;
-        k->h_cr_b = cb;
+        k->crP_off.upload(P.oP.data(), P.oP.size()); k->crS_off.upload(P.oS.data(), P.oS.size()); k->crG_off.upload(P.oG.data(), P.oG.size());
+        k->h_crP_off = P.oP;
+        k->h_cr_b = P.cb;
         k->h_chain_ptr.assign(d->chain_ptr, d->chain_ptr + nc + 1);
-        k->cr_nodes.upload(nodes.data(), nodes.size());
       }
     }
     k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2 + 256));
@@ -1330,6 +1247,25 @@ static inline int64_t plan_position(const pc_kkt_plan* P, int64_t a, int64_t b) 
     pos = P->border_off + la * P->nb + lb;
   }
   return pos;
+}
+
+// Host-only (no device): the cyclic reduction's tables for a chain as pc_kkt_create builds them (pc_kkt_cr.hpp) -- what the
+// CPU tests hold against a symbolic elimination of the chain graph.
+int pc_kkt_cr_plan(int64_t n_chain, int64_t n_phase, const int64_t* chain_phase_ptr, const int64_t* chain_ptr, int64_t nb,
+                   const uint8_t* chain_export, int64_t* cr_a, int64_t* cr_b, int64_t* mid_a, int64_t* mid_b, int32_t* level,
+                   int64_t* pull_ptr, int32_t* pull_e, int64_t pull_cap) {
+  return guarded([&] {
+    if (!chain_phase_ptr || !chain_ptr || !cr_a || !cr_b || !mid_a || !mid_b || !level || !pull_ptr || !pull_e)
+      throw std::runtime_error("null argument");
+    CrPlan P;
+    cr_build(n_chain, n_phase, chain_phase_ptr, chain_ptr, nb, chain_export, P);
+    if ((int64_t)P.n_pull > pull_cap) throw std::runtime_error("pull_e too short");
+    for (int64_t c = 0; c < n_chain; ++c) {
+      cr_a[c] = P.ca[c]; cr_b[c] = P.cb[c]; mid_a[c] = P.mida[c]; mid_b[c] = P.midb[c]; level[c] = P.lvl[c];
+    }
+    for (int64_t c = 0; c <= n_chain; ++c) pull_ptr[c] = P.pull_ptr[c];
+    for (int64_t e = 0; e < P.n_pull; ++e) pull_e[e] = P.pull_e[e];
+  });
 }
 
 int pc_kkt_plan_positions(const pc_kkt_plan* P, int64_t n, const int64_t* u, const int64_t* v, int64_t* out) {
