@@ -1158,6 +1158,7 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
         k->h_crP_off = P.oP;
         k->h_cr_b = P.cb;
         k->h_chain_ptr.assign(d->chain_ptr, d->chain_ptr + nc + 1);
+        k->cr_nodes.upload(nodes.data(), nodes.size());
       }
     }
     k->lds_border = (int)(8 * (2 * (int64_t)d->nb + 2 + 256));
@@ -1203,6 +1204,16 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
       a.pull_ptr = k->pull_ptr.p; a.pull_e = k->pull_e.p;
       a.chain_first = k->chain_first.p;
       a.chain_export = k->any_export ? k->chain_export.p : nullptr;
+      // (every table the level kernels dereference must be in device memory before the first launch: a forgotten upload is a
+      //  null read on the GPU, not an error code)
+      if (d->n_chain > 0) {
+        const void* need[] = {a.crbuf, a.cr_a, a.cr_b, a.crP_off, a.crS_off, a.crG_off, a.cr_nodes, a.cr_mid_a, a.cr_mid_b,
+                              a.pull_ptr, a.pull_e, a.chain_first, a.chain_last, a.chain_ptr, a.chainD_off};
+        for (const void* q : need)
+          if (!q) throw std::runtime_error("internal: a cyclic-reduction table was not uploaded");
+        if ((int64_t)k->cr_nodes.n != d->n_chain || k->cr_lvl_ptr.back() != d->n_chain)
+          throw std::runtime_error("internal: the level lists do not cover the chain");
+      }
     }
   });
   if (!ok) {
