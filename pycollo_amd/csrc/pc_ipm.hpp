@@ -30,7 +30,7 @@ struct pc_ipm {
 namespace {
 
 constexpr int IPM_NRED = 16;      // scalars a reduction kernel may return
-constexpr int IPM_BLOCKS = 128;   // workgroups of a reduction (partials are combined in block order: fixed order)
+constexpr int IPM_BLOCKS = 128;   // workgroups of a reduction (<= 256: the last block combines the partials one per thread, fixed tree)
 enum { IPM_SUM = 0, IPM_MAX = 1, IPM_MIN = 2 };
 
 // Block reduction of K per-thread values (op per slot), then the last block to arrive combines the blocks' partials
@@ -60,18 +60,30 @@ __device__ __forceinline__ void ipm_reduce(double (&val)[K], const int (&op)[K],
     last = atomicAdd(counter, 1u) == gridDim.x - 1;
   }
   __syncthreads();
-  if (last && tid == 0) {
+  if (last) {
+    // The last block combines the blocks' partials with the same tree, thread b holding block b's (gridDim.x <= 256): a
+    // fixed shape, so the same bits every run.  (One thread walking K x gridDim.x partials in a row, as this was first
+    // written, took 65-75 us of a 1.08 ms interior-point iteration at config 2 -- twice per iteration.)
     __threadfence();
 #pragma unroll
-    for (int q = 0; q < K; ++q) {
-      double a = part[q];
-      for (unsigned b = 1; b < gridDim.x; ++b) {
-        const double x = part[(size_t)b * K + q];
-        a = op[q] == IPM_SUM ? a + x : (op[q] == IPM_MAX ? (x > a || x != x ? x : a) : (x < a || x != x ? x : a));
+    for (int q = 0; q < K; ++q)
+      sh[q][tid] = tid < (int)gridDim.x ? part[(size_t)tid * K + q] : (op[q] == IPM_SUM ? 0.0 : (op[q] == IPM_MAX ? -INFINITY : INFINITY));
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+          const double a = sh[q][tid], b = sh[q][tid + s];
+          sh[q][tid] = op[q] == IPM_SUM ? a + b : (op[q] == IPM_MAX ? (b > a || b != b ? b : a) : (b < a || b != b ? b : a));
+        }
       }
-      out[q] = a;
+      __syncthreads();
     }
-    *counter = 0;
+    if (tid == 0) {
+#pragma unroll
+      for (int q = 0; q < K; ++q) out[q] = sh[q][0];
+      *counter = 0;
+    }
   }
 }
 
