@@ -214,9 +214,11 @@ __device__ __forceinline__ void blk_sync() {
   if constexpr (WAVE) wave_lds_sync();
   else __syncthreads();
 }
+// (tid / nt: the calling thread's index among the nt threads that work on this block -- the workgroup by default; a wave
+//  of a workgroup that handles several blocks at once passes its lane and 64, kkt_cr_top)
 template <bool WAVE = false>
-__device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, double* lds) {
-  const int tid = threadIdx.x, nt = blockDim.x, ld = m + w;
+__device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, double* lds, int tid, int nt) {
+  const int ld = m + w;
   double* colL = lds;
   double* lcol = lds + m;
   double* rowC = lds + 2 * m;
@@ -298,8 +300,7 @@ __device__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, do
 
 // t = A^-1 r for a factored block (r in lds, length m; result left there); one workgroup
 template <bool WAVE = false>
-__device__ void block_solve(const double* M, int m, int ld, double* r) {
-  const int tid = threadIdx.x, nt = blockDim.x;
+__device__ void block_solve(const double* M, int m, int ld, double* r, int tid, int nt) {
   for (int j = 0; j < m; ++j) {
     blk_sync<WAVE>();
     const double rj = r[j];
@@ -313,6 +314,15 @@ __device__ void block_solve(const double* M, int m, int ld, double* r) {
     for (int i = tid; i < j; i += nt) r[i] -= M[(size_t)j * ld + i] * rj;
   }
   blk_sync<WAVE>();
+}
+
+template <bool WAVE = false>
+__device__ __forceinline__ void block_eliminate(double* M, int m, int w, double* S, int* cnt, double* lds) {
+  block_eliminate<WAVE>(M, m, w, S, cnt, lds, (int)threadIdx.x, (int)blockDim.x);
+}
+template <bool WAVE = false>
+__device__ __forceinline__ void block_solve(const double* M, int m, int ld, double* r) {
+  block_solve<WAVE>(M, m, ld, r, (int)threadIdx.x, (int)blockDim.x);
 }
 
 struct KArgs {
@@ -460,11 +470,10 @@ __device__ __forceinline__ CrNode cr_node(const KArgs& k, int64_t c) {
   n.w = n.na + n.nbr + k.nb;
   return n;
 }
-// launch: one workgroup (one wave) per node of the level; `first` = offset of the level in cr_nodes
-__global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first) {
-  extern __shared__ double lds[];
-  const int tid = threadIdx.x, nb = k.nb;
-  const int64_t c = k.cr_nodes[first + blockIdx.x];
+// One chain node's turn in the factorisation, by one wave (tid = its lane): lds = the wave's scratch of the level kernels'
+// dynamic LDS size, pl_* = its five tables of CR_MAX_PULL entries.
+__device__ void cr_factor_node(const KArgs& k, int64_t c, double* lds, int64_t* pl_off, int* pl_row, int* pl_ew, int* pl_cD, int* pl_cF, int tid) {
+  const int nb = k.nb;
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, na = me.na, nr = me.nbr, w = me.w, ld = nz + w;
   double* M = lds + (2 * nz + w);                 // [nz][ld] panel; block_eliminate's scratch in front
@@ -474,8 +483,6 @@ __global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first) {
   // separator of (host list, level by level) -- where its Schur block starts, the row and column offsets of c's part in
   // it.  The element loop below then issues one load per entry and pulled node; with these look-ups inside it (four
   // dependent index loads per entry, level and side) the level kernels of a 9-unknown node took 35 us each at config 3.
-  __shared__ int64_t pl_off[CR_MAX_PULL];
-  __shared__ int pl_row[CR_MAX_PULL], pl_ew[CR_MAX_PULL], pl_cD[CR_MAX_PULL], pl_cF[CR_MAX_PULL];
   const int64_t q0 = k.pull_ptr[c];
   const int npull = (int)(k.pull_ptr[c + 1] - q0);
   if (tid < npull) {
@@ -545,16 +552,20 @@ __global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first) {
     if (tid < 2) k.counts[2 * (k.n_leaf + c) + tid] = 0;
     return;
   }
-  block_eliminate<true>(M, nz, w, S, k.counts + 2 * (k.n_leaf + c), lds);
+  block_eliminate<true>(M, nz, w, S, k.counts + 2 * (k.n_leaf + c), lds, tid, 64);
   double* Sg = k.crbuf + k.crS_off[c];
   for (int e = tid; e < nz * ld; e += 64) Pg[e] = M[e];
   for (int e = tid; e < w * w; e += 64) Sg[e] = S[e];
 }
-
-__global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first) {
+// launch: one workgroup (one wave) per node of the level; `first` = offset of the level in cr_nodes
+__global__ void __launch_bounds__(64) kkt_cr_factor(KArgs k, int64_t first) {
   extern __shared__ double lds[];
-  const int tid = threadIdx.x;
-  const int64_t c = k.cr_nodes[first + blockIdx.x];
+  __shared__ int64_t pl_off[CR_MAX_PULL];
+  __shared__ int pl_row[CR_MAX_PULL], pl_ew[CR_MAX_PULL], pl_cD[CR_MAX_PULL], pl_cF[CR_MAX_PULL];
+  cr_factor_node(k, k.cr_nodes[first + blockIdx.x], lds, pl_off, pl_row, pl_ew, pl_cD, pl_cF, (int)threadIdx.x);
+}
+
+__device__ void cr_forward_node(const KArgs& k, int64_t c, double* lds, int64_t* pg_off, int tid) {
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, w = me.w, ld = nz + w;
   const bool first_in_phase = k.chain_first[c] != 0, last_in_phase = k.chain_last[c] != 0;
@@ -565,7 +576,6 @@ __global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first) {
   if (!exported)
     for (int e = tid; e < nz * ld; e += 64) M[e] = Pg[e];
   // (where the levels below left what they owe this node's right-hand side: looked up once, as in kkt_cr_factor)
-  __shared__ int64_t pg_off[CR_MAX_PULL];
   const int64_t q0 = k.pull_ptr[c];
   const int npull = (int)(k.pull_ptr[c + 1] - q0);
   if (tid < npull) {
@@ -594,13 +604,17 @@ __global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first) {
     for (int i = 0; i < nz; ++i) g += M[(size_t)i * ld + nz + tid] * rr[i];
     k.crbuf[k.crG_off[c] + tid] = g;
   }
-  block_solve<true>(M, nz, ld, rr);
+  block_solve<true>(M, nz, ld, rr, tid, 64);
   if (tid < nz) k.r[k.base_chain + k.chain_ptr[c] + tid] = rr[tid];
 }
+__global__ void __launch_bounds__(64) kkt_cr_forward(KArgs k, int64_t first) {
+  extern __shared__ double lds[];
+  __shared__ int64_t pg_off[CR_MAX_PULL];
+  cr_forward_node(k, k.cr_nodes[first + blockIdx.x], lds, pg_off, (int)threadIdx.x);
+}
 
-__global__ void __launch_bounds__(64) kkt_cr_backward(KArgs k, int64_t first) {
-  const int tid = threadIdx.x, nb = k.nb;
-  const int64_t c = k.cr_nodes[first + blockIdx.x];
+__device__ void cr_backward_node(const KArgs& k, int64_t c, int tid) {
+  const int nb = k.nb;
   if (k.chain_export && k.chain_export[c]) return;   // (its solution comes from the reduced system)
   const CrNode me = cr_node(k, c);
   const int nz = me.nz, na = me.na, nr = me.nbr, ld = nz + me.w;
@@ -613,6 +627,41 @@ __global__ void __launch_bounds__(64) kkt_cr_backward(KArgs k, int64_t first) {
     const double* xB = k.r + k.base_border;
     for (int q = 0; q < nb; ++q) v -= row[na + nr + q] * xB[q];
     k.r[k.base_chain + k.chain_ptr[c] + tid] = v;
+  }
+}
+__global__ void __launch_bounds__(64) kkt_cr_backward(KArgs k, int64_t first) {
+  cr_backward_node(k, k.cr_nodes[first + blockIdx.x], (int)threadIdx.x);
+}
+
+// The last levels of the reduction hold a handful of nodes each (16, 8, 4, 2, 1, 1 of config 2's 501): as launches of
+// their own each pays a kernel's fixed cost for a few microseconds of work.  Here ONE workgroup runs them all: a wave per
+// node, the level's nodes dealt over the waves, a workgroup barrier between levels (what a level leaves in device memory
+// is read by other waves of the same workgroup on the same compute unit).  Same per-node code, same bits.
+// KIND 0: factorisation, 1: forward elimination, 2: back-substitution (levels walked downwards).
+struct CrTop {
+  int64_t ptr[18];     // level offsets into cr_nodes: levels [0, n) of the fused range
+  int32_t n;
+  int32_t wave_bytes;  // LDS per wave: the level kernels' dynamic size + the pull tables
+};
+template <int KIND>
+__global__ void __launch_bounds__(1024) kkt_cr_top(KArgs k, CrTop t) {
+  extern __shared__ double lds[];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63, nw = (int)blockDim.x >> 6;
+  char* mine = reinterpret_cast<char*>(lds) + (size_t)wave * t.wave_bytes;
+  int64_t* tab64 = reinterpret_cast<int64_t*>(mine);                       // [CR_MAX_PULL]
+  int* tab32 = reinterpret_cast<int*>(mine + 8 * CR_MAX_PULL);             // 4 x [CR_MAX_PULL]
+  double* scratch = reinterpret_cast<double*>(mine + 24 * CR_MAX_PULL);
+  for (int s = 0; s < t.n; ++s) {
+    const int l = KIND == 2 ? t.n - 1 - s : s;
+    const int64_t first = t.ptr[l], cnt = t.ptr[l + 1] - first;
+    for (int64_t i = wave; i < cnt; i += nw) {
+      const int64_t c = k.cr_nodes[first + i];
+      if constexpr (KIND == 0) cr_factor_node(k, c, scratch, tab64, tab32, tab32 + CR_MAX_PULL, tab32 + 2 * CR_MAX_PULL, tab32 + 3 * CR_MAX_PULL, lane);
+      else if constexpr (KIND == 1) cr_forward_node(k, c, scratch, tab64, lane);
+      else cr_backward_node(k, c, lane);
+    }
+    __threadfence_block();
+    __syncthreads();
   }
 }
 
@@ -895,6 +944,9 @@ struct pc_kkt {
   int lds_chain_factor = 0;
   bool chain_cr = false;     // the chain by cyclic reduction: one launch per level
   std::vector<int64_t> cr_lvl_ptr;   // nodes of level l: cr_nodes[cr_lvl_ptr[l-1] .. cr_lvl_ptr[l])
+  size_t cr_top_from = 0;            // levels [cr_top_from, cr_lvl_ptr.size()) run in one launch (kkt_cr_top); = size(): none
+  int cr_top_waves = 0, cr_top_lds = 0;
+  CrTop cr_top{};
   int lds_cr = 0;
   Dev<double> crbuf;
   Dev<int64_t> cr_a, cr_b, crP_off, crS_off, crG_off, cr_nodes, cr_mid_a, cr_mid_b, pull_ptr;
@@ -955,17 +1007,41 @@ static void border_terms_device(pc_kkt* k) {
   hipLaunchKernelGGL(kkt_border_terms_sum, dim3(n_entries), dim3(64), 0, k->stream, k->border_part.p, n_entries, k->border_blocks);
 }
 
+// the chain's levels on the handle's stream: one launch per level with many nodes, one launch for all the last ones
+// KIND 0: factorisation, 1: forward elimination, 2: back-substitution (downwards)
+template <int KIND>
+static void cr_levels_device(pc_kkt* k) {
+  hipStream_t st = k->stream;
+  // (the factorisation keeps a launch per level: its node kernel under a 1 024-thread workgroup's register budget measured
+  //  9 % slower at config 3 -- 0.65 -> 0.71 ms -- and no faster at config 2; the two substitutions gain 5-8 % at config 2 and
+  //  lose nothing at config 3, profiles/r04_ipm_iter_time.txt)
+  const size_t L = k->cr_lvl_ptr.size(), from = KIND == 0 ? L : k->cr_top_from;
+  auto level = [&](size_t l) {
+    const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
+    if (cnt <= 0) return;
+    if (KIND == 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
+    else if (KIND == 1) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
+    else hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
+  };
+  auto top = [&] {
+    if (from < L) hipLaunchKernelGGL(kkt_cr_top<KIND>, dim3(1), dim3(64 * k->cr_top_waves), k->cr_top_lds, st, k->args, k->cr_top);
+  };
+  if (KIND == 2) {
+    top();
+    for (size_t l = from - 1; l >= 1; --l) level(l);
+  } else {
+    for (size_t l = 1; l < from; ++l) level(l);
+    top();
+  }
+}
+
 static void forward_device(pc_kkt* k, const double* d_rhs) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
   hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, d_rhs, k->perm.p, k->fixed.p, k->r.p, k->nu);
   if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
-  if (k->chain_cr) {
-    for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
-      const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_forward, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
-    }
-  } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
+  if (k->chain_cr) cr_levels_device<1>(k);
+  else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
 }
 static void backward_device(pc_kkt* k, double* d_x);
 static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
@@ -977,12 +1053,8 @@ static void solve_device(pc_kkt* k, const double* d_rhs, double* d_x) {
 static void backward_device(pc_kkt* k, double* d_x) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
-  if (k->chain_cr) {
-    for (size_t l = k->cr_lvl_ptr.size() - 1; l >= 1; --l) {
-      const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-      if (cnt > 0) hipLaunchKernelGGL(kkt_cr_backward, dim3((unsigned)cnt), dim3(64), 0, st, k->args, first);
-    }
-  } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
+  if (k->chain_cr) cr_levels_device<2>(k);
+  else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_backward, dim3(k->n_phase), dim3(64), 0, st, k->args);
   if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_backward, dim3(k->n_leaf), dim3(64), 0, st, k->args);
   hipLaunchKernelGGL(kkt_perm_out, dim3(nbk), dim3(256), 0, st, k->r.p, k->perm.p, d_x, k->nu);
   KHIP(hipGetLastError());
@@ -1144,6 +1216,23 @@ int pc_kkt_create(const pc_kkt_desc* d, const double* d_jac, const double* d_hes
           k->cr_lvl_ptr.push_back((int64_t)nodes.size());
         }
         k->lds_cr = (int)P.ldsmax;
+        {   // the last levels in one launch (kkt_cr_top): as many trailing levels as hold at most two nodes per wave
+          const size_t L = k->cr_lvl_ptr.size();
+          const int wave_bytes = (int)(((int64_t)P.ldsmax + 24 * CR_MAX_PULL + 15) & ~(int64_t)15);
+          int nw = (int)std::min<int64_t>(16, 65536 / wave_bytes);
+          if (const char* env = std::getenv("PYCOLLO_AMD_KKT_CR_TOP")) nw = std::min(nw, std::atoi(env));   // (0 / 1: off)
+          size_t from = L;
+          if (nw >= 2) {
+            while (from > 1 && k->cr_lvl_ptr[from - 1] - k->cr_lvl_ptr[from - 2] <= nw && L - (from - 1) <= 17) --from;
+            if (L - from < 2) from = L;             // (a single level gains nothing over its own launch)
+          }
+          k->cr_top_from = from;
+          k->cr_top_waves = nw;
+          k->cr_top_lds = nw * wave_bytes;
+          k->cr_top.n = (int32_t)(L - from);
+          k->cr_top.wave_bytes = wave_bytes;
+          for (size_t i = 0; from + i <= L && i < 18; ++i) k->cr_top.ptr[i] = k->cr_lvl_ptr[from - 1 + i];
+        }
         k->crbuf.alloc((size_t)std::max<int64_t>(1, P.buf_len));
         k->cr_a.upload(P.ca.data(), P.ca.size()); k->cr_b.upload(P.cb.data(), P.cb.size());
         k->cr_mid_a.upload(P.mida.data(), P.mida.size()); k->cr_mid_b.upload(P.midb.data(), P.midb.size());
@@ -1395,12 +1484,8 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
       la.lds_doubles = k->lds_leaf_full / 8;
       hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(128), k->lds_leaf_full, st, la);
     }
-    if (k->chain_cr) {
-      for (size_t l = 1; l < k->cr_lvl_ptr.size(); ++l) {
-        const int64_t first = k->cr_lvl_ptr[l - 1], cnt = k->cr_lvl_ptr[l] - first;
-        if (cnt > 0) hipLaunchKernelGGL(kkt_cr_factor, dim3((unsigned)cnt), dim3(64), k->lds_cr, st, k->args, first);
-      }
-    } else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
+    if (k->chain_cr) cr_levels_device<0>(k);
+    else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
     border_terms_device<false>(k);
     if (border_mode == 0) hipLaunchKernelGGL(kkt_border_factor<0>, dim3(1), dim3(256), k->lds_border, st, k->args);
     else hipLaunchKernelGGL(kkt_border_factor<1>, dim3(1), dim3(256), k->lds_border, st, k->args);
