@@ -1407,13 +1407,29 @@ int pc_kkt_plan_entries(const pc_kkt_plan* P, int64_t n, int64_t nv, int64_t nH,
     const int64_t ne = (int64_t)E.size();
     // order by destination, entries of one destination in the order they were listed (what a stable argsort gives)
     // (as pairs (destination, entry number): the keys travel with the elements, no indirect comparisons)
-    std::vector<std::pair<int64_t, int64_t>> key((size_t)ne);
-    for (int64_t e = 0; e < ne; ++e) key[e] = {E[e].d, e};
-    std::sort(key.begin(), key.end());
+    // (a stable least-significant-digit radix sort of the entry numbers by destination, 11 bits a pass: the comparison sort of
+    //  (destination, entry) pairs it replaces took a third longer at config 3's 1.1 M entries: 118 -> 105 ms for the whole build)
     std::vector<int64_t> so((size_t)ne);
-    for (int64_t e = 0; e < ne; ++e) so[e] = key[e].second;
-    key.clear();
-    key.shrink_to_fit();
+    {
+      std::vector<int64_t> key((size_t)ne), key2((size_t)ne), tmp((size_t)ne);
+      int64_t dmax = 0;
+      for (int64_t e = 0; e < ne; ++e) { so[e] = e; key[e] = E[e].d; dmax = std::max(dmax, key[e]); }
+      constexpr int BITS = 11;
+      std::vector<int64_t> bucket((size_t)1 << BITS);
+      for (int shift = 0; shift < 63 && (dmax >> shift) != 0; shift += BITS) {
+        std::fill(bucket.begin(), bucket.end(), 0);
+        for (int64_t e = 0; e < ne; ++e) ++bucket[(size_t)((key[e] >> shift) & ((1 << BITS) - 1))];
+        int64_t run = 0;
+        for (auto& b : bucket) { const int64_t c = b; b = run; run += c; }
+        for (int64_t e = 0; e < ne; ++e) {
+          const int64_t p = bucket[(size_t)((key[e] >> shift) & ((1 << BITS) - 1))]++;
+          key2[(size_t)p] = key[e];
+          tmp[(size_t)p] = so[e];
+        }
+        key.swap(key2);
+        so.swap(tmp);
+      }
+    }
     int64_t n_dst = 0, n_mv = 0;
     for (int64_t k = 0; k < ne; ++k) {
       if (k == 0 || E[so[k]].d != E[so[k - 1]].d) ++n_dst;
