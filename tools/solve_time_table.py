@@ -19,7 +19,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "hypersensitive"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 order = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 max_iter = int(os.environ.get("MAX_ITER", "200"))
-for ls in ("gpu", "host"):
+for ls in os.environ.get("LINEAR_SOLVERS", "resident,gpu,host").split(","):
     it = MeshIteration(problems.REGISTRY[name](K=K, order=order), device=0)
     t0 = time.perf_counter()
     res = it.solve_with_ipm(max_iter=max_iter, tol=1e-8, linear_solver=ls)
