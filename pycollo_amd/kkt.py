@@ -144,7 +144,7 @@ class _Plan(C.Structure):
 
 
 def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: str = "library", cuts=None,
-                 _parts: dict | None = None) -> KktTables:
+                 _parts: dict | None = None, _layout_only: bool = False) -> KktTables:
     """``ineq_rows``: constraint rows with a slack (in order); ``fixed_v`` [n + ns]: primal unknowns held fixed;
     ``row_scale`` [m]: the solver's constraint-row scaling (multiplies G~ row-wise); ``group``: mesh sections per leaf
     (int or one per phase; default ``default_group``); ``cuts``: per phase the nodes at which the chain is cut
@@ -227,6 +227,10 @@ def build_tables(engine, ineq_rows, fixed_v, row_scale, group=None, positions: s
                       fixed=fixed.copy(), n=n, m=m, ns=ns, nv=nv, nu=nu, n_leaf=n_leaf, n_chain=n_chain,
                       chain_phase_ptr=chain_phase_ptr.copy(), leaf_left=leaf_left.copy(), maps=maps, chain_base=chain_base,
                       leaf_phase_ptr=leaf_phase_ptr, hr=hr, hc=hc, jr=jr, jc=jc, group=list(group), u_phase=u_phase, u_node=u_node)
+    if _layout_only:     # (block order and value-buffer layout without the entry tables: what kkt_sharded needs of the whole plan)
+        e0 = (np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0))
+        return _finish("positions", n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
+                       chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows, entries=e0)
     return _finish(positions, n, nv, nu, ns, m, cls, blk, key_node, key_kind, key_idx, dual, fixed, n_leaf, n_chain,
                    chain_phase_ptr, leaf_left, hr, hc, jr, jc, row_scale, ineq_rows)
 

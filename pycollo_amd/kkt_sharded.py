@@ -72,7 +72,7 @@ class ShardedKktPlan:
     """Local tables of every rank and the reduced system, from one classification of the whole NLP's unknowns."""
 
     def __init__(self, engine, ineq_rows, fixed_v, row_scale, shard_plan, group=None, positions="positions", only=None,
-                 ends="chain"):
+                 ends="chain", whole_entries=False):
         """``only``: the ranks whose local tables are built (default all; a process needs its own -- ``ranks[r]`` is None
         for the others; the checks that every entry is assembled exactly once still cover every rank).
 
@@ -80,7 +80,11 @@ class ShardedKktPlan:
         of its chain segment, *not eliminated* (``KktTables.chain_export``): the cyclic reduction runs between them and
         their assembled panels are the rank's term of the reduced system -- the rank's border is the NLP's own.
         "border": in the rank's local border (every block of the rank then carries their columns: the first version,
-        kept because it runs on the unchanged elimination kernels and in the NumPy oracle)."""
+        kept because it runs on the unchanged elimination kernels and in the NumPy oracle).
+
+        ``whole_entries``: also build the entry tables of ``self.whole`` (the cut plan as ONE system: the tests' cross-check);
+        by default only its block order and layout are computed -- the entry tables of the whole NLP are exactly what a
+        rank of a sharded solve should not have to build."""
         if ends not in ("chain", "border"):
             raise ValueError("ends must be 'chain' or 'border'")
         self.ends = ends
@@ -89,7 +93,8 @@ class ShardedKktPlan:
         self.cuts, self.seg_rank = shard_cuts(engine, shard_plan)
         P: dict = {}
         # the cut plan as one system (a single rank can run it: the reference of the tests, and the border's order)
-        self.whole = Tg = kkt.build_tables(engine, ineq_rows, fixed_v, row_scale, group, cuts=self.cuts, _parts=P)
+        self.whole = Tg = kkt.build_tables(engine, ineq_rows, fixed_v, row_scale, group, cuts=self.cuts, _parts=P,
+                                           _layout_only=not whole_entries)
         cls, blk, nu, nv, n = P["cls"], P["blk"], P["nu"], P["nv"], P["n"]
         self.nu = nu
         base_border = int(Tg.leaf_ptr[-1]) + int(Tg.chain_ptr[-1])
@@ -140,25 +145,30 @@ class ShardedKktPlan:
         eowner = pos_owner[src_pos]
         eowner = np.where(eowner < 0, 0, eowner)
         a_in, b_in = ~is_border[eu], ~is_border[ev]
-        taken = np.zeros(len(eu), np.int64)
+        # the rank that assembles an entry: the one that eliminates an end of it, else the one whose tiles write its source
+        # (one pass over the entries, not one per rank: 10 M entries at 60 k shuttle nodes)
+        erank = eowner.copy()
+        erank[b_in] = urank[ev[b_in]]
+        erank[a_in] = urank[eu[a_in]]
+        both = a_in & b_in
+        if np.any(urank[eu[both]] != urank[ev[both]]):
+            raise RuntimeError("a KKT entry is assembled by no rank or by two")
+        if not (member[erank, eu].all() and member[erank, ev].all()):
+            bad = int(erank[np.nonzero(~(member[erank, eu] & member[erank, ev]))[0][0]])
+            raise RuntimeError(f"rank {bad}: a KKT entry couples its blocks with an unknown outside its local border")
+        so = pos_owner[src_pos]                    # a rank must find every source it reads among its own tile outputs or the tail's
+        if np.any((so >= 0) & (so != erank)):
+            bad = int(erank[np.nonzero((so >= 0) & (so != erank))[0][0]])
+            raise RuntimeError(f"rank {bad}: a KKT entry of its blocks is written by another rank's tiles")
         self.ranks: list[RankTables] = []
         for r in range(W):
-            sel = (a_in & (urank[eu] == r)) | (b_in & (urank[ev] == r)) | (~a_in & ~b_in & (eowner == r))
-            if not (member[r, eu[sel]].all() and member[r, ev[sel]].all()):
-                raise RuntimeError(f"rank {r}: a KKT entry couples its blocks with an unknown outside its local border")
-            # a rank must find every source it reads among its own tile outputs or the tail's
-            so = pos_owner[src_pos[sel]]
-            if np.any((so >= 0) & (so != r)):
-                raise RuntimeError(f"rank {r}: a KKT entry of its blocks is written by another rank's tiles")
-            taken += sel
             if only is not None and r not in only:
                 self.ranks.append(None)
                 continue
+            sel = erank == r
             self.ranks.append(self._local(r, P, Tg, member[r], urank, owner, red_pos, chain_rank, leaf_rank,
                                           (eu[sel], ev[sel], ekind[sel], eidx[sel], ecoef[sel]), positions,
                                           remap[r] if ends == "chain" else []))
-        if not np.all(taken == 1):
-            raise RuntimeError("a KKT entry is assembled by no rank or by two")
         # ---- the reduced system: all border unknowns, dense, its entries arrive as the ranks' Schur complements --------
         nr = self.nb_red
         z = np.zeros(nr, np.int64)

@@ -36,7 +36,7 @@ def test_ranks_one_after_the_other_match_the_single_rank_factorisation(built, na
     c, G, H = eng.evaluate_all(x, 1.0, lam)
     eng.evaluate_resident(x, 1.0, lam)
     sp = ShardPlan(eng, world)
-    plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, sp, ends=ends)
+    plan = kkt_sharded.ShardedKktPlan(eng, ineq, fixed, sc, sp, ends=ends, whole_entries=True)
     dev = torch.device("cuda", 0)
     vals = [[torch.from_numpy(a).to(dev) for a in rank_values(plan, sp, r, G, H)] for r in range(world)]
     busy = [r for r in range(world) if any(te > tb for tb, te in sp.tile_ranges[r])]
