@@ -137,10 +137,23 @@ class MeshIteration:
         ``linear_solver``: "resident" (default) -- as "gpu", and the iteration's vectors stay on the device too
         (``ipm.ResidentInteriorPointSolver``, csrc/pc_ipm.hpp); "gpu" -- the KKT systems are assembled from device-resident G~ / H~ and factorised on the
         GPU (``pycollo_amd.kkt``; the role of IPOPT's ``linear_solver`` option, pycollo/backend.py:1703-1711);
-        "host" -- the callbacks deliver host arrays and SuperLU factorises (what a host-side IPOPT would do).
+        "host" -- the callbacks deliver host arrays and SuperLU factorises (what a host-side IPOPT would do);
+        "sharded" -- called by every rank of a ``torch.distributed`` world: sharded evaluation, KKT factorisation cut across
+        the ranks, replicated vectors (``ipm_sharded.solve_sharded``).
         ``warm_start``: pycollo's setting of that name (settings.py:228, backend.py:1703-1709).
         ``host_retry`` (off by default): repeat an NLP whose GPU-factorised solve did not succeed once more with the host
         factorisation (a second full solve on SuperLU; reported through a RuntimeWarning and the result's flags)."""
+        if linear_solver == "sharded":
+            # every rank of the torch.distributed world calls this with the same mesh iteration: the evaluation sharded by
+            # section ranges, the KKT factorisation cut across the ranks, the iteration on replicated vectors (ipm_sharded.py)
+            from .ipm_sharded import solve_sharded
+            res, sh = solve_sharded(self, max_iter=max_iter, tol=tol, verbose=verbose, warm_start=warm_start,
+                                    second_order_correction=os.environ.get("PYCOLLO_AMD_SOC", "1") != "0")
+            sh.release()
+            self.result = res
+            self.x_tilde = res.x
+            self.objective = res.objective / self.w
+            return res
         from .engine import PycolloGpuProblem
         from .ipm import GpuInteriorPointSolver, InteriorPointSolver, ResidentInteriorPointSolver
         pobj = PycolloGpuProblem(self.engine)

@@ -385,6 +385,16 @@ class ShardedNlp:
         return self.c, self.G, self.H
 
 
+    def release(self):
+        """Give the engine back whole: every phase's full tile range, its own partial-sum buffers (an engine adopted with
+        ``engine=`` goes on to serve its mesh iteration: mesh-error estimate, scaling)."""
+        import torch
+        torch.cuda.synchronize()
+        for ip, (k0, nred) in enumerate(self.plan.tiles):
+            if nred:
+                self.engine.set_partials_buffer(ip, None)
+            self.engine.set_tile_range(ip, 0, len(k0) - 1)
+
     def evaluate_local_device(self, d_x, obj_factor, d_lam, stream=None):
         """The evaluation for a consumer that reads only this rank's rows (the KKT factorisation cut across ranks,
         ``kkt_sharded.ShardedKkt``): the rank's tiles, an all-gather of the **per-tile partial sums only**, the tail on

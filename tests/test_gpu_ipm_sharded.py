@@ -94,3 +94,51 @@ def test_several_processes_solve_one_nlp(built, tmp_path, nproc, n_cases):
     assert out.count("ok: True") == nproc * n_cases, lines
     _keep(lines, f"sharded_ipm_{nproc}_ranks.txt")
     assert all(f"SHARDED IPM rank {r} done" in out for r in range(nproc))
+
+
+_OCP_TWO_RANKS = r'''
+import os, sys, traceback
+def _excepthook(t, v, tb):
+    with open(os.environ["IPM_LOG"] + f".{os.environ.get('RANK', '0')}", "w") as f:
+        traceback.print_exception(t, v, tb, file=f)
+    traceback.print_exception(t, v, tb)
+sys.excepthook = _excepthook
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+from pycollo_amd import problems
+from pycollo_amd.solve import solve_ocp
+prob = problems.hypersensitive(K=300, order=4)
+b = solve_ocp(prob, linear_solver="sharded", max_mesh_iterations=6)
+a = solve_ocp(prob, linear_solver="gpu", max_mesh_iterations=6)
+same = a.mesh_iterations == b.mesh_iterations and abs(a.objective - b.objective) <= 1e-9 * abs(a.objective)
+ref = abs(b.objective - 3.36206) <= 1e-5 * 3.36206          # the reference's assertion, tests/integration/test_hypersensitive_problem.py:129-130
+meshes = [it["N"][0] for it in b.iterations]
+print(f"SHARDED OCP rank {rank}: objective {b.objective:.8f} (single process {a.objective:.8f}), mesh iterations {b.mesh_iterations} / {a.mesh_iterations}, "
+      f"nodes {meshes}, tolerance met {b.mesh_tolerance_met}, ok: {bool(same and ref and b.mesh_tolerance_met)}", flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if (same and ref and b.mesh_tolerance_met) else 1)
+'''
+
+
+def test_two_processes_solve_an_optimal_control_problem_through_the_mesh_loop(built, tmp_path):
+    """``solve_ocp(..., linear_solver="sharded")`` on two ranks: every mesh iteration's NLP solved by both, the engine handed back
+    whole for the mesh-error estimate and the next mesh -- the reference's hypersensitive objective (rtol 1e-5) and the
+    single-process run's, mesh for mesh."""
+    script = tmp_path / "ocp_two_ranks.py"
+    script.write_text(_OCP_TWO_RANKS)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), IPM_LOG=str(tmp_path / "trace"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100)
+    out = res.stdout + res.stderr
+    traces = "".join(p.read_text() for p in tmp_path.glob("trace.*"))
+    lines = "\n".join(ln for ln in out.splitlines() if "SHARDED OCP" in ln)
+    assert res.returncode == 0, traces + lines + out[-1500:]
+    assert out.count("ok: True") == 2, lines
+    _keep(lines, "sharded_ocp_2_ranks.txt")
