@@ -17,8 +17,9 @@ spent on the collocation structure (no fill-reducing heuristic, no pivot search)
                   other only through separators, so all leaves are eliminated at once (one workgroup each, dense).
   chain node      the section boundary node between two leaves (its z, path slacks / multipliers) and the defect
   (p, k)          multipliers of the rows that end on it.  After the leaves are gone these nodes form a
-                  block-tridiagonal chain per phase, eliminated in order by one workgroup per phase -- the only
-                  sequential part, which is why g > 1: g sections per leaf divide its length by g.
+                  block-tridiagonal chain per phase, eliminated by cyclic reduction (log2 of its length levels, tables
+                  in csrc/pc_kkt_cr.hpp; node by node in one workgroup per phase where a block is too large for the
+                  level kernels) -- the only sequential part, which is why g > 1: g sections per leaf divide its length.
   border          everything global: integrals q, free times, static parameters, integral and endpoint multipliers,
                   endpoint slacks, and any endpoint variable an endpoint Hessian term couples across nodes.  Dense,
                   factorised last.
