@@ -1498,7 +1498,11 @@ static void factor_device(pc_kkt* k, int use_hess, const double* d_dvec, int32_t
     if (k->n_leaf) {
       KArgs la = k->args;
       la.lds_doubles = k->lds_leaf_full / 8;
-      hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(128), k->lds_leaf_full, st, la);
+      // four waves per leaf: 0.246 -> 0.221 ms per factorisation at config 2, 0.644 -> 0.594 at config 3 against two (the
+      // trailing update of a pivot step is the parallel part); one wave with LDS-only ordering 0.30 / 0.75, six or eight waves
+      // no better than four and 4 % worse on the shuttle's blocks (profiles/r04_ipm_iter_time.txt)
+      static const int leaf_waves = std::getenv("PYCOLLO_AMD_KKT_LEAF_WAVES") ? std::max(1, std::min(16, std::atoi(std::getenv("PYCOLLO_AMD_KKT_LEAF_WAVES")))) : 4;
+      hipLaunchKernelGGL(kkt_leaf_factor, dim3(k->n_leaf), dim3(64 * leaf_waves), k->lds_leaf_full, st, la);
     }
     if (k->chain_cr) cr_levels_device<0>(k);
     else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_factor, dim3(k->n_phase), dim3(64), k->lds_chain_factor, st, k->args);
