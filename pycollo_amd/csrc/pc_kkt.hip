@@ -806,6 +806,13 @@ __global__ void kkt_leaf_forward(KArgs a) {
   const double* M = a.vals + a.leafA_off[l];
   double* rl = a.r + a.leaf_ptr[l];
   for (int i = tid; i < m; i += nt) lds[i] = rl[i];
+  // a factored leaf that fits the workgroup's LDS is solved from there: the substitution is 2 m dependent steps, each a
+  // column of L -- from device memory a strided, uncoalesced read per step (27 us a leaf pass at config 2), from LDS not
+  if (m * ld + m <= a.lds_doubles) {
+    double* Ml = lds + m;
+    for (int e = tid; e < m * ld; e += nt) Ml[e] = M[e];
+    M = Ml;
+  }
   __syncthreads();
   double* g = a.leafG + a.leafG_off[l];
   for (int c = tid; c < w; c += nt) {   // X_C^T r_l
@@ -1039,7 +1046,15 @@ static void forward_device(pc_kkt* k, const double* d_rhs) {
   hipStream_t st = k->stream;
   const unsigned nbk = (unsigned)((k->nu + 255) / 256);
   hipLaunchKernelGGL(kkt_perm_in, dim3(nbk), dim3(256), 0, st, d_rhs, k->perm.p, k->fixed.p, k->r.p, k->nu);
-  if (k->n_leaf) hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(64), k->lds_leaf, st, k->args);
+  if (k->n_leaf) {
+    // (two waves and the leaf in LDS: pc_kkt_solve 0.199 -> 0.183 ms at config 2, 0.425 -> 0.410 at config 3; with the shuttle's
+    //  6 000 leaves the LDS costs occupancy and the solve got slower, 0.63 -> 0.65-0.71: staged up to 4 096 leaves)
+    static const int stage_env = std::getenv("PYCOLLO_AMD_KKT_LEAF_FWD_LDS") ? std::atoi(std::getenv("PYCOLLO_AMD_KKT_LEAF_FWD_LDS")) : -1;
+    const int stage = stage_env >= 0 ? stage_env : (k->n_leaf <= 4096 ? 2 : 0);
+    KArgs la = k->args;
+    la.lds_doubles = stage ? k->lds_leaf_full / 8 : 0;     // (0: solve from device memory, the A/B switch)
+    hipLaunchKernelGGL(kkt_leaf_forward, dim3(k->n_leaf), dim3(stage > 1 ? 64 * stage : 64), stage ? k->lds_leaf_full : k->lds_leaf, st, la);
+  }
   if (k->chain_cr) cr_levels_device<1>(k);
   else if (k->n_phase) hipLaunchKernelGGL(kkt_chain_forward, dim3(k->n_phase), dim3(64), k->lds_chain, st, k->args);
 }
